@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE in the build container.
+
+    cd /root/repo && python tests/golden/make_golden.py
+
+The reference (/root/reference, read-only) is imported through oracle/ref_harness.py; nothing of it
+is copied.  Each fixture is data only: the effective env config (JSON), the per-house / per-env
+parameters the reference sampled at reset, the action sequence that was fed, the outdoor temperature
+the reference drew each step, and the reference's outputs after every step.
+
+Scenario list follows SURVEY.md section 8c (S1..S6) plus a Perlin-wiring and a phase-offset case.
+"""
+from __future__ import annotations
+
+import copy
+import json
+import os
+import random
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from oracle import ref_harness  # noqa: E402
+from oracle import mdr_oracle as mo  # noqa: E402
+
+ENV_KEYS = ("default_house_prop", "noise_house_prop", "noise_house_prop_test", "default_hvac_prop",
+            "noise_hvac_prop", "noise_hvac_prop_test", "default_env_prop")
+
+
+def patch(cfg, dotted, value):
+    node = cfg
+    parts = dotted.split(".")
+    for p in parts[:-1]:
+        node = node[p]
+    node[parts[-1]] = value
+
+
+def jsonable(obj):
+    if isinstance(obj, dict):
+        return {str(k): jsonable(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [jsonable(v) for v in obj]
+    if isinstance(obj, (np.integer,)):
+        return int(obj)
+    if isinstance(obj, (np.floating,)):
+        return float(obj)
+    return obj
+
+
+def epoch(d):
+    return mo.to_epoch_seconds(d)
+
+
+def capture_state(env):
+    hs = [env.cluster.houses[i] for i in env.agent_ids]
+    return dict(
+        Ta=np.array([h.current_temp for h in hs], dtype=np.float64),
+        Tm=np.array([h.current_mass_temp for h in hs], dtype=np.float64),
+        on=np.array([bool(h.hvac.turned_on) for h in hs], dtype=np.uint8),
+        lock=np.array([bool(h.hvac.lockout) for h in hs], dtype=np.uint8),
+        sso=np.array([h.hvac.seconds_since_off for h in hs], dtype=np.int32),
+    )
+
+
+def capture_params(env):
+    hs = [env.cluster.houses[i] for i in env.agent_ids]
+    g = lambda fn, dt=np.float64: np.array([fn(h) for h in hs], dtype=dt)
+    return dict(
+        p_Ta=g(lambda h: h.current_temp), p_Tm=g(lambda h: h.current_mass_temp),
+        p_target=g(lambda h: h.target_temp), p_deadband=g(lambda h: h.deadband),
+        p_Ua=g(lambda h: h.Ua), p_Cm=g(lambda h: h.Cm), p_Ca=g(lambda h: h.Ca), p_Hm=g(lambda h: h.Hm),
+        p_capacity=g(lambda h: h.hvac.cooling_capacity), p_COP=g(lambda h: h.hvac.COP),
+        p_latent=g(lambda h: h.hvac.latent_cooling_fraction),
+        p_lockout=g(lambda h: h.hvac.lockout_duration, np.int64),
+        p_t0=np.int64(epoch(env.start_datetime)), p_phase=np.float64(env.cluster.phase),
+        p_ratio=np.float64(env.power_grid.artificial_ratio), p_max_power=np.float64(env.power_grid.max_power),
+    )
+
+
+def run_scenario(name, patches, seed, T, policy, perlin=False, norm_steps=(0, 1, -1)):
+    ref = ref_harness.load_reference()
+    cfg = copy.deepcopy({k: ref["config_dict"][k] for k in ENV_KEYS})
+    patch(cfg, "default_env_prop.power_grid_prop.base_power_mode", "constant")  # the interpolation grid is a missing blob
+    for k, v in patches.items():
+        patch(cfg, k, v)
+    N = cfg["default_env_prop"]["cluster_prop"]["nb_agents"]
+    if perlin:
+        # the lattice the oracle itself defines for (seed, env 0, episode 0)
+        k0, k1 = mo.seed_key(seed)
+        ref_harness.set_perlin_gradient(
+            lambda l: 2.0 * mo.u01(mo.philox4x32_10(0, np.asarray(l, dtype=np.int64) & 0xFFFFFFFF, 0, mo.TAG_PERLIN, k0, k1)[0]) - 1.0)
+    else:
+        ref_harness.set_perlin_gradient(None)
+    random.seed(seed)
+    np.random.seed(seed)
+    env = ref["MADemandResponseEnv"](cfg)
+    obs = env.reset()
+    rec = capture_params(env)
+    od = [env.cluster.current_OD_temp]
+    S = [float(env.power_grid.current_signal)]
+    act_rng = np.random.default_rng(seed + 1000)
+    actors = {i: ref["BangBangController"]({"id": i}, cfg) for i in range(N)}
+    norm = []
+    want_norm = set(s if s >= 0 else T + 1 + s for s in norm_steps)
+    if 0 in want_norm:
+        norm.append(np.array([ref["utils"].normStateDict(obs[i], cfg) for i in range(N)]))
+    keys = ("Ta", "Tm", "on", "lock", "sso")
+    out = {k: [] for k in keys}
+    out.update(P=[], reward=[], solar=[], actions=[])
+    for t in range(T):
+        if policy == "bangbang":
+            a = ref["utils"].get_actions(actors, obs)
+        elif policy == "on":
+            a = {i: True for i in range(N)}
+        elif policy == "off":
+            a = {i: False for i in range(N)}
+        elif policy == "onoff":      # long on / long off blocks: walks through every lockout edge
+            a = {i: bool(((t + 3 * i) // 7) % 2) for i in range(N)}
+        elif policy.startswith("random"):
+            p = float(policy.split(":")[1]) if ":" in policy else 0.5
+            r = act_rng.random(N)
+            a = {i: int(r[i] < p) for i in range(N)}     # ints, as Categorical.sample().item() gives
+        elif policy == "mixed":      # bang-bang with 20 % random flips
+            bb = ref["utils"].get_actions(actors, obs)
+            r = act_rng.random(N)
+            a = {i: (not bb[i]) if r[i] < 0.2 else bb[i] for i in range(N)}
+        else:
+            raise ValueError(policy)
+        out["actions"].append(np.array([bool(a[i]) for i in range(N)], dtype=np.uint8))
+        obs, rew, done, info = env.step(a)
+        st = capture_state(env)
+        for k in keys:
+            out[k].append(st[k])
+        out["P"].append(float(info["cluster_hvac_power"]))
+        out["reward"].append(np.array([rew[i] for i in range(N)], dtype=np.float64))
+        out["solar"].append(float(env.cluster.houses[0].current_solar_gain))
+        od.append(env.cluster.current_OD_temp)
+        S.append(float(env.power_grid.current_signal))
+        assert not any(done.values())
+        if (t + 1) in want_norm:
+            norm.append(np.array([ref["utils"].normStateDict(obs[i], cfg) for i in range(N)]))
+    meta = dict(name=name, seed=seed, T=T, N=N, policy=policy, perlin_standin=bool(perlin),
+                norm_steps=sorted(want_norm), config=jsonable(cfg),
+                generated_by="tests/golden/make_golden.py from /root/reference (snapshot 2025-03-14)")
+    arrays = dict(rec)
+    arrays.update({k: np.array(v) for k, v in out.items()})
+    arrays["od"] = np.array(od, dtype=np.float64)
+    arrays["S"] = np.array(S, dtype=np.float64)
+    arrays["norm_state"] = np.array(norm, dtype=np.float64)
+    arrays["meta"] = np.array(json.dumps(meta))
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("%-28s N=%-3d T=%-5d  sum(reward)=%.9f  %6.1f KB" % (
+        name, N, T, float(np.sum(arrays["reward"])), os.path.getsize(path) / 1024))
+    return arrays
+
+
+CL = "default_env_prop.cluster_prop."
+PG = "default_env_prop.power_grid_prop."
+RW = "default_env_prop.reward_prop."
+
+
+def main():
+    ref = ref_harness.load_reference()
+    # config snapshot (values only) so the product's own default_config() can be checked on any box
+    with open(os.path.join(OUT, "reference_env_config.json"), "w") as f:
+        json.dump(jsonable({k: ref["config_dict"][k] for k in ENV_KEYS}), f, indent=1, sort_keys=True)
+
+    # S1: BASELINE config 1 - 1 env x 10 houses, default noise, random start, bang-bang
+    a = run_scenario("s1_c1_sinusoidals", {CL + "nb_agents": 10, PG + "signal_mode": "sinusoidals"}, 1, 1000, "bangbang")
+    # anchor digits recorded in SURVEY.md section 8c
+    assert abs(float(a["reward"].sum()) - (-22544.136763550)) < 1e-6, float(a["reward"].sum())
+    run_scenario("s1_c1_flat", {CL + "nb_agents": 10, PG + "signal_mode": "flat"}, 2, 300, "bangbang")
+    run_scenario("s1_c1_regular_steps", {CL + "nb_agents": 10, PG + "signal_mode": "regular_steps"}, 3, 300, "bangbang")
+    # S2: BASELINE config 2's shape - fixed OD temp, no noise, uniform houses, random actions
+    run_scenario("s2_c2_uniform", {
+        CL + "nb_agents": 50, CL + "temp_mode": "constant", "noise_house_prop.noise_mode": "no_noise",
+        "default_env_prop.start_datetime_mode": "fixed", "default_env_prop.start_datetime": "2021-06-15 12:00:00",
+        "default_house_prop.solar_gain_bool": False, PG + "signal_mode": "flat"}, 1234, 500, "random:0.5")
+    # S3: BASELINE config 3's shape - heterogeneous houses and HVACs, noisy OD temp, solar edge at 07:30
+    run_scenario("s3_c3_heterogeneous", {
+        CL + "nb_agents": 64, "noise_house_prop.noise_mode": "house_big_noise", "noise_hvac_prop.noise_mode": "big_noise",
+        "default_hvac_prop.lockout_noise": 20, "default_house_prop.deadband": 1,
+        "default_env_prop.start_datetime_mode": "fixed", "default_env_prop.start_datetime": "2021-07-14 07:10:00",
+        PG + "signal_mode": "sinusoidals"}, 7, 600, "mixed")
+    run_scenario("s3_big_noise_random_start", {
+        CL + "nb_agents": 24, "noise_house_prop.noise_mode": "big_noise", "noise_hvac_prop.noise_mode": "small_noise",
+        PG + "signal_mode": "regular_steps", PG + "artificial_signal_ratio_range": 3}, 11, 400, "mixed")
+    # S4: every temperature-penalty mode
+    for mode in ("individual_L2", "common_L2", "common_max", "mixture"):
+        p = {CL + "nb_agents": 12, RW + "temp_penalty_mode": mode, "default_house_prop.deadband": 1,
+             "noise_house_prop.noise_mode": "big_noise", PG + "signal_mode": "sinusoidals",
+             RW + "alpha_temp": 0.7, RW + "alpha_sig": 1.3}
+        if mode == "mixture":
+            p[RW + "temp_penalty_parameters.mixture"] = {"alpha_ind_L2": 1, "alpha_common_L2": 2, "alpha_common_max": 0.5}
+        run_scenario("s4_penalty_" + mode, p, 21, 60, "mixed")
+    # S5: year-end rollover
+    run_scenario("s5_year_rollover", {
+        CL + "nb_agents": 12, "noise_house_prop.noise_mode": "house_big_noise",
+        "default_env_prop.start_datetime_mode": "fixed", "default_env_prop.start_datetime": "2021-12-31 23:50:00",
+        PG + "signal_mode": "flat"}, 5, 300, "mixed")
+    # leap day (2024-02-28 23:55 -> 02-29): calendar arithmetic feeds the solar polynomial's y term
+    run_scenario("s5_leap_day_noon", {
+        CL + "nb_agents": 8, "default_env_prop.start_datetime_mode": "fixed",
+        "default_env_prop.start_datetime": "2024-02-29 11:58:00", PG + "signal_mode": "flat"}, 6, 120, "bangbang")
+    # S6: lockout edges
+    for pol in ("on", "off", "onoff"):
+        run_scenario("s6_lockout_" + pol, {CL + "nb_agents": 8, "default_hvac_prop.lockout_noise": 10,
+                                           "default_hvac_prop.lockout_duration": 30, PG + "signal_mode": "flat"}, 31, 100, pol)
+    # time step other than 4 s and a lockout that is not a multiple of it
+    run_scenario("s6_dt7_lockout45", {CL + "nb_agents": 8, "default_env_prop.time_step": 7,
+                                      "default_hvac_prop.lockout_duration": 45, PG + "signal_mode": "sinusoidals"}, 32, 150, "onoff")
+    # S7: Perlin wiring with this build's lattice as the stand-in for the absent third-party package
+    run_scenario("s7_perlin_wiring", {CL + "nb_agents": 16, PG + "signal_mode": "perlin",
+                                      PG + "artificial_signal_ratio_range": 3}, 41, 400, "bangbang", perlin=True)
+    run_scenario("s7_fastpp_perlin_wiring", {CL + "nb_agents": 16, PG + "signal_mode": "fast++_perlin"}, 42, 200, "mixed", perlin=True)
+    # S8: random phase offset of the outdoor sinusoid
+    run_scenario("s8_phase_offset", {CL + "nb_agents": 8, CL + "temp_mode": "shifting_sinusoidal_heatwave",
+                                     PG + "signal_mode": "flat"}, 51, 200, "bangbang")
+    # N == 1 (config.py's literal default nb_agents) and no neighbours
+    run_scenario("s9_single_house", {CL + "nb_agents": 1, PG + "signal_mode": "sinusoidals"}, 61, 200, "bangbang")
+
+
+if __name__ == "__main__":
+    main()
