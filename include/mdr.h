@@ -1,0 +1,209 @@
+/*
+ * mdr.h - C ABI of the MI355X-native batched demand-response environment step.
+ *
+ * Drop-in boundary for ONE hot path of zhimaerfan/marl-demandresponse-original:
+ * MADemandResponseEnv.reset()/step() (env/MA_DemandResponse.py:135-210 of the reference)
+ * for E independent environments x N houses at once.  The reference has no FFI of its
+ * own (it is pure Python); these entry points are what a ctypes binding inside the
+ * reference's env module would call (INTEGRATION.md shows that stub).
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, PODs.  No torch / C++ types cross this boundary.
+ *   - every buffer is CALLER-OWNED DEVICE memory (hipMalloc'ed / a torch tensor's data_ptr());
+ *     the library allocates nothing on the device and nothing per step.
+ *   - every call is asynchronous on the hipStream_t passed as `stream` (void* here so that C
+ *     callers need no HIP headers); no hidden synchronisation.
+ *   - every function returns an mdr_status (0 = OK, negative = error); nothing throws.
+ *   - a handle is not thread-safe; distinct handles are independent.
+ *   - temperatures in device buffers are stored RELATIVE to mdr_config.temp_ref (deg C), see DESIGN.md.
+ *
+ * Layout: all per-house arrays are row-major [nb_envs][nb_houses] (house index fastest).
+ */
+#ifndef MDR_H
+#define MDR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDR_ABI_VERSION 1
+#define MDR_MAX_SINUSOIDS 8
+#define MDR_MAX_CAPACITIES 16
+#define MDR_OBS_COLUMNS 7
+
+typedef struct mdr_env mdr_env_t; /* opaque handle */
+
+typedef enum mdr_status {
+  MDR_OK = 0,
+  MDR_ERR_INVALID = -1,     /* bad argument / inconsistent config (ValueError in the reference) */
+  MDR_ERR_UNBOUND = -2,     /* buffers not bound, or episode not started */
+  MDR_ERR_HIP = -3,         /* a HIP runtime call failed; see mdr_last_error() */
+  MDR_ERR_UNSUPPORTED = -4  /* shape/mode combination this build has no kernel for */
+} mdr_status;
+
+/* PowerGrid.step signal families, env/MA_DemandResponse.py:1257-1310 */
+typedef enum mdr_signal_mode {
+  MDR_SIGNAL_FLAT = 0,
+  MDR_SIGNAL_SINUSOIDALS = 1,
+  MDR_SIGNAL_REGULAR_STEPS = 2,
+  MDR_SIGNAL_PERLIN = 3
+} mdr_signal_mode;
+
+/* compute_temp_penalty modes, env/MA_DemandResponse.py:263-326 */
+typedef enum mdr_penalty_mode {
+  MDR_PENALTY_INDIVIDUAL_L2 = 0,
+  MDR_PENALTY_COMMON_L2 = 1,
+  MDR_PENALTY_COMMON_MAX = 2,
+  MDR_PENALTY_MIXTURE = 3
+} mdr_penalty_mode;
+
+typedef enum mdr_action_source {
+  MDR_ACTIONS_EXTERNAL = 0, /* read uint8 actions[E][N] (truthy = ON), ClusterHouses.step 1026-1033 */
+  MDR_ACTIONS_BANGBANG = 1  /* on iff house_temp > target (agents/bangbang_controllers.py:41-61),
+                               evaluated in-kernel on the pre-step observation; the chosen action is
+                               written to actions[E][N] when that pointer is not NULL */
+} mdr_action_source;
+
+/* Flat restatement of the config.py entries the path consumes. */
+typedef struct mdr_config {
+  uint32_t struct_size;            /* sizeof(mdr_config_t), ABI guard */
+  int32_t nb_envs;                 /* E on this device */
+  int32_t nb_houses;               /* N on this device (== nb_houses_total unless houses are sharded) */
+  int64_t nb_houses_total;         /* nb_agents of the whole env: reward / signal normalisation */
+  int64_t env_offset;              /* global index of local env 0: RNG streams are partition invariant */
+  int64_t house_offset;            /* global index of local house 0 */
+  int32_t time_step;               /* seconds, default_env_prop.time_step */
+  int32_t table_steps;             /* K: per-env time tables are (re)built K steps at a time (>=1) */
+  double temp_ref;                 /* deg C; device temperatures are stored relative to it */
+  /* default_house_prop (config.py:12-26) */
+  double init_air_temp, init_mass_temp, target_temp, deadband;
+  double Ua, Cm, Ca, Hm;
+  double window_area, shading_coeff;
+  int32_t solar_gain;              /* solar_gain_bool */
+  /* default_hvac_prop (config.py:130-138) */
+  int32_t lockout_duration, lockout_noise;
+  double COP, cooling_capacity, latent_cooling_fraction;
+  /* noise_house_prop / noise_hvac_prop of the selected noise_mode (config.py:27-170) */
+  double std_start_temp, std_target_temp, factor_thermo_low, factor_thermo_high;
+  int32_t nb_capacities;
+  int32_t start_random;            /* start_datetime_mode == "random" */
+  double capacity_list[MDR_MAX_CAPACITIES];
+  int64_t start_epoch;             /* start_datetime as naive seconds since 1970-01-01 */
+  /* cluster_prop.temp_parameters[temp_mode] (config.py:206-291) */
+  double day_temp, night_temp, temp_std;
+  int32_t random_phase_offset;
+  /* power_grid_prop (config.py:324-396); base_power_mode "constant" only */
+  int32_t signal_mode;             /* mdr_signal_mode */
+  double avg_power_per_hvac;
+  int32_t nb_sinusoids;
+  int32_t perlin_nb_octaves;
+  double sin_periods[MDR_MAX_SINUSOIDS];
+  double sin_amplitude_ratios[MDR_MAX_SINUSOIDS];
+  double steps_amplitude_per_hvac, steps_period;
+  double perlin_amplitude, perlin_octaves_step, perlin_period;
+  double artificial_ratio, artificial_signal_ratio_range;
+  /* reward_prop (config.py:397-421) */
+  double alpha_temp, alpha_sig;
+  double norm_temp_penalty;        /* deadbandL2(T0, 0, T0+1), env 346-350 */
+  double norm_sig_penalty;         /* deadbandL2(R, 0, 0.75 R), env 352-356 */
+  int32_t penalty_mode;            /* mdr_penalty_mode */
+  int32_t reserved0;
+  double mix_ind_L2, mix_common_L2, mix_common_max;
+  /* normStateDict: reg_signal and cluster_hvac_power are divided by norm_reg_sig * nb_agents (utils.py:832-841) */
+  double obs_power_norm;
+} mdr_config_t;
+
+/* Caller-owned device buffers.  [E][N] unless noted. */
+typedef struct mdr_buffers {
+  uint32_t struct_size;
+  uint32_t reserved0;
+  /* state, read+written every step */
+  float *Ta, *Tm;                  /* indoor air / mass temperature minus temp_ref */
+  int32_t *sso;                    /* HVAC seconds_since_off */
+  uint8_t *flags;                  /* bit0 turned_on, bit1 lockout */
+  /* derived per-episode parameters, read every step (written by reset / load_episode) */
+  float *k01, *s0, *k10, *s1;      /* thermal map, difference form (DESIGN.md "Thermal update") */
+  float *inv_Ua, *Q_hvac, *P_max;  /* 1/Ua ; -cap/(1+latent) ; cap/COP */
+  float *target, *deadband;        /* target minus temp_ref ; deadband */
+  int32_t *lockout;                /* lockout_duration incl. noise */
+  /* raw per-episode parameters (static observation columns), written by reset / load_episode */
+  float *Ua, *Cm, *Ca, *Hm, *capacity, *COP, *latent;
+  /* outputs, written every step */
+  float *reward;
+  float *obs;                      /* [MDR_OBS_COLUMNS][E][N] planes: (Ta-20)/5, (Tm-20)/5, on, lock,
+                                      sso/lockout, reg_signal/norm, cluster_hvac_power/norm */
+  /* per env, [E] */
+  int64_t *t0;                     /* episode start, epoch seconds */
+  double *phase, *ratio, *max_power;
+  double *P;                       /* cluster_hvac_power after the last step */
+  double *tot_sum;                 /* [2][E]: local sum of HVAC power, local sum of temperature penalties */
+  double *tot_max;                 /* [E]: local max of temperature penalties */
+  /* per-env time tables, [(table_steps+1)][E], row r <-> time index j0 + r */
+  float *tab_od;                   /* outdoor temperature minus temp_ref */
+  float *tab_solar;                /* window_area * shading_coeff * SCL, W */
+  double *tab_signal;              /* regulation signal, W */
+  /* scratch for the split (multi-workgroup per env) path: [E][mdr_partials_per_env()][3] */
+  double *partials;
+} mdr_buffers_t;
+
+/* Raw episode parameters for mdr_env_load_episode (replay of an episode sampled elsewhere).
+ * Device pointers, fp64, [E][N] / [E]; temperatures in deg C (NOT relative). */
+typedef struct mdr_episode {
+  uint32_t struct_size;
+  uint32_t reserved0;
+  const double *Ta, *Tm, *target, *deadband, *Ua, *Cm, *Ca, *Hm, *capacity, *COP, *latent;
+  const int64_t *lockout;
+  const int64_t *t0;
+  const double *phase, *ratio;
+} mdr_episode_t;
+
+int mdr_abi_version(void);
+const char *mdr_status_string(int status);
+/* Last error text of a handle ("" if none); valid until the next call on that handle. */
+const char *mdr_last_error(const mdr_env_t *env);
+
+/* Number of per-env partial records the split path needs for (nb_houses): size `partials` with it. */
+int64_t mdr_partials_per_env(int32_t nb_houses);
+
+/* MADemandResponseEnv.__init__ (env 73-96) minus build_environment: validates and stores the config. */
+int mdr_env_create(const mdr_config_t *config, mdr_env_t **out);
+int mdr_env_destroy(mdr_env_t *env);
+int mdr_env_bind(mdr_env_t *env, const mdr_buffers_t *buffers);
+
+/* build_environment, part 1 (env 98-123; utils.applyPropertyNoise 573-709): sample every per-house and
+ * per-env episode parameter on the device from Philox4x32-10 streams keyed by (seed, episode), derive the
+ * kernel coefficients, initialise the state (HVAC off, not locked, sso = lockout: env 432-434) and leave
+ * the LOCAL sum of max consumption in max_power[E] (env 796-802). */
+int mdr_env_reset(mdr_env_t *env, uint64_t seed, uint32_t episode, void *stream);
+/* Same, but from caller-supplied raw parameters instead of sampling. */
+int mdr_env_load_episode(mdr_env_t *env, const mdr_episode_t *episode, uint64_t seed, uint32_t episode_index,
+                         void *stream);
+/* Optional: replace the modelled outdoor temperature by a table, double [rows][E] deg C (row = time index);
+ * NULL restores the model.  Takes effect at the next mdr_env_begin_episode / table refill. */
+int mdr_env_set_od_table(mdr_env_t *env, const double *od_table, int64_t rows);
+/* build_environment, part 2 (env 125-133): with max_power[E] final (all-reduced by the caller when houses
+ * are sharded), build the time tables from time index 0: OD temp (env 793), initial signal (env 133). */
+int mdr_env_begin_episode(mdr_env_t *env, void *stream);
+
+/* MADemandResponseEnv.step (env 174-210), whole step on this device. */
+int mdr_env_step(mdr_env_t *env, uint8_t *actions, int action_source, void *stream);
+/* `nb_steps` consecutive steps without returning to the host (device-resident rollout). */
+int mdr_env_rollout(mdr_env_t *env, uint8_t *actions, int action_source, int32_t nb_steps, void *stream);
+
+/* Sharded houses (one env spans several devices): step_begin updates the local houses and leaves the local
+ * reductions in tot_sum/tot_max; the caller all-reduces them (SUM / MAX); step_end writes rewards and the
+ * two power observation columns from the reduced values. */
+int mdr_env_step_begin(mdr_env_t *env, uint8_t *actions, int action_source, void *stream);
+int mdr_env_step_end(mdr_env_t *env, void *stream);
+
+/* Cursor: k = number of steps taken this episode; j0 = time index of table row 0. */
+int mdr_env_cursor(const mdr_env_t *env, int64_t *k, int64_t *j0);
+/* Re-create a cursor on a new handle whose buffers were cloned from another env (copy.deepcopy support). */
+int mdr_env_set_cursor(mdr_env_t *env, uint64_t seed, uint32_t episode, int64_t k, int64_t j0);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDR_H */

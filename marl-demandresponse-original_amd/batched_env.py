@@ -1,0 +1,352 @@
+"""Tensor API: E independent demand-response environments x N houses stepped by one HIP launch.
+
+Host-side mirror of ``MADemandResponseEnv`` (env/MA_DemandResponse.py:37-390 of the reference) for a batch of
+environments.  PyTorch-ROCm is plumbing only: it owns the device memory (one slab per env batch) and the
+stream; all arithmetic happens in libmdr_hip.so through the C ABI of include/mdr.h.
+
+    env = BatchedDemandResponseEnv(config, nb_envs=4096, device="cuda:0", seed=2024)
+    obs = env.reset()                                   # float32 [7, E, N] observation planes
+    obs, reward, done, info = env.step(actions)         # actions: uint8/bool [E, N] on the device
+    env.rollout(1000)                                   # 1000 fused bang-bang steps, no host round trip
+
+When one environment's houses are sharded over several devices (``house_shard=(offset, count)``) the step
+is split around an all-reduce of the per-env aggregates (cluster power, penalty sum / max) over
+``torch.distributed`` (RCCL on ROCm); independent env replicas need no collective at all.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from .config import EnvSpec, flatten_config, from_epoch_seconds
+
+OBS_COLUMNS = ("house_temp", "house_mass_temp", "hvac_turned_on", "hvac_lockout",
+               "hvac_seconds_since_off", "reg_signal", "cluster_hvac_power")
+
+_HOUSE_F32 = ("Ta", "Tm", "k01", "s0", "k10", "s1", "inv_Ua", "Q_hvac", "P_max", "target", "deadband",
+              "Ua", "Cm", "Ca", "Hm", "capacity", "COP", "latent", "reward")
+_HOUSE_I32 = ("sso", "lockout")
+_HOUSE_U8 = ("flags", "actions")
+_EPISODE_F64 = ("Ta", "Tm", "target", "deadband", "Ua", "Cm", "Ca", "Hm", "capacity", "COP", "latent")
+
+
+def _align(x: int, a: int) -> int:
+    return (x + a - 1) // a * a
+
+
+class BatchedDemandResponseEnv:
+    def __init__(self, config: dict, nb_envs: int = 1, device=None, seed: int = 0, test: bool = False,
+                 table_steps: int = 64, env_offset: int = 0,
+                 house_shard: Optional[Tuple[int, int]] = None, process_group=None,
+                 stagger_bytes: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchedDemandResponseEnv needs a ROCm device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self._lib = nat.load()
+        self.config = config
+        self.test = test
+        self.spec: EnvSpec = flatten_config(config, test=test)
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self.nb_envs = int(nb_envs)
+        self.nb_agents = self.spec.nb_houses_total
+        self.house_offset, self.nb_houses = (0, self.nb_agents) if house_shard is None else map(int, house_shard)
+        self.sharded = house_shard is not None and self.nb_houses != self.nb_agents
+        self.process_group = process_group
+        self.env_offset = int(env_offset)
+        self.table_steps = int(table_steps)
+        self.seed = int(seed)
+        self.episode = -1
+        self._od_table = None
+        self._stagger = int(stagger_bytes)
+        self._handle = C.c_void_p()
+        self._cfg = self._make_config()
+        rc = self._lib.mdr_env_create(C.byref(self._cfg), C.byref(self._handle))
+        try:
+            nat.check(self._lib, self._handle, rc, "mdr_env_create")
+        except Exception:
+            self._lib.mdr_env_destroy(self._handle)
+            self._handle = C.c_void_p()
+            raise
+        self._allocate()
+        self._bind()
+        self.done = torch.zeros((self.nb_envs, self.nb_houses), dtype=torch.bool, device=self.device)
+
+    # ------------------------------------------------------------------ setup
+    def _make_config(self) -> nat.MdrConfig:
+        s = self.spec
+        c = nat.MdrConfig()
+        c.struct_size = C.sizeof(nat.MdrConfig)
+        c.nb_envs, c.nb_houses, c.nb_houses_total = self.nb_envs, self.nb_houses, s.nb_houses_total
+        c.env_offset, c.house_offset = self.env_offset, self.house_offset
+        c.time_step, c.table_steps, c.temp_ref = s.time_step, self.table_steps, s.temp_ref
+        for name in ("init_air_temp", "init_mass_temp", "target_temp", "deadband", "Ua", "Cm", "Ca", "Hm",
+                     "window_area", "shading_coeff", "lockout_duration", "lockout_noise", "COP", "cooling_capacity",
+                     "latent_cooling_fraction", "std_start_temp", "std_target_temp", "factor_thermo_low",
+                     "factor_thermo_high", "start_epoch", "day_temp", "night_temp", "temp_std", "signal_mode",
+                     "avg_power_per_hvac", "steps_amplitude_per_hvac", "steps_period", "perlin_amplitude",
+                     "perlin_nb_octaves", "perlin_octaves_step", "perlin_period", "artificial_ratio",
+                     "artificial_signal_ratio_range", "alpha_temp", "alpha_sig", "norm_temp_penalty",
+                     "norm_sig_penalty", "penalty_mode", "mix_ind_L2", "mix_common_L2", "mix_common_max",
+                     "obs_power_norm"):
+            setattr(c, name, getattr(s, name))
+        c.solar_gain = int(s.solar_gain)
+        c.start_random = int(s.start_random)
+        c.random_phase_offset = int(s.random_phase_offset)
+        if len(s.capacity_list) > nat.MDR_MAX_CAPACITIES:
+            raise ValueError("cooling_capacity_list longer than %d" % nat.MDR_MAX_CAPACITIES)
+        c.nb_capacities = len(s.capacity_list)
+        for i, v in enumerate(s.capacity_list):
+            c.capacity_list[i] = v
+        if len(s.sin_periods) > nat.MDR_MAX_SINUSOIDS:
+            raise ValueError("more than %d sinusoids" % nat.MDR_MAX_SINUSOIDS)
+        c.nb_sinusoids = len(s.sin_periods)
+        for i, (p, r) in enumerate(zip(s.sin_periods, s.sin_amplitude_ratios)):
+            c.sin_periods[i], c.sin_amplitude_ratios[i] = p, r
+        return c
+
+    def _layout(self):
+        E, N, K1 = self.nb_envs, self.nb_houses, self.table_steps + 1
+        nblk = int(self._lib.mdr_partials_per_env(N))
+        items = [(n, torch.float32, (E, N)) for n in _HOUSE_F32]
+        items += [(n, torch.int32, (E, N)) for n in _HOUSE_I32]
+        items += [(n, torch.uint8, (E, N)) for n in _HOUSE_U8]
+        items += [("obs", torch.float32, (nat.MDR_OBS_COLUMNS, E, N))]
+        items += [("t0", torch.int64, (E,))] + [(n, torch.float64, (E,)) for n in ("phase", "ratio", "max_power", "P", "tot_max")]
+        items += [("tot_sum", torch.float64, (2, E))]
+        items += [("tab_od", torch.float32, (K1, E)), ("tab_solar", torch.float32, (K1, E)), ("tab_signal", torch.float64, (K1, E))]
+        items += [("partials", torch.float64, (E, nblk, 3))]
+        return items
+
+    def _allocate(self):
+        """One device slab; every array 256-byte aligned (optionally staggered so that the ~27 concurrently
+        streamed arrays do not all start on the same HBM channel)."""
+        items = self._layout()
+        offsets, off = {}, 0
+        for idx, (name, dtype, shape) in enumerate(items):
+            off = _align(off, 256) + (self._stagger * (idx % 16))
+            off = _align(off, 256)
+            nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+            offsets[name] = (off, nbytes, dtype, shape)
+            off += nbytes
+        self._slab = torch.zeros(_align(off, 256), dtype=torch.uint8, device=self.device)
+        self.t: Dict[str, torch.Tensor] = {}
+        for name, (o, nbytes, dtype, shape) in offsets.items():
+            self.t[name] = self._slab[o:o + nbytes].view(dtype).view(*shape)
+
+    def _bind(self):
+        b = nat.MdrBuffers()
+        b.struct_size = C.sizeof(nat.MdrBuffers)
+        for fname, _ in nat.MdrBuffers._fields_:
+            if fname in ("struct_size", "reserved0"):
+                continue
+            setattr(b, fname, self.t[fname].data_ptr())
+        self._buffers = b
+        nat.check(self._lib, self._handle, self._lib.mdr_env_bind(self._handle, C.byref(b)), "mdr_env_bind")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) and self._handle.value:
+                self._lib.mdr_env_destroy(self._handle)
+                self._handle = C.c_void_p()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ episode start
+    def _allreduce(self, tensor, op):
+        import torch.distributed as dist
+        dist.all_reduce(tensor, op=op, group=self.process_group)
+
+    def _begin_episode(self):
+        if self.sharded:  # ClusterHouses.max_power spans the whole env (env 798-802, 125)
+            import torch.distributed as dist
+            self._allreduce(self.t["max_power"], dist.ReduceOp.SUM)
+        nat.check(self._lib, self._handle, self._lib.mdr_env_begin_episode(self._handle, self._stream()), "begin_episode")
+
+    def reset(self, seed: Optional[int] = None, episode: Optional[int] = None) -> torch.Tensor:
+        """MADemandResponseEnv.reset (env 135-172): re-samples every house and the start date, on the device."""
+        if seed is not None:
+            self.seed = int(seed)
+        self.episode = self.episode + 1 if episode is None else int(episode)
+        with torch.cuda.device(self.device):
+            rc = self._lib.mdr_env_reset(self._handle, C.c_uint64(self.seed & 0xFFFFFFFFFFFFFFFF),
+                                         C.c_uint32(self.episode & 0xFFFFFFFF), self._stream())
+            nat.check(self._lib, self._handle, rc, "mdr_env_reset")
+            self._begin_episode()
+            return self._reset_obs()
+
+    def load_episode(self, params: Dict[str, np.ndarray], od_table=None, seed: Optional[int] = None,
+                     episode: int = 0) -> torch.Tensor:
+        """Start an episode from given raw parameters (fp64, deg C) instead of sampling: arrays ``Ta Tm target
+        deadband Ua Cm Ca Hm capacity COP latent lockout`` of shape [E, N] and ``t0`` (epoch s) ``phase ratio``
+        of shape [E].  ``od_table`` ([rows, E], deg C) replaces the outdoor-temperature model (replays)."""
+        if seed is not None:
+            self.seed = int(seed)
+        self.episode = int(episode)
+        E, N = self.nb_envs, self.nb_houses
+        with torch.cuda.device(self.device):
+            keep = {}
+            ep = nat.MdrEpisode()
+            ep.struct_size = C.sizeof(nat.MdrEpisode)
+
+            def dev(name, dtype, shape):
+                a = np.ascontiguousarray(np.broadcast_to(np.asarray(params[name]), shape)).astype(dtype)
+                keep[name] = torch.from_numpy(a).to(self.device)
+                return keep[name].data_ptr()
+
+            for name in _EPISODE_F64:
+                setattr(ep, name, dev(name, np.float64, (E, N)))
+            ep.lockout = dev("lockout", np.int64, (E, N))
+            ep.t0 = dev("t0", np.int64, (E,))
+            ep.phase = dev("phase", np.float64, (E,)) if "phase" in params else None
+            ep.ratio = dev("ratio", np.float64, (E,)) if "ratio" in params else None
+            if np.any(np.asarray(params["lockout"]) < 0):
+                raise ValueError("Lockout duration must be positive")
+            self.set_od_table(od_table)
+            rc = self._lib.mdr_env_load_episode(self._handle, C.byref(ep), C.c_uint64(self.seed & 0xFFFFFFFFFFFFFFFF),
+                                                C.c_uint32(self.episode), self._stream())
+            nat.check(self._lib, self._handle, rc, "mdr_env_load_episode")
+            self._begin_episode()
+            torch.cuda.current_stream(self.device).synchronize()  # `keep` may be freed after this
+            return self._reset_obs()
+
+    def set_od_table(self, od_table):
+        if od_table is None:
+            self._od_table = None
+            rc = self._lib.mdr_env_set_od_table(self._handle, None, 0)
+        else:
+            tab = torch.as_tensor(np.ascontiguousarray(np.asarray(od_table, dtype=np.float64)))
+            if tab.dim() != 2 or tab.shape[1] != self.nb_envs:
+                raise ValueError("od_table must have shape [rows, nb_envs]")
+            self._od_table = tab.to(self.device)
+            rc = self._lib.mdr_env_set_od_table(self._handle, self._od_table.data_ptr(), self._od_table.shape[0])
+        nat.check(self._lib, self._handle, rc, "mdr_env_set_od_table")
+
+    def _reset_obs(self) -> torch.Tensor:
+        """Observation planes after reset, written by mdr_env_begin_episode's k_reset_obs kernel:
+        all HVACs off (env 796-801), P = 0, initial signal (env 133)."""
+        return self.t["obs"]
+
+    # ------------------------------------------------------------------ stepping
+    def _actions_ptr(self, actions):
+        if actions is None:
+            return self.t["actions"].data_ptr()
+        if actions.dtype == torch.bool:
+            actions = actions.view(torch.uint8)
+        if (actions.dtype != torch.uint8 or actions.device != self.device or not actions.is_contiguous()
+                or tuple(actions.shape) != (self.nb_envs, self.nb_houses)):
+            self.t["actions"].copy_(actions.reshape(self.nb_envs, self.nb_houses).to(self.device) != 0)
+            return self.t["actions"].data_ptr()
+        self._keep_actions = actions
+        return actions.data_ptr()
+
+    def _step(self, ptr, source):
+        with torch.cuda.device(self.device):
+            if not self.sharded:
+                rc = self._lib.mdr_env_step(self._handle, C.c_void_p(ptr), source, self._stream())
+                nat.check(self._lib, self._handle, rc, "mdr_env_step")
+            else:
+                import torch.distributed as dist
+                rc = self._lib.mdr_env_step_begin(self._handle, C.c_void_p(ptr), source, self._stream())
+                nat.check(self._lib, self._handle, rc, "mdr_env_step_begin")
+                self._allreduce(self.t["tot_sum"], dist.ReduceOp.SUM)   # cluster power, penalty sum
+                self._allreduce(self.t["tot_max"], dist.ReduceOp.MAX)   # penalty max
+                rc = self._lib.mdr_env_step_end(self._handle, self._stream())
+                nat.check(self._lib, self._handle, rc, "mdr_env_step_end")
+
+    def step(self, actions: torch.Tensor):
+        """MADemandResponseEnv.step (env 174-210).  Returns (obs [7,E,N], reward [E,N], done [E,N], info)."""
+        self._step(self._actions_ptr(actions), nat.ACTIONS_EXTERNAL)
+        return self.t["obs"], self.t["reward"], self.done, {"cluster_hvac_power": self.t["P"]}
+
+    def step_bangbang(self):
+        """One step with the bang-bang rule evaluated in-kernel; the actions taken land in ``self.t['actions']``."""
+        self._step(self.t["actions"].data_ptr(), nat.ACTIONS_BANGBANG)
+        return self.t["obs"], self.t["reward"], self.done, {"cluster_hvac_power": self.t["P"]}
+
+    def rollout(self, nb_steps: int, actions: Optional[torch.Tensor] = None):
+        """nb_steps consecutive launches without returning to Python (bang-bang unless ``actions`` is given)."""
+        if self.sharded:
+            for _ in range(nb_steps):
+                self._step(self._actions_ptr(actions), nat.ACTIONS_EXTERNAL if actions is not None else nat.ACTIONS_BANGBANG)
+            return
+        src = nat.ACTIONS_EXTERNAL if actions is not None else nat.ACTIONS_BANGBANG
+        with torch.cuda.device(self.device):
+            rc = self._lib.mdr_env_rollout(self._handle, C.c_void_p(self._actions_ptr(actions)), src, int(nb_steps), self._stream())
+            nat.check(self._lib, self._handle, rc, "mdr_env_rollout")
+
+    # ------------------------------------------------------------------ views of the state
+    def cursor(self) -> Tuple[int, int]:
+        k, j0 = C.c_int64(), C.c_int64()
+        self._lib.mdr_env_cursor(self._handle, C.byref(k), C.byref(j0))
+        return k.value, j0.value
+
+    @property
+    def steps_taken(self) -> int:
+        return self.cursor()[0]
+
+    def _row(self) -> int:
+        k, j0 = self.cursor()
+        return k - j0
+
+    def house_temp(self) -> torch.Tensor:
+        return self.t["Ta"].double() + self.spec.temp_ref
+
+    def house_mass_temp(self) -> torch.Tensor:
+        return self.t["Tm"].double() + self.spec.temp_ref
+
+    def target_temp(self) -> torch.Tensor:
+        return self.t["target"].double() + self.spec.temp_ref
+
+    def hvac_turned_on(self) -> torch.Tensor:
+        return (self.t["flags"] & 1).bool()
+
+    def hvac_lockout(self) -> torch.Tensor:
+        return (self.t["flags"] & 2).bool()
+
+    def od_temp(self) -> torch.Tensor:
+        return self.t["tab_od"][self._row()].double() + self.spec.temp_ref
+
+    def reg_signal(self) -> torch.Tensor:
+        return self.t["tab_signal"][self._row()]
+
+    def solar_gain(self) -> torch.Tensor:
+        return self.t["tab_solar"][self._row()].double()
+
+    def datetimes(self):
+        k = self.steps_taken
+        return [from_epoch_seconds(int(t0) + k * self.spec.time_step) for t0 in self.t["t0"].cpu().tolist()]
+
+    # ------------------------------------------------------------------ snapshot (copy.deepcopy(env) in utils.py:890-1008)
+    def state_dict(self) -> dict:
+        k, j0 = self.cursor()
+        return {"slab": self._slab.clone(), "k": k, "j0": j0, "seed": self.seed, "episode": self.episode,
+                "od_table": None if self._od_table is None else self._od_table.clone()}
+
+    def load_state_dict(self, sd: dict):
+        self._slab.copy_(sd["slab"])
+        self.seed, self.episode = sd["seed"], sd["episode"]
+        if sd.get("od_table") is not None:
+            self.set_od_table(sd["od_table"].cpu().numpy())
+        else:
+            self.set_od_table(None)
+        rc = self._lib.mdr_env_set_cursor(self._handle, C.c_uint64(self.seed & 0xFFFFFFFFFFFFFFFF),
+                                          C.c_uint32(max(self.episode, 0) & 0xFFFFFFFF), sd["k"], sd["j0"])
+        nat.check(self._lib, self._handle, rc, "mdr_env_set_cursor")
+
+    def __deepcopy__(self, memo):
+        other = BatchedDemandResponseEnv(copy.deepcopy(self.config, memo), nb_envs=self.nb_envs, device=self.device,
+                                         seed=self.seed, test=self.test, table_steps=self.table_steps,
+                                         env_offset=self.env_offset,
+                                         house_shard=(self.house_offset, self.nb_houses) if self.sharded else None,
+                                         process_group=self.process_group, stagger_bytes=self._stagger)
+        if self.episode >= 0:
+            other.load_state_dict(self.state_dict())
+        return other

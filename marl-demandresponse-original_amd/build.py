@@ -1,0 +1,38 @@
+"""Build csrc/libmdr_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SOURCES = ("mdr_kernels.hip", "mdr_api.hip")
+HEADERS = ("mdr_device.h", "mdr_kernels.h", os.path.join("..", "..", "include", "mdr.h"))
+OUTPUT = os.path.join(CSRC, "libmdr_hip.so")
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.isfile(cand):
+            return cand
+    raise RuntimeError("hipcc not found (ROCm toolchain required to build libmdr_hip.so)")
+
+
+def is_stale() -> bool:
+    if not os.path.isfile(OUTPUT):
+        return True
+    built = os.path.getmtime(OUTPUT)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > built for d in deps)
+
+
+def build_native(force: bool = False, verbose: bool = False) -> str:
+    if not force and not is_stale():
+        return OUTPUT
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-o", OUTPUT] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return OUTPUT

@@ -1,0 +1,409 @@
+// C-ABI host side of libmdr_hip.so (include/mdr.h).  No device allocation, no hidden synchronisation:
+// each call validates, fills a kernel argument block and enqueues launches on the caller's stream.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "mdr_kernels.h"
+
+struct mdr_env {
+  mdr_config_t cfg;
+  mdr_buffers_t buf;
+  bool bound = false;
+  bool has_episode = false;   // per-house parameters present
+  bool has_tables = false;    // begin_episode done
+  bool split_pending = false; // step_begin issued, step_end outstanding
+  uint64_t seed = 0;
+  uint32_t episode = 0;
+  int64_t k = 0;              // steps taken this episode
+  int64_t j0 = 0;             // time index of table row 0
+  const double* od_ext = nullptr;
+  int64_t od_ext_rows = 0;
+  mdr::StepPlan plan;
+  int64_t nblk = 1;
+  std::string err;
+};
+
+namespace {
+
+int fail(mdr_env* env, int code, const std::string& msg) {
+  if (env) env->err = msg;
+  return code;
+}
+
+int hip_fail(mdr_env* env, hipError_t e, const char* what) {
+  return fail(env, MDR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+bool finite_pos(double v) { return std::isfinite(v) && v > 0.0; }
+
+std::string validate(const mdr_config_t& c) {
+  if (c.struct_size != sizeof(mdr_config_t)) return "mdr_config_t size mismatch (ABI)";
+  if (c.nb_envs < 1 || c.nb_houses < 1) return "nb_envs and nb_houses must be >= 1";
+  if (c.nb_houses_total < c.nb_houses) return "nb_houses_total must be >= nb_houses";
+  if (c.env_offset < 0 || c.house_offset < 0) return "offsets must be >= 0";
+  if (c.house_offset + c.nb_houses > c.nb_houses_total) return "house shard exceeds nb_houses_total";
+  if (c.time_step < 1) return "time_step must be >= 1 s";
+  if (c.table_steps < 1 || c.table_steps > (1 << 20)) return "table_steps out of range";
+  if (!finite_pos(c.Ua) || !finite_pos(c.Cm) || !finite_pos(c.Ca) || !finite_pos(c.Hm))
+    return "Ua, Cm, Ca, Hm must be positive";
+  if (c.factor_thermo_low <= 0.0 || c.factor_thermo_high < c.factor_thermo_low) return "bad thermal noise factors";
+  // HVAC.__init__ validation, env/MA_DemandResponse.py:438-461
+  if (c.latent_cooling_fraction > 1.0 || c.latent_cooling_fraction < 0.0)
+    return "Latent cooling fraction must be between 0 and 1";
+  if (c.lockout_noise < 0) return "lockout_noise must be >= 0";
+  if (c.lockout_duration - c.lockout_noise < 0) return "Lockout duration must be positive";
+  if (c.COP <= 0.0) return "Coefficient of performance (COP) must be positive";
+  if (c.nb_capacities < 1 || c.nb_capacities > MDR_MAX_CAPACITIES) return "nb_capacities out of range";
+  for (int i = 0; i < c.nb_capacities; ++i)
+    if (!(c.capacity_list[i] >= 0.0)) return "Cooling capacity must be positive";
+  if (c.signal_mode < MDR_SIGNAL_FLAT || c.signal_mode > MDR_SIGNAL_PERLIN) return "Invalid power grid signal mode";
+  if (c.nb_sinusoids < 0 || c.nb_sinusoids > MDR_MAX_SINUSOIDS) return "too many sinusoids";
+  if (c.signal_mode == MDR_SIGNAL_SINUSOIDALS)
+    for (int i = 0; i < c.nb_sinusoids; ++i)
+      if (!(c.sin_periods[i] > 0.0)) return "sinusoid periods must be positive";
+  if (c.signal_mode == MDR_SIGNAL_REGULAR_STEPS && !(c.steps_amplitude_per_hvac > 0.0 && c.steps_period > 0.0))
+    return "regular_steps needs positive amplitude_per_hvac and period";
+  if (c.signal_mode == MDR_SIGNAL_PERLIN &&
+      !(c.perlin_nb_octaves >= 1 && c.perlin_nb_octaves <= 16 && c.perlin_period > 0.0 && c.perlin_octaves_step > 0.0))
+    return "perlin needs 1..16 octaves, positive period and octaves_step";
+  if (!(c.artificial_signal_ratio_range > 0.0)) return "artificial_signal_ratio_range must be positive";
+  if (c.penalty_mode < MDR_PENALTY_INDIVIDUAL_L2 || c.penalty_mode > MDR_PENALTY_MIXTURE)
+    return "Unknown temperature penalty mode";
+  if (c.penalty_mode == MDR_PENALTY_MIXTURE && !(c.mix_ind_L2 + c.mix_common_L2 + c.mix_common_max != 0.0))
+    return "mixture weights sum to zero";
+  if (!(c.norm_temp_penalty > 0.0) || !(c.norm_sig_penalty > 0.0) || !(c.obs_power_norm > 0.0))
+    return "normalisation constants must be positive";
+  if ((int64_t)c.nb_envs * (int64_t)c.nb_houses > (int64_t)1 << 40) return "E * N too large";
+  return "";
+}
+
+std::string check_buffers(const mdr_buffers_t& b, bool need_partials) {
+  if (b.struct_size != sizeof(mdr_buffers_t)) return "mdr_buffers_t size mismatch (ABI)";
+#define MDR_NEED(p) \
+  if (!b.p) return "buffer '" #p "' is NULL"
+  MDR_NEED(Ta); MDR_NEED(Tm); MDR_NEED(sso); MDR_NEED(flags);
+  MDR_NEED(k01); MDR_NEED(s0); MDR_NEED(k10); MDR_NEED(s1); MDR_NEED(inv_Ua); MDR_NEED(Q_hvac); MDR_NEED(P_max);
+  MDR_NEED(target); MDR_NEED(deadband); MDR_NEED(lockout);
+  MDR_NEED(Ua); MDR_NEED(Cm); MDR_NEED(Ca); MDR_NEED(Hm); MDR_NEED(capacity); MDR_NEED(COP); MDR_NEED(latent);
+  MDR_NEED(reward); MDR_NEED(obs);
+  MDR_NEED(t0); MDR_NEED(phase); MDR_NEED(ratio); MDR_NEED(max_power); MDR_NEED(P); MDR_NEED(tot_sum); MDR_NEED(tot_max);
+  MDR_NEED(tab_od); MDR_NEED(tab_solar); MDR_NEED(tab_signal);
+#undef MDR_NEED
+  if (need_partials && !b.partials) return "buffer 'partials' is NULL (needed by the split path)";
+  // the vector kernels use 16-byte accesses on the float/int arrays
+  const void* aligned16[] = {b.Ta, b.Tm, b.sso, b.k01, b.s0, b.k10, b.s1, b.inv_Ua, b.Q_hvac, b.P_max,
+                             b.target, b.deadband, b.lockout, b.reward, b.obs};
+  for (const void* p : aligned16)
+    if (((uintptr_t)p & 15u) != 0) return "per-house float/int buffers must be 16-byte aligned";
+  if (((uintptr_t)b.flags & 3u) != 0) return "flags must be 4-byte aligned";
+  return "";
+}
+
+mdr::EpisodeArgs episode_args(const mdr_env& env) {
+  const mdr_config_t& c = env.cfg;
+  mdr::EpisodeArgs a{};
+  a.b = env.buf;
+  a.E = c.nb_envs;
+  a.N = c.nb_houses;
+  a.dt = c.time_step;
+  a.env_offset = c.env_offset;
+  a.house_offset = c.house_offset;
+  a.k0 = (uint32_t)(env.seed & 0xFFFFFFFFull);
+  a.k1 = (uint32_t)(env.seed >> 32);
+  a.episode = env.episode;
+  a.temp_ref = c.temp_ref;
+  a.init_air = c.init_air_temp;
+  a.init_mass = c.init_mass_temp;
+  a.target = c.target_temp;
+  a.deadband = c.deadband;
+  a.Ua = c.Ua; a.Cm = c.Cm; a.Ca = c.Ca; a.Hm = c.Hm;
+  a.COP = c.COP;
+  a.latent = c.latent_cooling_fraction;
+  a.std_start = c.std_start_temp;
+  a.std_target = c.std_target_temp;
+  a.f_low = c.factor_thermo_low;
+  a.f_high = c.factor_thermo_high;
+  a.lockout = c.lockout_duration;
+  a.lockout_noise = c.lockout_noise;
+  a.ncaps = c.nb_capacities;
+  for (int i = 0; i < MDR_MAX_CAPACITIES; ++i) a.caps[i] = c.capacity_list[i];
+  a.start_random = c.start_random;
+  a.random_phase = c.random_phase_offset;
+  a.start_epoch = c.start_epoch;
+  a.artificial_ratio = c.artificial_ratio;
+  a.ratio_range = c.artificial_signal_ratio_range;
+  return a;
+}
+
+int fill_tables(mdr_env* env, int64_t j0, hipStream_t s) {
+  const mdr_config_t& c = env->cfg;
+  mdr::TableArgs t{};
+  t.tab_od = env->buf.tab_od;
+  t.tab_solar = env->buf.tab_solar;
+  t.tab_signal = env->buf.tab_signal;
+  t.t0 = env->buf.t0;
+  t.phase = env->buf.phase;
+  t.ratio = env->buf.ratio;
+  t.max_power = env->buf.max_power;
+  t.od_ext = env->od_ext;
+  t.od_ext_rows = env->od_ext_rows;
+  t.j0 = j0;
+  t.rows = c.table_steps + 1;
+  t.E = c.nb_envs;
+  t.dt = c.time_step;
+  t.env_offset = c.env_offset;
+  t.k0 = (uint32_t)(env->seed & 0xFFFFFFFFull);
+  t.k1 = (uint32_t)(env->seed >> 32);
+  t.episode = env->episode;
+  t.temp_ref = c.temp_ref;
+  t.day_temp = c.day_temp;
+  t.night_temp = c.night_temp;
+  t.temp_std = c.temp_std;
+  t.solar_on = c.solar_gain;
+  t.area_shading = c.window_area * c.shading_coeff;
+  t.n_total = c.nb_houses_total;
+  t.avg_power_per_hvac = c.avg_power_per_hvac;
+  t.signal_mode = c.signal_mode;
+  t.nb_sin = c.nb_sinusoids;
+  t.perlin_octaves = c.perlin_nb_octaves;
+  for (int i = 0; i < MDR_MAX_SINUSOIDS; ++i) {
+    t.sin_periods[i] = c.sin_periods[i];
+    t.sin_ratios[i] = c.sin_amplitude_ratios[i];
+  }
+  t.steps_amp = c.steps_amplitude_per_hvac;
+  t.steps_period = c.steps_period;
+  t.perlin_amp = c.perlin_amplitude;
+  t.perlin_step = c.perlin_octaves_step;
+  t.perlin_period = c.perlin_period;
+  hipError_t e = mdr::launch_tables(t, s);
+  if (e != hipSuccess) return hip_fail(env, e, "fill_tables");
+  env->j0 = j0;
+  return MDR_OK;
+}
+
+// Builds the argument block of step k -> k+1, refilling the time tables when the cursor leaves them.
+int step_args(mdr_env* env, uint8_t* actions, int action_source, hipStream_t s, mdr::StepArgs* out) {
+  const mdr_config_t& c = env->cfg;
+  if (!env->bound) return fail(env, MDR_ERR_UNBOUND, "buffers not bound");
+  if (!env->has_tables) return fail(env, MDR_ERR_UNBOUND, "no episode: call reset/load_episode and begin_episode first");
+  if (action_source != MDR_ACTIONS_EXTERNAL && action_source != MDR_ACTIONS_BANGBANG)
+    return fail(env, MDR_ERR_INVALID, "unknown action_source");
+  if (action_source == MDR_ACTIONS_EXTERNAL && !actions) return fail(env, MDR_ERR_INVALID, "actions is NULL");
+  if (actions && ((uintptr_t)actions & 3u) != 0) return fail(env, MDR_ERR_INVALID, "actions must be 4-byte aligned");
+  if (env->k + 1 - env->j0 > c.table_steps) {
+    int rc = fill_tables(env, env->k, s);
+    if (rc != MDR_OK) return rc;
+  }
+  const int64_t r0 = env->k - env->j0, r1 = r0 + 1;
+  const mdr_buffers_t& b = env->buf;
+  mdr::StepArgs a{};
+  a.Ta = b.Ta; a.Tm = b.Tm; a.sso = b.sso; a.flags = b.flags;
+  a.k01 = b.k01; a.s0 = b.s0; a.k10 = b.k10; a.s1 = b.s1; a.inv_Ua = b.inv_Ua; a.Q_hvac = b.Q_hvac; a.P_max = b.P_max;
+  a.target = b.target; a.deadband = b.deadband; a.lockout = b.lockout;
+  a.actions = actions;
+  a.reward = b.reward; a.obs = b.obs;
+  a.P = b.P; a.tot_sum = b.tot_sum; a.tot_max = b.tot_max; a.partials = b.partials;
+  a.od_old = b.tab_od + r0 * c.nb_envs;
+  a.solar_new = b.tab_solar + r1 * c.nb_envs;
+  a.sig_old = b.tab_signal + r0 * c.nb_envs;
+  a.sig_new = b.tab_signal + r1 * c.nb_envs;
+  a.plane = (int64_t)c.nb_envs * c.nb_houses;
+  a.E = c.nb_envs; a.N = c.nb_houses; a.dt = c.time_step;
+  a.penalty_mode = c.penalty_mode;
+  a.action_source = action_source;
+  a.nblk = (int)env->nblk;
+  a.c_temp = (float)(c.alpha_temp / c.norm_temp_penalty);
+  const double ms = c.mix_ind_L2 + c.mix_common_L2 + c.mix_common_max;
+  if (c.penalty_mode == MDR_PENALTY_MIXTURE) {
+    a.mix_i = (float)(c.mix_ind_L2 / ms); a.mix_c = (float)(c.mix_common_L2 / ms); a.mix_m = (float)(c.mix_common_max / ms);
+  }
+  a.obs_tshift = (float)(c.temp_ref - 20.0);
+  a.c_sig = c.alpha_sig / c.norm_sig_penalty;
+  a.inv_n_total = 1.0 / (double)c.nb_houses_total;
+  a.inv_obs_norm = 1.0 / c.obs_power_norm;
+  *out = a;
+  return MDR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdr_abi_version(void) { return MDR_ABI_VERSION; }
+
+const char* mdr_status_string(int status) {
+  switch (status) {
+    case MDR_OK: return "ok";
+    case MDR_ERR_INVALID: return "invalid argument";
+    case MDR_ERR_UNBOUND: return "buffers not bound or episode not started";
+    case MDR_ERR_HIP: return "HIP runtime error";
+    case MDR_ERR_UNSUPPORTED: return "unsupported shape or mode";
+    default: return "unknown status";
+  }
+}
+
+const char* mdr_last_error(const mdr_env_t* env) { return env ? env->err.c_str() : ""; }
+
+int64_t mdr_partials_per_env(int32_t nb_houses) { return nb_houses < 1 ? 0 : mdr::split_blocks(nb_houses); }
+
+int mdr_env_create(const mdr_config_t* config, mdr_env_t** out) {
+  if (!config || !out) return MDR_ERR_INVALID;
+  *out = nullptr;
+  mdr_env* env = new (std::nothrow) mdr_env();
+  if (!env) return MDR_ERR_INVALID;
+  const std::string msg = validate(*config);
+  env->cfg = *config;
+  env->err = msg;
+  *out = env;  // returned even on failure so that mdr_last_error() can explain; caller destroys it
+  if (!msg.empty()) return MDR_ERR_INVALID;
+  env->plan = mdr::plan_step(config->nb_houses);
+  env->nblk = mdr::split_blocks(config->nb_houses);
+  return MDR_OK;
+}
+
+int mdr_env_destroy(mdr_env_t* env) {
+  delete env;
+  return MDR_OK;
+}
+
+int mdr_env_bind(mdr_env_t* env, const mdr_buffers_t* buffers) {
+  if (!env || !buffers) return MDR_ERR_INVALID;
+  const bool sharded = env->cfg.nb_houses_total != env->cfg.nb_houses;
+  const std::string msg = check_buffers(*buffers, sharded || env->plan.kind == mdr::STEP_SPLIT);
+  if (!msg.empty()) return fail(env, MDR_ERR_INVALID, msg);
+  env->buf = *buffers;
+  env->bound = true;
+  env->err.clear();
+  return MDR_OK;
+}
+
+int mdr_env_reset(mdr_env_t* env, uint64_t seed, uint32_t episode, void* stream) {
+  if (!env) return MDR_ERR_INVALID;
+  if (!env->bound) return fail(env, MDR_ERR_UNBOUND, "buffers not bound");
+  env->seed = seed;
+  env->episode = episode;
+  env->has_tables = false;
+  env->split_pending = false;
+  hipError_t e = mdr::launch_sample(episode_args(*env), (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(env, e, "reset");
+  env->has_episode = true;
+  env->k = 0;
+  return MDR_OK;
+}
+
+int mdr_env_load_episode(mdr_env_t* env, const mdr_episode_t* ep, uint64_t seed, uint32_t episode_index, void* stream) {
+  if (!env || !ep) return MDR_ERR_INVALID;
+  if (!env->bound) return fail(env, MDR_ERR_UNBOUND, "buffers not bound");
+  if (ep->struct_size != sizeof(mdr_episode_t)) return fail(env, MDR_ERR_INVALID, "mdr_episode_t size mismatch (ABI)");
+  if (!ep->Ta || !ep->Tm || !ep->target || !ep->deadband || !ep->Ua || !ep->Cm || !ep->Ca || !ep->Hm || !ep->capacity ||
+      !ep->COP || !ep->latent || !ep->lockout || !ep->t0)
+    return fail(env, MDR_ERR_INVALID, "mdr_episode_t has NULL arrays");
+  env->seed = seed;
+  env->episode = episode_index;
+  env->has_tables = false;
+  env->split_pending = false;
+  hipError_t e = mdr::launch_load(episode_args(*env), *ep, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(env, e, "load_episode");
+  env->has_episode = true;
+  env->k = 0;
+  return MDR_OK;
+}
+
+int mdr_env_set_od_table(mdr_env_t* env, const double* od_table, int64_t rows) {
+  if (!env) return MDR_ERR_INVALID;
+  if (od_table && rows < 1) return fail(env, MDR_ERR_INVALID, "od table needs rows >= 1");
+  env->od_ext = od_table;
+  env->od_ext_rows = od_table ? rows : 0;
+  return MDR_OK;
+}
+
+int mdr_env_begin_episode(mdr_env_t* env, void* stream) {
+  if (!env) return MDR_ERR_INVALID;
+  if (!env->bound || !env->has_episode) return fail(env, MDR_ERR_UNBOUND, "call reset or load_episode first");
+  env->k = 0;
+  int rc = fill_tables(env, 0, (hipStream_t)stream);
+  if (rc != MDR_OK) return rc;
+  env->has_tables = true;
+  mdr::StepArgs a;
+  rc = step_args(env, nullptr, MDR_ACTIONS_BANGBANG, (hipStream_t)stream, &a);  // row 0 of the fresh tables
+  if (rc != MDR_OK) return rc;
+  hipError_t e = mdr::launch_reset_obs(a, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(env, e, "reset_obs");
+  return MDR_OK;
+}
+
+int mdr_env_step(mdr_env_t* env, uint8_t* actions, int action_source, void* stream) {
+  if (!env) return MDR_ERR_INVALID;
+  if (env->cfg.nb_houses_total != env->cfg.nb_houses)
+    return fail(env, MDR_ERR_INVALID, "houses are sharded: use mdr_env_step_begin / all-reduce / mdr_env_step_end");
+  if (env->split_pending) return fail(env, MDR_ERR_INVALID, "step_begin without step_end");
+  mdr::StepArgs a;
+  int rc = step_args(env, actions, action_source, (hipStream_t)stream, &a);
+  if (rc != MDR_OK) return rc;
+  hipError_t e = mdr::launch_step(a, env->plan, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(env, e, "step");
+  env->k += 1;
+  return MDR_OK;
+}
+
+int mdr_env_rollout(mdr_env_t* env, uint8_t* actions, int action_source, int32_t nb_steps, void* stream) {
+  if (!env) return MDR_ERR_INVALID;
+  if (nb_steps < 0) return fail(env, MDR_ERR_INVALID, "nb_steps must be >= 0");
+  for (int32_t i = 0; i < nb_steps; ++i) {
+    int rc = mdr_env_step(env, actions, action_source, stream);
+    if (rc != MDR_OK) return rc;
+  }
+  return MDR_OK;
+}
+
+int mdr_env_step_begin(mdr_env_t* env, uint8_t* actions, int action_source, void* stream) {
+  if (!env) return MDR_ERR_INVALID;
+  if (env->split_pending) return fail(env, MDR_ERR_INVALID, "step_begin called twice");
+  if (env->bound && !env->buf.partials) return fail(env, MDR_ERR_UNBOUND, "buffer 'partials' is NULL");
+  mdr::StepArgs a;
+  int rc = step_args(env, actions, action_source, (hipStream_t)stream, &a);
+  if (rc != MDR_OK) return rc;
+  hipError_t e = mdr::launch_step_begin_split(a, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(env, e, "step_begin");
+  env->split_pending = true;
+  return MDR_OK;
+}
+
+int mdr_env_step_end(mdr_env_t* env, void* stream) {
+  if (!env) return MDR_ERR_INVALID;
+  if (!env->split_pending) return fail(env, MDR_ERR_INVALID, "step_end without step_begin");
+  mdr::StepArgs a;
+  int rc = step_args(env, nullptr, MDR_ACTIONS_BANGBANG, (hipStream_t)stream, &a);  // actions unused here
+  if (rc != MDR_OK) return rc;
+  hipError_t e = mdr::launch_step_end_split(a, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(env, e, "step_end");
+  env->split_pending = false;
+  env->k += 1;
+  return MDR_OK;
+}
+
+int mdr_env_cursor(const mdr_env_t* env, int64_t* k, int64_t* j0) {
+  if (!env) return MDR_ERR_INVALID;
+  if (k) *k = env->k;
+  if (j0) *j0 = env->j0;
+  return MDR_OK;
+}
+
+int mdr_env_set_cursor(mdr_env_t* env, uint64_t seed, uint32_t episode, int64_t k, int64_t j0) {
+  if (!env) return MDR_ERR_INVALID;
+  if (!env->bound) return fail(env, MDR_ERR_UNBOUND, "buffers not bound");
+  if (k < 0 || j0 < 0 || k < j0 || k - j0 > env->cfg.table_steps) return fail(env, MDR_ERR_INVALID, "cursor outside the tables");
+  env->seed = seed;
+  env->episode = episode;
+  env->k = k;
+  env->j0 = j0;
+  env->has_episode = true;
+  env->has_tables = true;
+  env->split_pending = false;
+  return MDR_OK;
+}
+
+}  // extern "C"

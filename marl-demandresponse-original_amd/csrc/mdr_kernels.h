@@ -1,0 +1,94 @@
+// Kernel argument blocks and launchers shared between mdr_kernels.hip and the C-ABI host side (mdr_api.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "../../include/mdr.h"
+
+namespace mdr {
+
+// Episode start (sampling or replay): everything k_sample_* / k_load_* / k_env_max_power need.
+struct EpisodeArgs {
+  mdr_buffers_t b;
+  int E, N, dt;
+  int64_t env_offset, house_offset;
+  uint32_t k0, k1, episode;
+  double temp_ref;
+  double init_air, init_mass, target, deadband, Ua, Cm, Ca, Hm, COP, latent;
+  double std_start, std_target, f_low, f_high;
+  int lockout, lockout_noise, ncaps;
+  double caps[MDR_MAX_CAPACITIES];
+  int start_random, random_phase;
+  int64_t start_epoch;
+  double artificial_ratio, ratio_range;
+};
+
+// Time tables for rows [j0, j0 + rows)
+struct TableArgs {
+  float* tab_od;
+  float* tab_solar;
+  double* tab_signal;
+  const int64_t* t0;
+  const double* phase;
+  const double* ratio;
+  const double* max_power;
+  const double* od_ext;
+  int64_t od_ext_rows;
+  int64_t j0;
+  int rows, E, dt;
+  int64_t env_offset;
+  uint32_t k0, k1, episode;
+  double temp_ref;
+  double day_temp, night_temp, temp_std;
+  int solar_on;
+  double area_shading;
+  int64_t n_total;
+  double avg_power_per_hvac;
+  int signal_mode, nb_sin, perlin_octaves;
+  double sin_periods[MDR_MAX_SINUSOIDS], sin_ratios[MDR_MAX_SINUSOIDS];
+  double steps_amp, steps_period;
+  double perlin_amp, perlin_step, perlin_period;
+};
+
+// One env step
+struct StepArgs {
+  float *Ta, *Tm;
+  int32_t* sso;
+  uint8_t* flags;
+  const float *k01, *s0, *k10, *s1, *inv_Ua, *Q_hvac, *P_max, *target, *deadband;
+  const int32_t* lockout;
+  uint8_t* actions;
+  float* reward;
+  float* obs;
+  double *P, *tot_sum, *tot_max, *partials;
+  const float *od_old, *solar_new;     // table rows for this step: OD temp at time index k-1, solar at k
+  const double *sig_old, *sig_new;     // regulation signal at k-1 (reward) and k (observation)
+  int64_t plane;                       // E * N: stride between observation planes
+  int E, N, dt, penalty_mode, action_source, nblk;
+  float c_temp;                        // alpha_temp / norm_temp_penalty
+  float mix_i, mix_c, mix_m;           // mixture weights divided by their sum
+  float obs_tshift;                    // temp_ref - 20
+  double c_sig;                        // alpha_sig / norm_sig_penalty
+  double inv_n_total;                  // 1 / nb_agents
+  double inv_obs_norm;                 // 1 / (norm_reg_sig * nb_agents)
+};
+
+enum StepKind { STEP_FUSED = 0, STEP_GROUP = 1, STEP_SPLIT = 2 };
+struct StepPlan {
+  int kind, vec, threads, tiles;
+};
+
+StepPlan plan_step(int N);
+int64_t split_blocks(int N);
+
+hipError_t launch_sample(const EpisodeArgs& a, hipStream_t s);
+hipError_t launch_load(const EpisodeArgs& a, const mdr_episode_t& ep, hipStream_t s);
+hipError_t launch_tables(const TableArgs& a, hipStream_t s);
+hipError_t launch_reset_obs(const StepArgs& a, hipStream_t s);  // uses sig_old = table row 0
+hipError_t launch_step(const StepArgs& a, const StepPlan& p, hipStream_t s);
+hipError_t launch_step_begin_split(const StepArgs& a, hipStream_t s);
+hipError_t launch_step_end_split(const StepArgs& a, hipStream_t s);
+
+}  // namespace mdr

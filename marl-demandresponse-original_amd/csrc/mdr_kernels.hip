@@ -1,0 +1,614 @@
+// HIP kernels of the batched demand-response step path for MI355X (gfx950, wave64).
+//
+// Bound: HBM bandwidth (element-wise fp32, ~0.4 flop/B) - no MFMA.  One fused launch per env step:
+// every per-house array is read/written once with 16-byte accesses, the per-env reductions stay in
+// registers + LDS, per-env scalars (weather, solar, signal) come from small pre-built time tables.
+#include "mdr_device.h"
+#include "mdr_kernels.h"
+
+namespace mdr {
+
+// =================================================================================================
+// Episode start
+// =================================================================================================
+
+// Writes every derived / raw per-house buffer from fp64 raw values (shared by sampling and replay).
+__device__ __forceinline__ void store_house(const EpisodeArgs& a, int64_t i, double Ta, double Tm, double target,
+                                            double deadband, double Ua, double Cm, double Ca, double Hm, double cap,
+                                            double COP, double latent, int64_t lockout) {
+  const ThermalMap m = thermal_map(Ua, Cm, Ca, Hm, (double)a.dt);
+  a.b.Ta[i] = (float)(Ta - a.temp_ref);
+  a.b.Tm[i] = (float)(Tm - a.temp_ref);
+  a.b.sso[i] = (int32_t)lockout;  // env 434
+  a.b.flags[i] = 0;               // env 432-433
+  a.b.k01[i] = (float)m.k01;
+  a.b.s0[i] = (float)m.s0;
+  a.b.k10[i] = (float)m.k10;
+  a.b.s1[i] = (float)m.s1;
+  a.b.inv_Ua[i] = (float)(1.0 / Ua);
+  a.b.Q_hvac[i] = (float)(-cap / (1.0 + latent));  // env 505
+  a.b.P_max[i] = (float)(cap / COP);               // env 436
+  a.b.target[i] = (float)(target - a.temp_ref);
+  a.b.deadband[i] = (float)deadband;
+  a.b.lockout[i] = (int32_t)lockout;
+  a.b.Ua[i] = (float)Ua;
+  a.b.Cm[i] = (float)Cm;
+  a.b.Ca[i] = (float)Ca;
+  a.b.Hm[i] = (float)Hm;
+  a.b.capacity[i] = (float)cap;
+  a.b.COP[i] = (float)COP;
+  a.b.latent[i] = (float)latent;
+}
+
+// utils.apply_house_noise / apply_hvac_noise (utils.py:623-676) + HVAC.__init__ lockout noise (env 430)
+__global__ __launch_bounds__(256) void k_sample_houses(EpisodeArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)a.E * a.N) return;
+  const uint32_t e = (uint32_t)(i / a.N + a.env_offset);
+  const uint32_t h = (uint32_t)(i % a.N + a.house_offset);
+  const u32x4 A = philox4x32_10(e, h, a.episode, TAG_HOUSE_TEMPS, a.k0, a.k1);
+  const u32x4 B = philox4x32_10(e, h, a.episode, TAG_HOUSE_HVAC, a.k0, a.k1);
+  const u32x4 C = philox4x32_10(e, h, a.episode, TAG_HOUSE_THERMO, a.k0, a.k1);
+  const double Ta = a.init_air + fabs(a.std_start * gauss01(A.x, A.y));
+  const double Tm = a.init_mass + fabs(a.std_start * gauss01(A.z, A.w));
+  const double target = a.target + fabs(a.std_target * gauss01(B.x, B.y));
+  const double cap = a.caps[mulhi_pick(B.z, (uint32_t)a.ncaps)];
+  const int64_t lockout = a.lockout + (-(int64_t)a.lockout_noise + mulhi_pick(B.w, (uint32_t)(2 * a.lockout_noise + 1)));
+  const double Ua = a.Ua * triangular_mode1(u01(C.x), a.f_low, a.f_high);
+  const double Cm = a.Cm * triangular_mode1(u01(C.y), a.f_low, a.f_high);
+  const double Ca = a.Ca * triangular_mode1(u01(C.z), a.f_low, a.f_high);
+  const double Hm = a.Hm * triangular_mode1(u01(C.w), a.f_low, a.f_high);
+  store_house(a, i, Ta, Tm, target, a.deadband, Ua, Cm, Ca, Hm, cap, a.COP, a.latent, lockout);
+}
+
+// start datetime (utils.get_random_date_time 701-709), phase (env 789-792), artificial ratio (env 1116)
+__global__ __launch_bounds__(256) void k_sample_envs(EpisodeArgs a) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.E) return;
+  const u32x4 D = philox4x32_10((uint32_t)(e + a.env_offset), ENV_LEVEL, a.episode, TAG_ENV_START, a.k0, a.k1);
+  int64_t t0 = a.start_epoch;
+  if (a.start_random) t0 += mulhi_pick(D.x, 364u) * 86400 + mulhi_pick(D.y, 86400u);
+  a.b.t0[e] = t0;
+  a.b.phase[e] = a.random_phase ? u01(D.z) * 24.0 : 0.0;
+  a.b.ratio[e] = a.artificial_ratio * pow(a.ratio_range, 2.0 * u01(D.w) - 1.0);
+}
+
+__global__ __launch_bounds__(256) void k_load_houses(EpisodeArgs a, mdr_episode_t ep) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)a.E * a.N) return;
+  store_house(a, i, ep.Ta[i], ep.Tm[i], ep.target[i], ep.deadband[i], ep.Ua[i], ep.Cm[i], ep.Ca[i], ep.Hm[i],
+              ep.capacity[i], ep.COP[i], ep.latent[i], ep.lockout[i]);
+}
+
+__global__ __launch_bounds__(256) void k_load_envs(EpisodeArgs a, mdr_episode_t ep) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.E) return;
+  a.b.t0[e] = ep.t0[e];
+  a.b.phase[e] = ep.phase ? ep.phase[e] : 0.0;
+  a.b.ratio[e] = ep.ratio ? ep.ratio[e] : a.artificial_ratio;
+}
+
+// Local sum of max consumption per env (ClusterHouses.__init__, env 796-802) in a fixed order; P <- 0.
+__global__ __launch_bounds__(256) void k_env_max_power(EpisodeArgs a) {
+  __shared__ double lds[3 * 4];
+  const int e = blockIdx.x;
+  const float* p = a.b.P_max + (int64_t)e * a.N;
+  Red3 v{0.0, 0.0, 0.0f};
+  for (int i = threadIdx.x; i < a.N; i += 256) v.sum_p += (double)p[i];
+  v = block_reduce<256>(v, lds);
+  if (threadIdx.x == 0) {
+    a.b.max_power[e] = v.sum_p;
+    a.b.P[e] = 0.0;
+  }
+}
+
+// Observation planes right after reset (MADemandResponseEnv.reset, env 163-170): every HVAC is off
+// (env 796-801) so cluster_hvac_power = 0; reg_signal is the initial signal (table row 0); rewards <- 0.
+__global__ __launch_bounds__(256) void k_reset_obs(StepArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.plane) return;
+  const int e = (int)(i / a.N);
+  a.obs[0 * a.plane + i] = (a.Ta[i] + a.obs_tshift) * 0.2f;
+  a.obs[1 * a.plane + i] = (a.Tm[i] + a.obs_tshift) * 0.2f;
+  a.obs[2 * a.plane + i] = (a.flags[i] & 1u) ? 1.0f : 0.0f;
+  a.obs[3 * a.plane + i] = (a.flags[i] & 2u) ? 1.0f : 0.0f;
+  a.obs[4 * a.plane + i] = (float)a.sso[i] / (float)a.lockout[i];
+  a.obs[5 * a.plane + i] = (float)(a.sig_old[e] * a.inv_obs_norm);
+  a.obs[6 * a.plane + i] = (float)(a.P[e] * a.inv_obs_norm);
+  a.reward[i] = 0.0f;
+}
+
+// =================================================================================================
+// Per-env time tables: outdoor temperature, solar gain, regulation signal for K+1 consecutive time
+// indices, in fp64, one thread per (row, env).  These are functions of (env, time) only - the step
+// kernel reads them as wave-uniform scalars.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_fill_tables(TableArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)a.rows * a.E) return;
+  const int r = (int)(i / a.E);
+  const int e = (int)(i % a.E);
+  const int64_t j = a.j0 + r;
+  const uint32_t eg = (uint32_t)(e + a.env_offset);
+  const Civil c = civil_from_epoch(a.t0[e] + j * (int64_t)a.dt);
+
+  // ClusterHouses.compute_OD_temp (env 1057-1081): minute resolution, coldest at 06:00 + phase
+  double od;
+  if (a.od_ext != nullptr && j < a.od_ext_rows) {
+    od = a.od_ext[j * a.E + e];
+  } else {
+    const double amp = 0.5 * (a.day_temp - a.night_temp), bias = 0.5 * (a.day_temp + a.night_temp);
+    const double tday = (double)c.hour + (double)c.minute / 60.0;
+    od = amp * sin(6.283185307179586476925286766559 * (tday + (-6.0 + a.phase[e])) / 24.0) + bias;
+    const u32x4 g = philox4x32_10(eg, (uint32_t)j, a.episode, TAG_OD_NOISE, a.k0, a.k1);
+    od += a.temp_std * gauss01(g.x, g.y);
+  }
+  a.tab_od[i] = (float)(od - a.temp_ref);
+
+  // utils.house_solar_gain (utils.py:1277-1350); identical for every house of the env
+  a.tab_solar[i] = a.solar_on ? (float)(a.area_shading * solar_cooling_load(c.hour, c.minute, c.month, c.day)) : 0.0f;
+
+  // PowerGrid.step (env 1236-1316), constant base power (env 1249)
+  const double base = a.avg_power_per_hvac * (double)a.n_total;
+  const double sod = (double)c.sod;
+  double sig;
+  if (a.signal_mode == MDR_SIGNAL_FLAT) {
+    sig = base;
+  } else if (a.signal_mode == MDR_SIGNAL_SINUSOIDALS) {
+    sig = base;
+    for (int q = 0; q < a.nb_sin; ++q)
+      sig += base * a.sin_ratios[q] * sin(6.283185307179586476925286766559 * sod / a.sin_periods[q]);
+  } else if (a.signal_mode == MDR_SIGNAL_REGULAR_STEPS) {
+    const double ampl = a.steps_amp * (double)a.n_total;
+    const double duty = base / ampl;
+    sig = (fmod(sod, a.steps_period) - (1.0 - duty) * a.steps_period) >= 0.0 ? ampl : 0.0;
+  } else {  // Perlin family; mktime(t) % 86400 == seconds of day for naive/UTC time (env 1297)
+    const double x = sod / a.perlin_period;
+    double n = 0.0;
+    for (int q = 0; q < a.perlin_octaves; ++q) {
+      const double f = ldexp(a.perlin_step, q);
+      const double w = (q < a.perlin_octaves - 1) ? ldexp(1.0, -q) : 1.0 / (ldexp(1.0, a.perlin_octaves) - 1.0);
+      n += w * lattice_noise_1d(x * f, eg, a.episode, a.k0, a.k1);
+    }
+    sig = fmax(0.0, base + base * a.perlin_amp * n);
+  }
+  sig *= a.ratio[e];                        // env 1312
+  a.tab_signal[i] = fmin(sig, a.max_power[e]);  // env 1314
+}
+
+// =================================================================================================
+// Step kernels
+// =================================================================================================
+__device__ __forceinline__ float temp_penalty(const StepArgs& a, float pen, double sum_pen, float max_pen) {
+  if (a.penalty_mode == MDR_PENALTY_INDIVIDUAL_L2) return pen;
+  const float common = (float)(sum_pen * a.inv_n_total);
+  if (a.penalty_mode == MDR_PENALTY_COMMON_L2) return common;
+  if (a.penalty_mode == MDR_PENALTY_COMMON_MAX) return max_pen;
+  return a.mix_i * pen + a.mix_c * common + a.mix_m * max_pen;
+}
+
+// signal part of the reward with the OLD signal (env 196, 234-251), fp64 per env
+__device__ __forceinline__ float signal_term(const StepArgs& a, double P, double S_old) {
+  const double d = (P - S_old) * a.inv_n_total;
+  return (float)(a.c_sig * d * d);
+}
+
+// ---- (1) one workgroup per env, VEC houses per thread per tile ---------------------------------
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<4> {
+  using F = float4;
+  using I = int4;
+  using B = uchar4;
+};
+template <>
+struct Vec<1> {
+  using F = float;
+  using I = int;
+  using B = unsigned char;
+};
+
+template <typename T, typename V>
+__device__ __forceinline__ void unpack(const V& v, T* out);
+template <>
+__device__ __forceinline__ void unpack<float, float4>(const float4& v, float* o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+template <>
+__device__ __forceinline__ void unpack<int, int4>(const int4& v, int* o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+template <>
+__device__ __forceinline__ void unpack<unsigned, uchar4>(const uchar4& v, unsigned* o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+template <>
+__device__ __forceinline__ void unpack<float, float>(const float& v, float* o) { o[0] = v; }
+template <>
+__device__ __forceinline__ void unpack<int, int>(const int& v, int* o) { o[0] = v; }
+template <>
+__device__ __forceinline__ void unpack<unsigned, unsigned char>(const unsigned char& v, unsigned* o) { o[0] = v; }
+
+__device__ __forceinline__ float4 pack4(const float* v) { return make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ int4 pack4(const int* v) { return make_int4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ uchar4 pack4(const unsigned* v) {
+  return make_uchar4((unsigned char)v[0], (unsigned char)v[1], (unsigned char)v[2], (unsigned char)v[3]);
+}
+
+template <int VEC, typename T>
+__device__ __forceinline__ void load_vec(const T* __restrict__ p, int64_t i, T* out) {
+  if constexpr (VEC == 4) {
+    using V = typename std::conditional<std::is_same<T, float>::value, float4, int4>::type;
+    unpack<T, V>(*reinterpret_cast<const V*>(p + i), out);
+  } else {
+    out[0] = p[i];
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void load_bytes(const uint8_t* __restrict__ p, int64_t i, unsigned* out) {
+  if constexpr (VEC == 4) {
+    unpack<unsigned, uchar4>(*reinterpret_cast<const uchar4*>(p + i), out);
+  } else {
+    out[0] = p[i];
+  }
+}
+template <int VEC, typename T>
+__device__ __forceinline__ void store_vec(T* __restrict__ p, int64_t i, const T* v) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<decltype(pack4(v))*>(p + i) = pack4(v);
+  } else {
+    p[i] = v[0];
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void store_bytes(uint8_t* __restrict__ p, int64_t i, const unsigned* v) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<uchar4*>(p + i) = pack4(v);
+  } else {
+    p[i] = (uint8_t)v[0];
+  }
+}
+
+// Loads VEC houses starting at flat index i, steps them, stores the new state, returns outputs.
+template <int VEC>
+__device__ __forceinline__ void step_vec(const StepArgs& a, int64_t i, float od_old, float solar, HouseOut* out, int* lockout) {
+  float Ta[VEC], Tm[VEC], k01[VEC], s0[VEC], k10[VEC], s1[VEC], iu[VEC], q[VEC], pm[VEC], tg[VEC], db[VEC];
+  int sso[VEC];
+  unsigned fl[VEC], act[VEC];
+  load_vec<VEC>(a.Ta, i, Ta);
+  load_vec<VEC>(a.Tm, i, Tm);
+  load_vec<VEC>(a.sso, i, sso);
+  load_bytes<VEC>(a.flags, i, fl);
+  if (a.action_source == MDR_ACTIONS_EXTERNAL) load_bytes<VEC>(a.actions, i, act);
+  load_vec<VEC>(a.k01, i, k01);
+  load_vec<VEC>(a.s0, i, s0);
+  load_vec<VEC>(a.k10, i, k10);
+  load_vec<VEC>(a.s1, i, s1);
+  load_vec<VEC>(a.inv_Ua, i, iu);
+  load_vec<VEC>(a.Q_hvac, i, q);
+  load_vec<VEC>(a.P_max, i, pm);
+  load_vec<VEC>(a.target, i, tg);
+  load_vec<VEC>(a.deadband, i, db);
+  load_vec<VEC>(a.lockout, i, lockout);
+  float nTa[VEC], nTm[VEC];
+  int nsso[VEC];
+  unsigned nfl[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    HouseIn h{Ta[v], Tm[v], sso[v], fl[v], k01[v], s0[v], k10[v], s1[v], iu[v], q[v], pm[v], tg[v], db[v], lockout[v]};
+    // BangBangController.act (agents/bangbang_controllers.py:49-59) on the pre-step observation
+    const bool cmd = (a.action_source == MDR_ACTIONS_BANGBANG) ? (Ta[v] > tg[v]) : (act[v] != 0u);
+    if (a.action_source == MDR_ACTIONS_BANGBANG) act[v] = cmd ? 1u : 0u;
+    out[v] = house_step(h, cmd, od_old, solar, a.dt);
+    nTa[v] = out[v].Ta;
+    nTm[v] = out[v].Tm;
+    nsso[v] = out[v].sso;
+    nfl[v] = out[v].flags;
+  }
+  store_vec<VEC>(a.Ta, i, nTa);
+  store_vec<VEC>(a.Tm, i, nTm);
+  store_vec<VEC>(a.sso, i, nsso);
+  store_bytes<VEC>(a.flags, i, nfl);
+  if (a.action_source == MDR_ACTIONS_BANGBANG && a.actions != nullptr) store_bytes<VEC>(a.actions, i, act);
+}
+
+// The five observation columns that do not depend on the env-wide reductions.
+template <int VEC>
+__device__ __forceinline__ void store_obs_local(const StepArgs& a, int64_t i, const HouseOut* o, const int* lockout) {
+  float c0[VEC], c1[VEC], c2[VEC], c3[VEC], c4[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    c0[v] = (o[v].Ta + a.obs_tshift) * 0.2f;  // (house_temp - 20) / 5, utils.py:800-802
+    c1[v] = (o[v].Tm + a.obs_tshift) * 0.2f;
+    c2[v] = (o[v].flags & 1u) ? 1.0f : 0.0f;  // utils.py:823
+    c3[v] = (o[v].flags & 2u) ? 1.0f : 0.0f;  // utils.py:824
+    c4[v] = (float)o[v].sso / (float)lockout[v];  // utils.py:826-828
+  }
+  store_vec<VEC>(a.obs + 0 * a.plane, i, c0);
+  store_vec<VEC>(a.obs + 1 * a.plane, i, c1);
+  store_vec<VEC>(a.obs + 2 * a.plane, i, c2);
+  store_vec<VEC>(a.obs + 3 * a.plane, i, c3);
+  store_vec<VEC>(a.obs + 4 * a.plane, i, c4);
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_reward_power(const StepArgs& a, int64_t i, const float* pen, double sum_pen,
+                                                   float max_pen, float sig_term, float o_sig, float o_pow) {
+  float r[VEC], c5[VEC], c6[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    r[v] = -(a.c_temp * temp_penalty(a, pen[v], sum_pen, max_pen) + sig_term);  // env 364-372
+    c5[v] = o_sig;
+    c6[v] = o_pow;
+  }
+  store_vec<VEC>(a.reward, i, r);
+  store_vec<VEC>(a.obs + 5 * a.plane, i, c5);
+  store_vec<VEC>(a.obs + 6 * a.plane, i, c6);
+}
+
+template <int VEC, int TILES, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_step_fused(StepArgs a) {
+  __shared__ double lds[3 * (THREADS / 64)];
+  const int e = blockIdx.x;
+  const float od_old = a.od_old[e];
+  const float solar = a.solar_new[e];
+  const int64_t base = (int64_t)e * a.N;
+  HouseOut o[TILES][VEC];
+  int lockout[TILES][VEC];
+  Red3 acc{0.0, 0.0, 0.0f};
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+    const int h = (t * THREADS + (int)threadIdx.x) * VEC;
+    if (h < a.N) {
+      step_vec<VEC>(a, base + h, od_old, solar, o[t], lockout[t]);
+      float p = 0.0f, ps = 0.0f;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        p += o[t][v].power;
+        ps += o[t][v].pen;
+        acc.max_pen = fmaxf(acc.max_pen, o[t][v].pen);
+      }
+      acc.sum_p += (double)p;
+      acc.sum_pen += (double)ps;
+      store_obs_local<VEC>(a, base + h, o[t], lockout[t]);
+    }
+  }
+  const Red3 tot = block_reduce<THREADS>(acc, lds);
+  const float sig_term = signal_term(a, tot.sum_p, a.sig_old[e]);
+  const float o_sig = (float)(a.sig_new[e] * a.inv_obs_norm);
+  const float o_pow = (float)(tot.sum_p * a.inv_obs_norm);
+  if (threadIdx.x == 0) a.P[e] = tot.sum_p;
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+    const int h = (t * THREADS + (int)threadIdx.x) * VEC;
+    if (h < a.N) {
+      float pen[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) pen[v] = o[t][v].pen;
+      store_reward_power<VEC>(a, base + h, pen, tot.sum_pen, tot.max_pen, sig_term, o_sig, o_pow);
+    }
+  }
+}
+
+// ---- (2) small envs: GROUP lanes per env (N <= GROUP <= 64), several envs per wavefront --------
+template <int GROUP>
+__global__ __launch_bounds__(256) void k_step_group(StepArgs a) {
+  const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / GROUP;
+  const int lane = threadIdx.x % GROUP;
+  const bool env_ok = gid < a.E;
+  const int e = env_ok ? (int)gid : a.E - 1;
+  const bool active = env_ok && lane < a.N;
+  const int64_t i = (int64_t)e * a.N + lane;
+  HouseOut o[1];
+  int lockout[1];
+  Red3 acc{0.0, 0.0, 0.0f};
+  if (active) {
+    step_vec<1>(a, i, a.od_old[e], a.solar_new[e], o, lockout);
+    acc.sum_p = (double)o[0].power;
+    acc.sum_pen = (double)o[0].pen;
+    acc.max_pen = o[0].pen;
+    store_obs_local<1>(a, i, o, lockout);
+  }
+  const Red3 tot = lanes_reduce<GROUP>(acc);
+  if (active) {
+    const float sig_term = signal_term(a, tot.sum_p, a.sig_old[e]);
+    if (lane == 0) a.P[e] = tot.sum_p;
+    store_reward_power<1>(a, i, &o[0].pen, tot.sum_pen, tot.max_pen, sig_term, (float)(a.sig_new[e] * a.inv_obs_norm),
+                          (float)(tot.sum_p * a.inv_obs_norm));
+  }
+}
+
+// ---- (3) split path: any N, several workgroups per env, and the sharded-houses case -------------
+// grid = (nblk, E); workgroup b of env e owns houses [b * 256 * VEC, (b + 1) * 256 * VEC)
+template <int VEC>
+__global__ __launch_bounds__(256) void k_step_partial(StepArgs a) {
+  __shared__ double lds[3 * 4];
+  const int e = blockIdx.y;
+  const int h = ((int)blockIdx.x * 256 + (int)threadIdx.x) * VEC;
+  const int64_t base = (int64_t)e * a.N;
+  Red3 acc{0.0, 0.0, 0.0f};
+  if (h < a.N) {
+    HouseOut o[VEC];
+    int lockout[VEC];
+    step_vec<VEC>(a, base + h, a.od_old[e], a.solar_new[e], o, lockout);
+    float p = 0.0f, ps = 0.0f;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      p += o[v].power;
+      ps += o[v].pen;
+      acc.max_pen = fmaxf(acc.max_pen, o[v].pen);
+    }
+    acc.sum_p = (double)p;
+    acc.sum_pen = (double)ps;
+    store_obs_local<VEC>(a, base + h, o, lockout);
+  }
+  const Red3 tot = block_reduce<256>(acc, lds);
+  if (threadIdx.x == 0) {
+    double* rec = a.partials + ((int64_t)e * a.nblk + blockIdx.x) * 3;
+    rec[0] = tot.sum_p;
+    rec[1] = tot.sum_pen;
+    rec[2] = (double)tot.max_pen;
+  }
+}
+
+// one workgroup per env: fixed-order sum of the per-workgroup partial records -> tot_sum / tot_max
+__global__ __launch_bounds__(256) void k_reduce_partials(StepArgs a) {
+  __shared__ double lds[3 * 4];
+  const int e = blockIdx.x;
+  Red3 acc{0.0, 0.0, 0.0f};
+  for (int b = threadIdx.x; b < a.nblk; b += 256) {
+    const double* rec = a.partials + ((int64_t)e * a.nblk + b) * 3;
+    acc.sum_p += rec[0];
+    acc.sum_pen += rec[1];
+    acc.max_pen = fmaxf(acc.max_pen, (float)rec[2]);
+  }
+  const Red3 tot = block_reduce<256>(acc, lds);
+  if (threadIdx.x == 0) {
+    a.tot_sum[e] = tot.sum_p;
+    a.tot_sum[a.E + e] = tot.sum_pen;
+    a.tot_max[e] = (double)tot.max_pen;
+  }
+}
+
+// rewards and the two power columns from the (possibly all-reduced) totals; re-derives the penalty
+template <int VEC>
+__global__ __launch_bounds__(256) void k_step_finish(StepArgs a) {
+  const int e = blockIdx.y;
+  const int h = ((int)blockIdx.x * 256 + (int)threadIdx.x) * VEC;
+  const double P = a.tot_sum[e];
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.P[e] = P;
+  if (h >= a.N) return;
+  const int64_t i = (int64_t)e * a.N + h;
+  float Ta[VEC], tg[VEC], db[VEC], pen[VEC];
+  load_vec<VEC>(a.Ta, i, Ta);
+  load_vec<VEC>(a.target, i, tg);
+  load_vec<VEC>(a.deadband, i, db);
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    const float hi = fmaf(0.5f, db[v], tg[v]), lo = fmaf(-0.5f, db[v], tg[v]);
+    const float above = Ta[v] - hi, below = lo - Ta[v];
+    pen[v] = above > 0.0f ? above * above : (below > 0.0f ? below * below : 0.0f);
+  }
+  store_reward_power<VEC>(a, i, pen, a.tot_sum[a.E + e], (float)a.tot_max[e], signal_term(a, P, a.sig_old[e]),
+                          (float)(a.sig_new[e] * a.inv_obs_norm), (float)(P * a.inv_obs_norm));
+}
+
+// =================================================================================================
+// Launchers (host)
+// =================================================================================================
+hipError_t launch_sample(const EpisodeArgs& a, hipStream_t s) {
+  const int64_t n = (int64_t)a.E * a.N;
+  hipLaunchKernelGGL(k_sample_houses, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_sample_envs, dim3((unsigned)((a.E + 255) / 256)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_env_max_power, dim3((unsigned)a.E), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_load(const EpisodeArgs& a, const mdr_episode_t& ep, hipStream_t s) {
+  const int64_t n = (int64_t)a.E * a.N;
+  hipLaunchKernelGGL(k_load_houses, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, ep);
+  hipLaunchKernelGGL(k_load_envs, dim3((unsigned)((a.E + 255) / 256)), dim3(256), 0, s, a, ep);
+  hipLaunchKernelGGL(k_env_max_power, dim3((unsigned)a.E), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_reset_obs(const StepArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_reset_obs, dim3((unsigned)((a.plane + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_tables(const TableArgs& a, hipStream_t s) {
+  const int64_t n = (int64_t)a.rows * a.E;
+  hipLaunchKernelGGL(k_fill_tables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+template <int VEC, int THREADS>
+static void launch_fused_tiles(const StepArgs& a, int tiles, hipStream_t s) {
+  const dim3 g((unsigned)a.E), b(THREADS);
+  switch (tiles) {
+    case 1: hipLaunchKernelGGL((k_step_fused<VEC, 1, THREADS>), g, b, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((k_step_fused<VEC, 2, THREADS>), g, b, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((k_step_fused<VEC, 3, THREADS>), g, b, 0, s, a); break;
+    default: hipLaunchKernelGGL((k_step_fused<VEC, 4, THREADS>), g, b, 0, s, a); break;
+  }
+}
+
+StepPlan plan_step(int N) {
+  StepPlan p{};
+  if (N % 4 == 0 && N >= 64 && N <= 4096) {
+    p.kind = STEP_FUSED;
+    p.vec = 4;
+    p.threads = N <= 256 ? 64 : (N <= 512 ? 128 : 256);
+    p.tiles = (N + p.threads * 4 - 1) / (p.threads * 4);
+  } else if (N <= 64) {
+    p.kind = STEP_GROUP;
+    p.vec = 1;
+    int g = 1;
+    while (g < N) g <<= 1;
+    p.threads = g;  // lanes per env
+    p.tiles = 1;
+  } else if (N <= 1024) {
+    p.kind = STEP_FUSED;
+    p.vec = 1;
+    p.threads = 256;
+    p.tiles = (N + 255) / 256;
+  } else {
+    p.kind = STEP_SPLIT;
+    p.vec = (N % 4 == 0) ? 4 : 1;
+    p.threads = 256;
+    p.tiles = 1;
+  }
+  return p;
+}
+
+int64_t split_blocks(int N) {
+  const int vec = (N % 4 == 0) ? 4 : 1;
+  return ((int64_t)N + 256 * vec - 1) / (256 * vec);
+}
+
+hipError_t launch_step_begin_split(const StepArgs& a, hipStream_t s) {
+  const dim3 g((unsigned)a.nblk, (unsigned)a.E), b(256);
+  if (a.N % 4 == 0)
+    hipLaunchKernelGGL(k_step_partial<4>, g, b, 0, s, a);
+  else
+    hipLaunchKernelGGL(k_step_partial<1>, g, b, 0, s, a);
+  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)a.E), b, 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_step_end_split(const StepArgs& a, hipStream_t s) {
+  const dim3 g((unsigned)a.nblk, (unsigned)a.E), b(256);
+  if (a.N % 4 == 0)
+    hipLaunchKernelGGL(k_step_finish<4>, g, b, 0, s, a);
+  else
+    hipLaunchKernelGGL(k_step_finish<1>, g, b, 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_step(const StepArgs& a, const StepPlan& p, hipStream_t s) {
+  if (p.kind == STEP_FUSED) {
+    if (p.vec == 4) {
+      if (p.threads == 64) launch_fused_tiles<4, 64>(a, p.tiles, s);
+      else if (p.threads == 128) launch_fused_tiles<4, 128>(a, p.tiles, s);
+      else launch_fused_tiles<4, 256>(a, p.tiles, s);
+    } else {
+      launch_fused_tiles<1, 256>(a, p.tiles, s);
+    }
+    return hipGetLastError();
+  }
+  if (p.kind == STEP_GROUP) {
+    const int64_t lanes = (int64_t)a.E * p.threads;
+    const dim3 g((unsigned)((lanes + 255) / 256)), b(256);
+    switch (p.threads) {
+      case 1: hipLaunchKernelGGL(k_step_group<1>, g, b, 0, s, a); break;
+      case 2: hipLaunchKernelGGL(k_step_group<2>, g, b, 0, s, a); break;
+      case 4: hipLaunchKernelGGL(k_step_group<4>, g, b, 0, s, a); break;
+      case 8: hipLaunchKernelGGL(k_step_group<8>, g, b, 0, s, a); break;
+      case 16: hipLaunchKernelGGL(k_step_group<16>, g, b, 0, s, a); break;
+      case 32: hipLaunchKernelGGL(k_step_group<32>, g, b, 0, s, a); break;
+      default: hipLaunchKernelGGL(k_step_group<64>, g, b, 0, s, a); break;
+    }
+    return hipGetLastError();
+  }
+  hipError_t err = launch_step_begin_split(a, s);
+  if (err != hipSuccess) return err;
+  return launch_step_end_split(a, s);
+}
+
+}  // namespace mdr

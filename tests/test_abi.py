@@ -1,0 +1,76 @@
+"""The C-ABI library loads and exports every symbol include/mdr.h declares; the ctypes mirrors match the header.
+No compute calls here (no GPU in the build container)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import mdr_amd
+from mdr_amd import _native as nat
+
+HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mdr.h")
+
+
+def _header():
+    with open(HEADER) as f:
+        text = f.read()
+    return re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+
+
+def _struct_fields(text, name):
+    body = re.search(r"typedef struct %s \{(.*?)\} %s_t;" % (name, name), text, flags=re.S).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        decl = re.sub(r"^(const\s+)?(uint32_t|int32_t|int64_t|uint8_t|double|float)\s+", "", decl)
+        for part in decl.split(","):
+            fields.append(re.sub(r"[\s\*]|\[.*?\]|const", "", part))
+    return fields
+
+
+def test_library_is_built_and_exports_header_symbols():
+    mdr_amd.build_native()
+    lib = mdr_amd.load_native()
+    declared = set(re.findall(r"\b(mdr_[a-z_]+)\s*\(", _header()))
+    assert declared == set(nat.EXPORTS), declared ^ set(nat.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mdr_abi_version() == nat.MDR_ABI_VERSION
+    assert lib.mdr_status_string(0) == b"ok"
+    assert lib.mdr_partials_per_env(1024) == 1 and lib.mdr_partials_per_env(1025) == 5 and lib.mdr_partials_per_env(10**6) == 977
+
+
+@pytest.mark.parametrize("cname,cls", [("mdr_config", nat.MdrConfig), ("mdr_buffers", nat.MdrBuffers), ("mdr_episode", nat.MdrEpisode)])
+def test_ctypes_mirror_matches_header(cname, cls):
+    assert _struct_fields(_header(), cname) == [f[0] for f in cls._fields_]
+
+
+def test_create_validates_without_touching_the_gpu():
+    """mdr_env_create is host-only: size guard and the reference's ValueError conditions."""
+    lib = mdr_amd.load_native()
+    cfg = nat.MdrConfig()
+    h = C.c_void_p()
+    assert lib.mdr_env_create(C.byref(cfg), C.byref(h)) == nat.MDR_ERR_INVALID      # struct_size == 0
+    assert b"size mismatch" in lib.mdr_last_error(h)
+    lib.mdr_env_destroy(h)
+    assert lib.mdr_env_step(None, None, 0, None) == nat.MDR_ERR_INVALID
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.dirname(nat.__file__)
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                with open(os.path.join(root, f)) as fh:
+                    src = fh.read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(nat, "_lib", None)
+    monkeypatch.setattr(nat, "LIB_PATH", "/nonexistent/libmdr_hip.so")
+    with pytest.raises(nat.NativeLibraryMissing):
+        nat.load()

@@ -1,0 +1,282 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the reference's golden vectors and the oracle.
+
+Tolerances (BASELINE.json north_star: "within 1e-5 relative fp32 on temperatures/rewards"):
+  * hvac_turned_on / hvac_lockout / seconds_since_off / cluster_hvac_power : bit-exact
+  * house_temp, house_mass_temp (deg C)                                     : |d| <= 1e-5 * |T|
+  * rewards : |d| <= 1e-5 * |r| + 1e-5.  The absolute floor is in normalised reward units (1 == a 1 degC
+    temperature error, env 346-350); a pure relative bound is ill-posed where the penalty crosses zero.
+  * regulation signal (fp64 tables) : 1e-9 relative ; solar gain / OD temperature (fp32 tables) : 1e-6
+Actions are always the RECORDED sequence: a bang-bang threshold can flip on a 1e-7 difference and the
+trajectories would then legitimately diverge (SURVEY.md section 7 "threshold-driven divergence").
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+T_RTOL = 1e-5
+R_RTOL, R_ATOL = 1e-5, 1e-5
+
+
+def _mdr():
+    import mdr_amd
+    return mdr_amd
+
+
+def run_fixture(g, table_steps=64):
+    mdr = _mdr()
+    env = mdr.BatchedDemandResponseEnv(g.config, nb_envs=1, device="cuda:0", seed=g.seed, table_steps=table_steps)
+    env.load_episode(g.params(), od_table=g.od_table(), seed=g.seed, episode=0)
+    return env
+
+
+@pytest.mark.parametrize("name", gu.names())
+def test_hip_path_reproduces_reference_golden(name):
+    g = gu.Golden(name)
+    a = g.a
+    env = run_fixture(g)
+    assert env.t["max_power"][0].item() == pytest.approx(float(a["p_max_power"]), rel=1e-12)
+    assert env.reg_signal()[0].item() == pytest.approx(float(a["S"][0]), rel=1e-9, abs=1e-6)
+    acts = torch.from_numpy(a["actions"]).to("cuda:0")
+    hist = {k: [] for k in ("Ta", "Tm", "sso", "flags", "reward", "P", "S", "solar")}
+    for t in range(g.T):
+        obs, reward, done, info = env.step(acts[t][None, :])
+        hist["Ta"].append(env.house_temp()[0])
+        hist["Tm"].append(env.house_mass_temp()[0])
+        hist["sso"].append(env.t["sso"][0].clone())
+        hist["flags"].append(env.t["flags"][0].clone())
+        hist["reward"].append(reward[0].clone())
+        hist["P"].append(info["cluster_hvac_power"][0].clone())
+        hist["S"].append(env.reg_signal()[0].clone())
+        hist["solar"].append(env.solar_gain()[0].clone())
+        assert not bool(done.any())
+    h = {k: torch.stack(v).cpu().numpy() for k, v in hist.items()}
+    np.testing.assert_array_equal(h["flags"] & 1, a["on"])
+    np.testing.assert_array_equal((h["flags"] >> 1) & 1, a["lock"])
+    np.testing.assert_array_equal(h["sso"], a["sso"])
+    np.testing.assert_array_equal(h["P"], a["P"])
+    np.testing.assert_allclose(h["S"], a["S"][1:], rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(h["solar"], a["solar"], rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(h["Ta"], a["Ta"], rtol=T_RTOL, atol=0)
+    np.testing.assert_allclose(h["Tm"], a["Tm"], rtol=T_RTOL, atol=0)
+    np.testing.assert_allclose(h["reward"], a["reward"], rtol=R_RTOL, atol=R_ATOL)
+
+
+@pytest.mark.parametrize("table_steps", [1, 7, 64])
+def test_time_table_chunking_is_invisible(table_steps):
+    """Refilling the per-env time tables every K steps must not change a single bit."""
+    g = gu.Golden("s3_c3_heterogeneous")
+    ref = run_fixture(g, table_steps=1024)
+    env = run_fixture(g, table_steps=table_steps)
+    acts = torch.from_numpy(g.a["actions"]).to("cuda:0")
+    for t in range(150):
+        ref.step(acts[t][None, :])
+        env.step(acts[t][None, :])
+    for k in ("Ta", "Tm", "sso", "flags", "reward", "obs", "P"):
+        assert torch.equal(ref.t[k], env.t[k]), k
+
+
+def test_observation_columns_match_normStateDict():
+    """The 7 planes the kernel writes == entries 0,1,5,6,7,9,10 of utils.normStateDict (utils.py:800-841)."""
+    for name in ("s1_c1_sinusoidals", "s3_c3_heterogeneous"):
+        g = gu.Golden(name)
+        env = run_fixture(g)
+        steps = g.meta["norm_steps"]
+        cols = [0, 1, 5, 6, 7, 9, 10]
+        k = 0
+        acts = torch.from_numpy(g.a["actions"]).to("cuda:0")
+        if steps[0] == 0:
+            np.testing.assert_allclose(env.t["obs"][:, 0, :].cpu().numpy().T, g.a["norm_state"][0][:, cols], rtol=2e-5, atol=2e-6)
+            k = 1
+        for t in range(g.T):
+            obs, *_ = env.step(acts[t][None, :])
+            if (t + 1) in steps:
+                np.testing.assert_allclose(obs[:, 0, :].cpu().numpy().T, g.a["norm_state"][k][:, cols], rtol=2e-5, atol=2e-6)
+                k += 1
+        assert k == len(steps)
+
+
+def _oracle_pair(cfg, E, seed, **kw):
+    from oracle import mdr_oracle as mo
+    mdr = _mdr()
+    env = mdr.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=seed, **kw)
+    env.reset(episode=0)
+    ora = mo.OracleEnv(cfg, nb_envs=E).reset(seed=seed, episode=0)
+    return env, ora
+
+
+def _cfg(n, **patches):
+    mdr = _mdr()
+    cfg = mdr.default_config()
+    cfg["default_env_prop"]["cluster_prop"]["nb_agents"] = n
+    cfg["default_env_prop"]["power_grid_prop"]["base_power_mode"] = "constant"
+    for dotted, v in patches.items():
+        node = cfg
+        parts = dotted.split(".")
+        for p in parts[:-1]:
+            node = node[p]
+        node[parts[-1]] = v
+    return cfg
+
+
+def _compare_state(env, ora, reward=None, r_ref=None):
+    flags = env.t["flags"].cpu().numpy()
+    np.testing.assert_array_equal((flags & 1).astype(bool), ora.on)
+    np.testing.assert_array_equal((flags & 2).astype(bool), ora.lock)
+    np.testing.assert_array_equal(env.t["sso"].cpu().numpy(), ora.sso)
+    np.testing.assert_array_equal(env.t["P"].cpu().numpy(), ora.P)
+    np.testing.assert_allclose(env.house_temp().cpu().numpy(), ora.Ta, rtol=T_RTOL, atol=0)
+    np.testing.assert_allclose(env.house_mass_temp().cpu().numpy(), ora.Tm, rtol=T_RTOL, atol=0)
+    np.testing.assert_allclose(env.reg_signal().cpu().numpy(), ora.S, rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(env.od_temp().cpu().numpy(), ora.OD, rtol=0, atol=5e-6)
+    if reward is not None:
+        np.testing.assert_allclose(reward.cpu().numpy(), r_ref, rtol=R_RTOL, atol=R_ATOL)
+
+
+# every kernel family: sub-wave groups (N<=64), fused scalar, fused float4 with 1..4 tiles / 64..256 threads, split
+SHAPES = [(37, 1), (33, 5), (16, 10), (9, 50), (5, 64), (6, 100), (4, 200), (5, 256), (3, 508), (3, 1021),
+          (4, 1024), (2, 2048), (2, 3000), (2, 4096), (2, 4100), (1, 10001)]
+
+
+@pytest.mark.parametrize("E,N", SHAPES)
+def test_device_reset_and_steps_match_oracle(E, N):
+    """Device-sampled episode (Philox streams) + 40 steps with random actions, every kernel family."""
+    cfg = _cfg(N, **{"noise_house_prop.noise_mode": "big_noise", "noise_hvac_prop.noise_mode": "big_noise",
+                     "default_hvac_prop.lockout_noise": 12, "default_house_prop.deadband": 0.5,
+                     "default_env_prop.power_grid_prop.signal_mode": "perlin",
+                     "default_env_prop.power_grid_prop.artificial_signal_ratio_range": 2,
+                     "default_env_prop.cluster_prop.temp_mode": "noisy_sinusoidal_heatwave"})
+    env, ora = _oracle_pair(cfg, E, seed=2024 + N)
+    # sampled parameters, draw by draw
+    for name, ref in (("Ua", ora.Ua), ("Cm", ora.Cm), ("Ca", ora.Ca), ("Hm", ora.Hm), ("capacity", ora.capacity)):
+        np.testing.assert_allclose(env.t[name].cpu().numpy(), ref, rtol=2e-7)
+    np.testing.assert_array_equal(env.t["lockout"].cpu().numpy(), ora.lockout)
+    np.testing.assert_array_equal(env.t["t0"].cpu().numpy(), ora.t0)
+    np.testing.assert_allclose(env.t["ratio"].cpu().numpy(), ora.ratio, rtol=1e-12)
+    np.testing.assert_allclose(env.t["max_power"].cpu().numpy(), ora.max_power, rtol=1e-12)
+    np.testing.assert_allclose(env.target_temp().cpu().numpy(), ora.target, rtol=2e-7)
+    _compare_state(env, ora)
+    rng = np.random.default_rng(N)
+    for t in range(40):
+        act = (rng.random((E, N)) < 0.55).astype(np.uint8)
+        obs, reward, done, info = env.step(torch.from_numpy(act).to("cuda:0"))
+        r_ref = ora.step(act)
+        _compare_state(env, ora, reward, r_ref)
+    np.testing.assert_allclose(obs.cpu().numpy(), ora.dynamic_obs(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("mode", ["individual_L2", "common_L2", "common_max", "mixture"])
+@pytest.mark.parametrize("N", [48, 1024, 5000])
+def test_penalty_modes(mode, N):
+    cfg = _cfg(N, **{"noise_house_prop.noise_mode": "big_noise", "default_house_prop.deadband": 1,
+                     "default_env_prop.reward_prop.temp_penalty_mode": mode,
+                     "default_env_prop.reward_prop.alpha_temp": 0.6, "default_env_prop.reward_prop.alpha_sig": 1.7,
+                     "default_env_prop.power_grid_prop.signal_mode": "sinusoidals"})
+    cfg["default_env_prop"]["reward_prop"]["temp_penalty_parameters"]["mixture"] = {
+        "alpha_ind_L2": 1, "alpha_common_L2": 2, "alpha_common_max": 0.5}
+    env, ora = _oracle_pair(cfg, 3, seed=99)
+    rng = np.random.default_rng(1)
+    for t in range(25):
+        act = (rng.random((3, N)) < 0.5).astype(np.uint8)
+        _, reward, _, _ = env.step(torch.from_numpy(act).to("cuda:0"))
+        _compare_state(env, ora, reward, ora.step(act))
+
+
+@pytest.mark.parametrize("signal", ["flat", "sinusoidals", "regular_steps", "perlin", "fast++_perlin"])
+def test_signal_modes_long_horizon(signal):
+    """Signals over 3 simulated hours crossing midnight (fixed start 22:30), fp64 tables vs oracle."""
+    cfg = _cfg(64, **{"default_env_prop.power_grid_prop.signal_mode": signal,
+                      "default_env_prop.start_datetime_mode": "fixed",
+                      "default_env_prop.start_datetime": "2021-08-30 22:30:00",
+                      "default_env_prop.time_step": 30})
+    env, ora = _oracle_pair(cfg, 4, seed=5)
+    act = np.ones((4, 64), dtype=np.uint8)
+    dev_act = torch.from_numpy(act).to("cuda:0")
+    for t in range(360):
+        env.step(dev_act)
+        ora.step(act)
+        if t % 20 == 0:
+            np.testing.assert_allclose(env.reg_signal().cpu().numpy(), ora.S, rtol=1e-9, atol=1e-6)
+    _compare_state(env, ora)
+
+
+def test_fused_bangbang_is_self_consistent_and_matches_oracle():
+    """The in-kernel bang-bang rule: feed the actions the kernel reports to the oracle and compare; the rule
+    itself (house_temp > target on the PRE-step observation) is checked against the kernel's own temperatures."""
+    cfg = _cfg(1024, **{"noise_house_prop.noise_mode": "big_noise", "noise_hvac_prop.noise_mode": "big_noise"})
+    env, ora = _oracle_pair(cfg, 4, seed=31)
+    for t in range(60):
+        pre = (env.t["Ta"] > env.t["target"]).to(torch.uint8)
+        _, reward, _, _ = env.step_bangbang()
+        taken = env.t["actions"]
+        assert torch.equal(pre, taken)
+        _compare_state(env, ora, reward, ora.step(taken.cpu().numpy()))
+    # and the oracle's own bang-bang decision agrees wherever the temperature is not within fp32 noise of the target
+    margin = np.abs(ora.Ta - ora.target) > 1e-4
+    np.testing.assert_array_equal(ora.bangbang_actions()[margin], (env.t["Ta"] > env.t["target"]).cpu().numpy()[margin])
+
+
+def test_rollout_equals_single_steps():
+    cfg = _cfg(1024, **{"noise_house_prop.noise_mode": "big_noise"})
+    mdr = _mdr()
+    a = mdr.BatchedDemandResponseEnv(cfg, nb_envs=8, device="cuda:0", seed=7, table_steps=16)
+    b = mdr.BatchedDemandResponseEnv(cfg, nb_envs=8, device="cuda:0", seed=7, table_steps=16)
+    a.reset(episode=0)
+    b.reset(episode=0)
+    a.rollout(50)
+    for _ in range(50):
+        b.step_bangbang()
+    for k in ("Ta", "Tm", "sso", "flags", "reward", "obs", "P", "actions"):
+        assert torch.equal(a.t[k], b.t[k]), k
+    assert a.steps_taken == b.steps_taken == 50
+
+
+def test_env_partition_invariance():
+    """C4-style sharding: envs [0,E) in one batch == the same envs in two batches with env_offset (no collective)."""
+    cfg = _cfg(256, **{"noise_house_prop.noise_mode": "big_noise", "noise_hvac_prop.noise_mode": "small_noise",
+                       "default_env_prop.power_grid_prop.artificial_signal_ratio_range": 3})
+    mdr = _mdr()
+    whole = mdr.BatchedDemandResponseEnv(cfg, nb_envs=12, device="cuda:0", seed=77)
+    lo = mdr.BatchedDemandResponseEnv(cfg, nb_envs=5, device="cuda:0", seed=77, env_offset=0)
+    hi = mdr.BatchedDemandResponseEnv(cfg, nb_envs=7, device="cuda:0", seed=77, env_offset=5)
+    for e in (whole, lo, hi):
+        e.reset(episode=3)
+        e.rollout(80)
+    for k in ("Ta", "Tm", "sso", "flags", "reward", "P", "t0"):
+        assert torch.equal(whole.t[k][:5], lo.t[k]), k
+        assert torch.equal(whole.t[k][5:], hi.t[k]), k
+    assert torch.equal(whole.t["obs"][:, :5], lo.t["obs"]) and torch.equal(whole.t["obs"][:, 5:], hi.t["obs"])
+
+
+def test_deepcopy_is_independent_snapshot():
+    import copy
+    cfg = _cfg(128)
+    mdr = _mdr()
+    env = mdr.BatchedDemandResponseEnv(cfg, nb_envs=3, device="cuda:0", seed=1)
+    env.reset()
+    env.rollout(70)       # past one table refill (K=64)
+    twin = copy.deepcopy(env)
+    env.rollout(30)
+    before = twin.t["Ta"].clone()
+    twin.rollout(30)
+    assert not torch.equal(before, twin.t["Ta"])
+    for k in ("Ta", "Tm", "sso", "flags", "reward", "P"):
+        assert torch.equal(env.t[k], twin.t[k]), k
+
+
+def test_errors_map_to_reference_exceptions():
+    mdr = _mdr()
+    with pytest.raises(ValueError):
+        mdr.BatchedDemandResponseEnv(_cfg(8, **{"default_env_prop.power_grid_prop.signal_mode": "square"}), device="cuda:0")
+    with pytest.raises(ValueError):
+        mdr.BatchedDemandResponseEnv(_cfg(8, **{"default_env_prop.reward_prop.temp_penalty_mode": "L1"}), device="cuda:0")
+    with pytest.raises(ValueError):   # HVAC.__init__: latent fraction outside [0, 1] (env 438-443)
+        mdr.BatchedDemandResponseEnv(_cfg(8, **{"default_hvac_prop.latent_cooling_fraction": 1.5}), device="cuda:0")
+    with pytest.raises(ValueError):   # lockout_duration + noise could go negative (env 444-449)
+        mdr.BatchedDemandResponseEnv(_cfg(8, **{"default_hvac_prop.lockout_noise": 50}), device="cuda:0")
+    env = mdr.BatchedDemandResponseEnv(_cfg(8), device="cuda:0")
+    with pytest.raises(RuntimeError):  # step before reset
+        env.step_bangbang()
