@@ -241,7 +241,7 @@ class BatchedDemandResponseEnv:
         if actions.dtype == torch.bool:
             actions = actions.view(torch.uint8)
         if (actions.dtype != torch.uint8 or actions.device != self.device or not actions.is_contiguous()
-                or tuple(actions.shape) != (self.nb_envs, self.nb_houses)):
+                or tuple(actions.shape) != (self.nb_envs, self.nb_houses) or actions.data_ptr() % 4 != 0):
             self.t["actions"].copy_(actions.reshape(self.nb_envs, self.nb_houses).to(self.device) != 0)
             return self.t["actions"].data_ptr()
         self._keep_actions = actions
