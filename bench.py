@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--stagger", type=int, default=int(os.environ.get("MDR_STAGGER", "0")))
+    ap.add_argument("--stagger", type=int, default=int(os.environ.get("MDR_STAGGER", "2304")))
     args = ap.parse_args()
 
     import torch

@@ -43,7 +43,7 @@ class BatchedDemandResponseEnv:
     def __init__(self, config: dict, nb_envs: int = 1, device=None, seed: int = 0, test: bool = False,
                  table_steps: int = 64, env_offset: int = 0,
                  house_shard: Optional[Tuple[int, int]] = None, process_group=None,
-                 stagger_bytes: int = 0):
+                 stagger_bytes: int = 2304):
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedDemandResponseEnv needs a ROCm device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")

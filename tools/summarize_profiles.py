@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output under gpurun_out/ into the tracked summaries under profiles/.
+
+    python tools/summarize_profiles.py r01
+
+Inputs (written on the GPU box by the commands recorded in profiles/<round>_README.md):
+  gpurun_out/prof_<round>/step_kernel_stats.csv       rocprofv3 --kernel-trace --stats
+  gpurun_out/pmc_fetch/fetch_counter_collection.csv   rocprofv3 --pmc FETCH_SIZE   (own pass)
+  gpurun_out/pmc_write/write_counter_collection.csv   rocprofv3 --pmc WRITE_SIZE   (own pass)
+Outputs: profiles/<round>_kernel_stats.csv, profiles/<round>_traffic.json, profiles/<round>_bench.json
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md "HBM": counters are in KiB; on gfx950 FETCH_SIZE
+reports exactly half of the bytes of a wide (16 B/lane) coalesced streaming read, so it is doubled;
+WRITE_SIZE is exact for 16 B/lane streaming stores.
+"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+
+
+def counter_mean(path, kernel_substr):
+    vals = collections.defaultdict(list)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if kernel_substr in r["Kernel_Name"]:
+                vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in vals.items()}
+
+
+def main(rnd):
+    os.makedirs(P, exist_ok=True)
+    stats = os.path.join(G, "prof_" + rnd, "step_kernel_stats.csv")
+    shutil.copy(stats, os.path.join(P, rnd + "_kernel_stats.csv"))
+    with open(stats) as f:
+        rows = list(csv.DictReader(f))
+    step = [r for r in rows if "k_step_fused" in r["Name"]][0]
+    kernel = "k_step_fused"
+    fetch, nf = counter_mean(os.path.join(G, "pmc_fetch", "fetch_counter_collection.csv"), kernel)["FETCH_SIZE"]
+    write, nw = counter_mean(os.path.join(G, "pmc_write", "write_counter_collection.csv"), kernel)["WRITE_SIZE"]
+    houses = 4096 * 1024
+    fetch_bytes = fetch * 1024 * 2      # gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads
+    write_bytes = write * 1024
+    out = {
+        "kernel": step["Name"], "calls": int(step["Calls"]), "avg_ns": float(step["AverageNs"]),
+        "min_ns": float(step["MinNs"]), "max_ns": float(step["MaxNs"]),
+        "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write, "pmc_dispatches": [nf, nw],
+        "fetch_bytes_corrected_x2": fetch_bytes, "write_bytes": write_bytes,
+        "hbm_bytes_per_launch": fetch_bytes + write_bytes,
+        "algorithmic_bytes_per_launch": 99 * houses,
+        "algorithmic_read_bytes": 53 * houses, "algorithmic_write_bytes": 46 * houses,
+        "achieved_GBps_from_rocprof_avg": 99 * houses / float(step["AverageNs"]),
+        "note": "reads: state 13 + parameters 40 B/house; writes: state 13 + action 1 (in-kernel bang-bang) + reward 4 + obs 28 B/house",
+    }
+    with open(os.path.join(P, rnd + "_traffic.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    bench = os.path.join(G, "bench_" + rnd + ".json")
+    if os.path.isfile(bench):
+        shutil.copy(bench, os.path.join(P, rnd + "_bench.json"))
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
