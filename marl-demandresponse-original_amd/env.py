@@ -134,6 +134,17 @@ class MADemandResponseEnv:
         seed = self._fixed_seed if self._fixed_seed is not None else random.getrandbits(63)
         self._batched.reset(seed=seed, episode=self._episode)
         self._episode += 1
+        self._episode_started()
+
+    def load_episode(self, params, od_table=None, seed=0):
+        """Replay hook (no counterpart in the reference): start an episode from given raw per-house / per-env
+        parameters and, optionally, a recorded outdoor-temperature sequence instead of sampling them.
+        See BatchedDemandResponseEnv.load_episode for the array names.  Returns the reset observation dict."""
+        self._batched.load_episode(params, od_table=od_table, seed=seed, episode=0)
+        self._episode_started()
+        return self._make_obs_dict()
+
+    def _episode_started(self):
         b = self._batched
         st = {k: b.t[k][0].cpu().numpy() for k in ("Ua", "Cm", "Ca", "Hm", "capacity", "COP", "latent", "deadband")}
         st["lockout"] = b.t["lockout"][0].cpu().numpy()
