@@ -159,6 +159,27 @@ typedef struct mdr_episode {
   const double *phase, *ratio;
 } mdr_episode_t;
 
+/* What utils.normStateDict (utils.py:740-880) reads from config_dict besides the observation itself. */
+typedef enum mdr_obs_layout {
+  MDR_OBS_PLANES = 0, /* out[F][E][N]: feature-major planes (coalesced; a GEMM consumes it as X^T) */
+  MDR_OBS_ROWS = 1    /* out[E][N][F]: one contiguous normStateDict vector per house */
+} mdr_obs_layout;
+
+typedef struct mdr_obs_spec {
+  uint32_t struct_size;
+  int32_t layout;                  /* mdr_obs_layout */
+  /* default_env_prop.state_properties (config.py:311-317) */
+  int32_t state_hour, state_day, state_solar_gain, state_thermal, state_hvac;
+  /* default_env_prop.message_properties (config.py:319-322) */
+  int32_t message_thermal, message_hvac;
+  int32_t nb_comm;                 /* messages per house: min(nb_agents_comm, nb_agents - 1), env 808-810 */
+  const int32_t *links;            /* device int32 [N][nb_comm] sender ids (ClusterHouses.agent_communicators,
+                                      env 806-902), shared by all envs; NULL = circular "neighbours" (816-828) */
+  double comm_defect_prob;         /* per-link probability of an all-zero message (env 992-1002) */
+  /* normalisation defaults (default_house_prop / default_hvac_prop / reward_prop.norm_reg_sig) */
+  double def_Ua, def_Cm, def_Ca, def_Hm, def_COP, def_capacity, def_latent, norm_reg_sig;
+} mdr_obs_spec_t;
+
 int mdr_abi_version(void);
 const char *mdr_status_string(int status);
 /* Last error text of a handle ("" if none); valid until the next call on that handle. */
@@ -197,6 +218,13 @@ int mdr_env_rollout(mdr_env_t *env, uint8_t *actions, int action_source, int32_t
  * two power observation columns from the reduced values. */
 int mdr_env_step_begin(mdr_env_t *env, uint8_t *actions, int action_source, void *stream);
 int mdr_env_step_end(mdr_env_t *env, void *stream);
+
+/* utils.normStateDict (utils.py:740-880) for every house at once, including the neighbour messages
+ * (SingleHouse.message env 624-662, gathered through `links`): writes the flat state vector of length
+ * mdr_obs_vector_length(spec) per house into `out` in the requested layout.  Reads the post-step (or post-reset)
+ * state of the bound buffers; sharded houses need the neighbouring shards' halo and are not supported here. */
+int32_t mdr_obs_vector_length(const mdr_obs_spec_t *spec);
+int mdr_env_obs_vector(mdr_env_t *env, const mdr_obs_spec_t *spec, float *out, void *stream);
 
 /* Cursor: k = number of steps taken this episode; j0 = time index of table row 0. */
 int mdr_env_cursor(const mdr_env_t *env, int64_t *k, int64_t *j0);

@@ -82,11 +82,28 @@ class MdrEpisode(C.Structure):
     ]
 
 
+class MdrObsSpec(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("layout", C.c_int32),
+        ("state_hour", C.c_int32), ("state_day", C.c_int32), ("state_solar_gain", C.c_int32),
+        ("state_thermal", C.c_int32), ("state_hvac", C.c_int32),
+        ("message_thermal", C.c_int32), ("message_hvac", C.c_int32),
+        ("nb_comm", C.c_int32),
+        ("links", _i32p),
+        ("comm_defect_prob", C.c_double),
+        ("def_Ua", C.c_double), ("def_Cm", C.c_double), ("def_Ca", C.c_double), ("def_Hm", C.c_double),
+        ("def_COP", C.c_double), ("def_capacity", C.c_double), ("def_latent", C.c_double), ("norm_reg_sig", C.c_double),
+    ]
+
+
+OBS_PLANES, OBS_ROWS = 0, 1
+
 EXPORTS = (
     "mdr_abi_version", "mdr_status_string", "mdr_last_error", "mdr_partials_per_env",
     "mdr_env_create", "mdr_env_destroy", "mdr_env_bind", "mdr_env_reset", "mdr_env_load_episode",
     "mdr_env_set_od_table", "mdr_env_begin_episode", "mdr_env_step", "mdr_env_rollout",
-    "mdr_env_step_begin", "mdr_env_step_end", "mdr_env_cursor", "mdr_env_set_cursor",
+    "mdr_env_step_begin", "mdr_env_step_end", "mdr_obs_vector_length", "mdr_env_obs_vector",
+    "mdr_env_cursor", "mdr_env_set_cursor",
 )
 
 _lib = None
@@ -123,6 +140,8 @@ def load():
         "mdr_env_rollout": (C.c_int, [vp, vp, C.c_int, i32, vp]),
         "mdr_env_step_begin": (C.c_int, [vp, vp, C.c_int, vp]),
         "mdr_env_step_end": (C.c_int, [vp, vp]),
+        "mdr_obs_vector_length": (i32, [C.POINTER(MdrObsSpec)]),
+        "mdr_env_obs_vector": (C.c_int, [vp, C.POINTER(MdrObsSpec), vp, vp]),
         "mdr_env_cursor": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
         "mdr_env_set_cursor": (C.c_int, [vp, u64, u32, i64, i64]),
     }

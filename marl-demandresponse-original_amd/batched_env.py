@@ -282,6 +282,70 @@ class BatchedDemandResponseEnv:
             rc = self._lib.mdr_env_rollout(self._handle, C.c_void_p(self._actions_ptr(actions)), src, int(nb_steps), self._stream())
             nat.check(self._lib, self._handle, rc, "mdr_env_rollout")
 
+    # ------------------------------------------------------------------ full normStateDict vector
+    def _obs_spec(self, layout: str) -> nat.MdrObsSpec:
+        from .comm import build_comm_links, nb_comm
+        env = self.config["default_env_prop"]
+        cluster, sp, mp = env["cluster_prop"], env["state_properties"], env["message_properties"]
+        spec = nat.MdrObsSpec()
+        spec.struct_size = C.sizeof(nat.MdrObsSpec)
+        spec.layout = {"planes": nat.OBS_PLANES, "rows": nat.OBS_ROWS}[layout]
+        spec.state_hour, spec.state_day, spec.state_solar_gain = int(sp["hour"]), int(sp["day"]), int(sp["solar_gain"])
+        spec.state_thermal, spec.state_hvac = int(sp["thermal"]), int(sp["hvac"])
+        spec.message_thermal, spec.message_hvac = int(mp["thermal"]), int(mp["hvac"])
+        spec.nb_comm = nb_comm(cluster)
+        mode = cluster["agents_comm_mode"]
+        if mode == "random_sample":
+            raise ValueError("agents_comm_mode 'random_sample' re-draws its links every step and has no batched form; "
+                             "use the dict adapter or a fixed topology")
+        if mode == "no_message":
+            spec.nb_comm = 0
+        if getattr(self, "_links_dev", None) is None and mode not in ("neighbours", "no_message"):
+            links = build_comm_links(cluster)
+            table = np.array([links[i] for i in range(self.nb_agents)], dtype=np.int32).reshape(self.nb_agents, -1)
+            self._links_dev = torch.from_numpy(table).to(self.device)
+        if mode not in ("neighbours", "no_message") or getattr(self, "_links_forced", False):
+            spec.nb_comm = int(self._links_dev.shape[1])
+            spec.links = self._links_dev.data_ptr() if spec.nb_comm > 0 else None
+        spec.comm_defect_prob = float(cluster["comm_defect_prob"])
+        house, hvac = self.config["default_house_prop"], self.config["default_hvac_prop"]
+        spec.def_Ua, spec.def_Cm, spec.def_Ca, spec.def_Hm = house["Ua"], house["Cm"], house["Ca"], house["Hm"]
+        spec.def_COP, spec.def_capacity, spec.def_latent = hvac["COP"], hvac["cooling_capacity"], hvac["latent_cooling_fraction"]
+        spec.norm_reg_sig = self.spec.norm_reg_sig
+        return spec
+
+    def set_comm_links(self, table) -> None:
+        """Install a static [N, c] sender table (ClusterHouses.agent_communicators) instead of the one derived from
+        cluster_prop - e.g. the links a 'random_fixed' episode drew elsewhere."""
+        table = np.ascontiguousarray(np.asarray(table, dtype=np.int32)).reshape(self.nb_agents, -1)
+        if table.size and (table.min() < 0 or table.max() >= self.nb_agents):
+            raise ValueError("sender ids must be in [0, nb_agents)")
+        self._links_dev = torch.from_numpy(table).to(self.device)
+        self._links_forced = True
+
+    def obs_vector_length(self) -> int:
+        spec = self._obs_spec("planes")
+        return int(self._lib.mdr_obs_vector_length(C.byref(spec)))
+
+    def obs_vector(self, layout: str = "planes", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """utils.normStateDict (utils.py:740-880) of every house, messages included, as one tensor:
+        ``planes`` -> float32 [F, E, N] (feature-major), ``rows`` -> float32 [E, N, F] (what Actor(num_state) eats).
+        Feature order is normStateDict's; F = 11 (+ optional state columns) + nb_comm * 4 (+ optional message columns)."""
+        spec = self._obs_spec(layout)
+        F = int(self._lib.mdr_obs_vector_length(C.byref(spec)))
+        shape = (F, self.nb_envs, self.nb_houses) if layout == "planes" else (self.nb_envs, self.nb_houses, F)
+        if out is None:
+            cache = self.__dict__.setdefault("_obs_vec", {})
+            out = cache.get(layout)
+            if out is None or tuple(out.shape) != shape:
+                out = cache[layout] = torch.empty(shape, dtype=torch.float32, device=self.device)
+        if tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float32 tensor of shape %s" % (shape,))
+        with torch.cuda.device(self.device):
+            rc = self._lib.mdr_env_obs_vector(self._handle, C.byref(spec), C.c_void_p(out.data_ptr()), self._stream())
+            nat.check(self._lib, self._handle, rc, "mdr_env_obs_vector")
+        return out
+
     # ------------------------------------------------------------------ views of the state
     def cursor(self) -> Tuple[int, int]:
         k, j0 = C.c_int64(), C.c_int64()

@@ -1,0 +1,55 @@
+"""Static communication-link tables: ClusterHouses.build_agent_comm_links (env/MA_DemandResponse.py:806-902).
+
+Returns ``{agent_id: [sender ids]}`` for every mode whose links are fixed for an episode; ``random_sample``
+re-draws its senders every step (env 976-983) and is returned as ``None`` (the dict adapter samples it per step).
+"""
+from __future__ import annotations
+
+import random
+from typing import Dict, List, Optional
+
+COMM_MODES = ("neighbours", "closed_groups", "random_sample", "random_fixed", "neighbours_2D", "no_message")
+
+
+def nb_comm(cluster_prop: dict) -> int:
+    return int(min(cluster_prop["nb_agents_comm"], cluster_prop["nb_agents"] - 1))   # env 808-810
+
+
+def build_comm_links(cluster_prop: dict) -> Optional[Dict[int, List[int]]]:
+    n = int(cluster_prop["nb_agents"])
+    c = nb_comm(cluster_prop)
+    mode = cluster_prop["agents_comm_mode"]
+    ids = range(n)
+    if mode == "neighbours":       # circular: floor(c/2) before, ceil(c/2) after (env 816-828)
+        before, after = c // 2, c - c // 2
+        return {i: [(i - before + j) % n for j in range(before)] + [(i + 1 + j) % n for j in range(after)] for i in ids}
+    if mode == "closed_groups":    # env 830-844
+        links = {}
+        for i in ids:
+            base = i - (i % (c + 1))
+            if base + c <= n:
+                group = [base + j for j in range(cluster_prop["nb_agents_comm"] + 1)]
+            else:
+                group = [n - c - 1 + j for j in range(c + 1)]
+            group.remove(i)
+            links[i] = group
+        return links
+    if mode == "random_sample":
+        return None
+    if mode == "random_fixed":     # env 849-854
+        return {i: random.sample([j for j in ids if j != i], k=c) for i in ids}
+    if mode == "neighbours_2D":    # env 856-890
+        p2 = cluster_prop["agents_comm_parameters"]["neighbours_2D"]
+        row, dist = p2["row_size"], p2["distance_comm"]
+        if n % row != 0:
+            raise ValueError("Neighbours 2D row_size must be a divisor of nb_agents")
+        rows = n // row
+        if dist >= (row + 1) // 2 or dist >= (rows + 1) // 2:
+            raise ValueError("Neighbours 2D distance_comm ({}) must be strictly smaller than (row_size+1) / 2 ({}) "
+                             "and (max_y+1) / 2 ({})".format(dist, (row + 1) // 2, (rows + 1) // 2))
+        pattern = [(dx, dy) for dx in range(-dist, dist + 1) for dy in range(-dist, dist + 1)
+                   if abs(dx) + abs(dy) <= dist and (dx, dy) != (0, 0)]
+        return {i: [((i // row + dy) % rows) * row + (i % row + dx) % row for dx, dy in pattern] for i in ids}
+    if mode == "no_message":
+        return {i: [] for i in ids}
+    raise ValueError("Cluster property: unknown agents_comm_mode '{}'.".format(mode))

@@ -386,6 +386,58 @@ int mdr_env_step_end(mdr_env_t* env, void* stream) {
   return MDR_OK;
 }
 
+
+int32_t mdr_obs_vector_length(const mdr_obs_spec_t* spec) {
+  if (!spec || spec->struct_size != sizeof(mdr_obs_spec_t) || spec->nb_comm < 0) return -1;
+  return mdr::obs_vector_length(*spec);
+}
+
+int mdr_env_obs_vector(mdr_env_t* env, const mdr_obs_spec_t* spec, float* out, void* stream) {
+  if (!env || !spec || !out) return MDR_ERR_INVALID;
+  if (spec->struct_size != sizeof(mdr_obs_spec_t)) return fail(env, MDR_ERR_INVALID, "mdr_obs_spec_t size mismatch (ABI)");
+  if (!env->bound || !env->has_tables) return fail(env, MDR_ERR_UNBOUND, "no episode: call reset/load_episode and begin_episode first");
+  const mdr_config_t& c = env->cfg;
+  if (c.nb_houses_total != c.nb_houses) return fail(env, MDR_ERR_UNSUPPORTED, "obs_vector needs all houses of an env on one device");
+  if (spec->layout != MDR_OBS_PLANES && spec->layout != MDR_OBS_ROWS) return fail(env, MDR_ERR_INVALID, "unknown obs layout");
+  if (spec->nb_comm < 0 || spec->nb_comm > c.nb_houses - 1 + (c.nb_houses == 1 ? 1 : 0) || (c.nb_houses == 1 && spec->nb_comm != 0))
+    return fail(env, MDR_ERR_INVALID, "nb_comm must be in [0, nb_houses - 1]");
+  if (!(spec->comm_defect_prob >= 0.0 && spec->comm_defect_prob <= 1.0)) return fail(env, MDR_ERR_INVALID, "comm_defect_prob outside [0, 1]");
+  if (!(spec->def_Ua > 0 && spec->def_Cm > 0 && spec->def_Ca > 0 && spec->def_Hm > 0 && spec->def_COP > 0 && spec->def_capacity > 0 &&
+        spec->def_latent > 0 && spec->norm_reg_sig > 0))
+    return fail(env, MDR_ERR_INVALID, "normalisation defaults must be positive");
+  const mdr_buffers_t& b = env->buf;
+  const int64_t row = env->k - env->j0;
+  mdr::ObsArgs a{};
+  a.Ta = b.Ta; a.Tm = b.Tm; a.target = b.target; a.deadband = b.deadband; a.P_max = b.P_max;
+  a.Ua = b.Ua; a.Cm = b.Cm; a.Ca = b.Ca; a.Hm = b.Hm; a.capacity = b.capacity; a.COP = b.COP; a.latent = b.latent;
+  a.sso = b.sso; a.lockout = b.lockout; a.flags = b.flags;
+  a.P = b.P;
+  a.sig_now = b.tab_signal + row * c.nb_envs;
+  a.od_now = b.tab_od + row * c.nb_envs;
+  a.solar_now = b.tab_solar + row * c.nb_envs;
+  a.t0 = b.t0;
+  a.links = spec->links;
+  a.out = out;
+  a.plane = (int64_t)c.nb_envs * c.nb_houses;
+  a.k = env->k;
+  a.E = c.nb_envs; a.N = c.nb_houses; a.c = spec->nb_comm; a.F = mdr::obs_vector_length(*spec); a.dt = c.time_step;
+  a.f_hour = spec->state_hour; a.f_day = spec->state_day; a.f_solar = spec->state_solar_gain;
+  a.f_thermal = spec->state_thermal; a.f_hvac = spec->state_hvac;
+  a.m_thermal = spec->message_thermal; a.m_hvac = spec->message_hvac;
+  a.env_offset = c.env_offset; a.house_offset = c.house_offset;
+  a.k0 = (uint32_t)(env->seed & 0xFFFFFFFFull); a.k1 = (uint32_t)(env->seed >> 32); a.episode = env->episode;
+  a.defect_prob = (float)spec->comm_defect_prob;
+  a.obs_tshift = (float)(c.temp_ref - 20.0);
+  a.inv_obs_norm = 1.0 / c.obs_power_norm;
+  a.inv_norm_reg = (float)(1.0 / spec->norm_reg_sig);
+  a.inv_cap = (float)(1.0 / spec->def_capacity); a.inv_Ua = (float)(1.0 / spec->def_Ua); a.inv_Cm = (float)(1.0 / spec->def_Cm);
+  a.inv_Ca = (float)(1.0 / spec->def_Ca); a.inv_Hm = (float)(1.0 / spec->def_Hm); a.inv_COP = (float)(1.0 / spec->def_COP);
+  a.inv_latent = (float)(1.0 / spec->def_latent);
+  hipError_t e = mdr::launch_obs_vector(a, spec->layout, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(env, e, "obs_vector");
+  return MDR_OK;
+}
+
 int mdr_env_cursor(const mdr_env_t* env, int64_t* k, int64_t* j0) {
   if (!env) return MDR_ERR_INVALID;
   if (k) *k = env->k;

@@ -20,6 +20,7 @@ enum : uint32_t {
   TAG_ENV_START = 4,     // x0 -> days ; x1 -> seconds ; x2 -> phase ; x3 -> artificial ratio
   TAG_OD_NOISE = 5,      // item = time index ; x0,x1 -> gauss
   TAG_PERLIN = 6,        // item = lattice index ; x0 -> gradient
+  TAG_COMM = 7,          // item = house ; counter word 2 = time index ; x0..x3 -> link defects (4 links per draw)
   ENV_LEVEL = 0xFFFFFFFFu
 };
 
@@ -75,7 +76,7 @@ __device__ __forceinline__ double triangular_mode1(double u, double low, double 
 // Calendar: naive epoch seconds -> civil fields (era-based days algorithm, H. Hinnant, public domain)
 // ---------------------------------------------------------------------------------------------
 struct Civil {
-  int month, day, hour, minute, sod;
+  int month, day, hour, minute, sod, yday;  // yday = tm_yday (1..366)
 };
 
 __device__ __forceinline__ Civil civil_from_epoch(int64_t t) {
@@ -97,6 +98,10 @@ __device__ __forceinline__ Civil civil_from_epoch(int64_t t) {
   c.sod = (int)sod;
   c.hour = c.sod / 3600;
   c.minute = (c.sod % 3600) / 60;
+  // day of year counted from 1 January: doy above counts from 1 March
+  const int64_t y = yoe + era * 400 + (c.month <= 2 ? 1 : 0);
+  const bool leap = (y % 4 == 0 && y % 100 != 0) || (y % 400 == 0);
+  c.yday = (int)(c.month > 2 ? doy + 60 + (leap ? 1 : 0) : doy - 305);
   return c;
 }
 

@@ -75,6 +75,29 @@ struct StepArgs {
   double inv_obs_norm;                 // 1 / (norm_reg_sig * nb_agents)
 };
 
+// utils.normStateDict for all houses (k_obs_vector)
+struct ObsArgs {
+  const float *Ta, *Tm, *target, *deadband, *P_max, *Ua, *Cm, *Ca, *Hm, *capacity, *COP, *latent;
+  const int32_t *sso, *lockout;
+  const uint8_t* flags;
+  const double* P;          // [E]
+  const double* sig_now;    // table row of the current time index
+  const float *od_now, *solar_now;
+  const int64_t* t0;
+  const int32_t* links;     // [N][c] or nullptr (circular neighbours)
+  float* out;
+  int64_t plane;            // E * N
+  int64_t k;                // steps taken (time index)
+  int E, N, c, F, dt;
+  int f_hour, f_day, f_solar, f_thermal, f_hvac, m_thermal, m_hvac;
+  int64_t env_offset, house_offset;
+  uint32_t k0, k1, episode;
+  float defect_prob;
+  float obs_tshift;
+  double inv_obs_norm;
+  float inv_norm_reg, inv_cap, inv_Ua, inv_Cm, inv_Ca, inv_Hm, inv_COP, inv_latent;
+};
+
 enum StepKind { STEP_FUSED = 0, STEP_GROUP = 1, STEP_SPLIT = 2 };
 struct StepPlan {
   int kind, vec, threads, tiles;
@@ -88,6 +111,8 @@ hipError_t launch_load(const EpisodeArgs& a, const mdr_episode_t& ep, hipStream_
 hipError_t launch_tables(const TableArgs& a, hipStream_t s);
 hipError_t launch_reset_obs(const StepArgs& a, hipStream_t s);  // uses sig_old = table row 0
 hipError_t launch_step(const StepArgs& a, const StepPlan& p, hipStream_t s);
+hipError_t launch_obs_vector(const ObsArgs& a, int layout, hipStream_t s);
+int obs_vector_length(const mdr_obs_spec_t& spec);
 hipError_t launch_step_begin_split(const StepArgs& a, hipStream_t s);
 hipError_t launch_step_end_split(const StepArgs& a, hipStream_t s);
 

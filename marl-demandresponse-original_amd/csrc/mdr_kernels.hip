@@ -488,6 +488,123 @@ __global__ __launch_bounds__(256) void k_step_finish(StepArgs a) {
                           (float)(a.sig_new[e] * a.inv_obs_norm), (float)(P * a.inv_obs_norm));
 }
 
+
+// =================================================================================================
+// Full flat observation: utils.normStateDict (utils.py:740-880) for every house, messages included.
+// Feature order = the dict insertion order of normStateDict:
+//   (Ta-20)/5, (Tm-20)/5, (target-20)/5, [(OD-20)/5], deadband, [sin,cos day], [sin,cos hour], [solar/1000],
+//   capacity/def, [Ua,Cm,Ca,Hm/def], [COP,latent/def], on, lock, sso/L, 1, S/norm, P/norm,
+//   then per sender j: diff_j/5, sso_j/L_own, curr_j/norm_reg, max_j/norm_reg, [Ua..Hm_j/def], [COP,latent,cap_j/def]
+// One thread per house; a sender's fields are read straight from global memory (senders are neighbouring
+// houses of the same env, so these are L1/L2 hits - HBM sees each state array once).
+// =================================================================================================
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void k_obs_vector(ObsArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.plane) return;
+  const int e = (int)(i / a.N);
+  const int h = (int)(i - (int64_t)e * a.N);
+  const int64_t base = (int64_t)e * a.N;
+  int f = 0;
+  auto put = [&](float v) {
+    if (LAYOUT == MDR_OBS_PLANES) a.out[(int64_t)f * a.plane + i] = v;
+    else a.out[i * a.F + f] = v;
+    ++f;
+  };
+  const float L = (float)a.lockout[i];
+  put((a.Ta[i] + a.obs_tshift) * 0.2f);
+  put((a.Tm[i] + a.obs_tshift) * 0.2f);
+  put((a.target[i] + a.obs_tshift) * 0.2f);
+  if (a.f_thermal) put((a.od_now[e] + a.obs_tshift) * 0.2f);
+  put(a.deadband[i]);
+  if (a.f_day || a.f_hour) {
+    const Civil c = civil_from_epoch(a.t0[e] + a.k * (int64_t)a.dt);
+    if (a.f_day) {   // utils.py:806-809: tm_yday * 2 pi / 365
+      const double ang = (double)c.yday * 6.283185307179586476925286766559 / 365.0;
+      put((float)sin(ang));
+      put((float)cos(ang));
+    }
+    if (a.f_hour) {  // utils.py:810-813: integer hour * 2 pi / 24
+      const double ang = (double)c.hour * 6.283185307179586476925286766559 / 24.0;
+      put((float)sin(ang));
+      put((float)cos(ang));
+    }
+  }
+  if (a.f_solar) put(a.k > 0 ? a.solar_now[e] * 1e-3f : 0.0f);   // current_solar_gain is 0 until the first step (env 573)
+  put(a.capacity[i] * a.inv_cap);
+  if (a.f_thermal) {
+    put(a.Ua[i] * a.inv_Ua);
+    put(a.Cm[i] * a.inv_Cm);
+    put(a.Ca[i] * a.inv_Ca);
+    put(a.Hm[i] * a.inv_Hm);
+  }
+  if (a.f_hvac) {
+    put(a.COP[i] * a.inv_COP);
+    put(a.latent[i] * a.inv_latent);
+  }
+  const unsigned fl = a.flags[i];
+  put((fl & 1u) ? 1.0f : 0.0f);
+  put((fl & 2u) ? 1.0f : 0.0f);
+  put((float)a.sso[i] / L);
+  put(L / L);
+  put((float)(a.sig_now[e] * a.inv_obs_norm));
+  put((float)(a.P[e] * a.inv_obs_norm));
+  const int before = a.c / 2;
+  u32x4 rnd{0, 0, 0, 0};
+  for (int m = 0; m < a.c; ++m) {
+    int j;
+    if (a.links != nullptr) {
+      j = a.links[(int64_t)h * a.c + m];
+    } else {  // env 816-828: floor(c/2) houses before, ceil(c/2) after, circular
+      j = m < before ? h - before + m : h + 1 + (m - before);
+      j %= a.N;
+      if (j < 0) j += a.N;
+    }
+    bool ok = true;
+    if (a.defect_prob > 0.0f) {   // np.random.rand() > comm_defect_prob keeps the message (env 992)
+      if ((m & 3) == 0)
+        rnd = philox4x32_10((uint32_t)(e + a.env_offset), (uint32_t)(h + a.house_offset), (uint32_t)a.k,
+                            TAG_COMM | ((uint32_t)(m >> 2) << 8), a.k0, a.k1 ^ (a.episode * 0x85EBCA6Bu));
+      const uint32_t x = (m & 3) == 0 ? rnd.x : (m & 3) == 1 ? rnd.y : (m & 3) == 2 ? rnd.z : rnd.w;
+      ok = (float)u01(x) > a.defect_prob;
+    }
+    const int64_t s = base + j;
+    const float z = ok ? 1.0f : 0.0f;
+    const float pmax = a.P_max[s];
+    put(z * (a.Ta[s] - a.target[s]) * 0.2f);
+    put(z * (float)a.sso[s] / L);
+    put(z * ((a.flags[s] & 1u) ? pmax : 0.0f) * a.inv_norm_reg);
+    put(z * pmax * a.inv_norm_reg);
+    if (a.m_thermal) {
+      put(z * a.Ua[s] * a.inv_Ua);
+      put(z * a.Cm[s] * a.inv_Cm);
+      put(z * a.Ca[s] * a.inv_Ca);
+      put(z * a.Hm[s] * a.inv_Hm);
+    }
+    if (a.m_hvac) {
+      put(z * a.COP[s] * a.inv_COP);
+      put(z * a.latent[s] * a.inv_latent);
+      put(z * a.capacity[s] * a.inv_cap);
+    }
+  }
+}
+
+int obs_vector_length(const mdr_obs_spec_t& s) {
+  int own = 11 + (s.state_thermal ? 5 : 0) + (s.state_day ? 2 : 0) + (s.state_hour ? 2 : 0) + (s.state_solar_gain ? 1 : 0) +
+            (s.state_hvac ? 2 : 0);
+  int msg = 4 + (s.message_thermal ? 4 : 0) + (s.message_hvac ? 3 : 0);
+  return own + s.nb_comm * msg;
+}
+
+hipError_t launch_obs_vector(const ObsArgs& a, int layout, hipStream_t s) {
+  const dim3 g((unsigned)((a.plane + 255) / 256)), b(256);
+  if (layout == MDR_OBS_PLANES)
+    hipLaunchKernelGGL(k_obs_vector<MDR_OBS_PLANES>, g, b, 0, s, a);
+  else
+    hipLaunchKernelGGL(k_obs_vector<MDR_OBS_ROWS>, g, b, 0, s, a);
+  return hipGetLastError();
+}
+
 // =================================================================================================
 // Launchers (host)
 // =================================================================================================

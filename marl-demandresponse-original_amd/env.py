@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from .batched_env import BatchedDemandResponseEnv
+from .comm import build_comm_links, nb_comm
 from .config import from_epoch_seconds
 
 
@@ -199,55 +200,13 @@ class MADemandResponseEnv:
 
     # ------------------------------------------------------------------ communication links (env 806-902)
     def _build_agent_comm_links(self) -> Dict[int, List[int]]:
-        cp = self.default_env_prop["cluster_prop"]
-        n = self.nb_agents
-        nb_comm = int(min(cp["nb_agents_comm"], cp["nb_agents"] - 1))
-        mode = cp["agents_comm_mode"]
-        links: Dict[int, List[int]] = {}
-        if mode == "neighbours":      # circular: floor(c/2) before, ceil(c/2) after (env 816-828)
-            before, after = nb_comm // 2, nb_comm - nb_comm // 2
-            for i in self.agent_ids:
-                links[i] = [(i - before + j) % n for j in range(before)] + [(i + 1 + j) % n for j in range(after)]
-        elif mode == "closed_groups":  # env 830-844
-            for i in self.agent_ids:
-                base = i - (i % (nb_comm + 1))
-                if base + nb_comm <= cp["nb_agents"]:
-                    ids = [base + j for j in range(cp["nb_agents_comm"] + 1)]
-                else:
-                    ids = [cp["nb_agents"] - nb_comm - 1 + j for j in range(nb_comm + 1)]
-                ids.remove(i)
-                links[i] = ids
-        elif mode == "random_sample":  # drawn per step in _neighbours (env 976-983)
-            pass
-        elif mode == "random_fixed":   # env 849-854
-            for i in self.agent_ids:
-                others = [j for j in self.agent_ids if j != i]
-                links[i] = random.sample(others, k=nb_comm)
-        elif mode == "neighbours_2D":  # env 856-890
-            p2 = cp["agents_comm_parameters"]["neighbours_2D"]
-            row, dist = p2["row_size"], p2["distance_comm"]
-            if n % row != 0:
-                raise ValueError("Neighbours 2D row_size must be a divisor of nb_agents")
-            rows = n // row
-            if dist >= (row + 1) // 2 or dist >= (rows + 1) // 2:
-                raise ValueError("Neighbours 2D distance_comm ({}) must be strictly smaller than (row_size+1) / 2 ({}) "
-                                 "and (max_y+1) / 2 ({})".format(dist, (row + 1) // 2, (rows + 1) // 2))
-            pattern = [(dx, dy) for dx in range(-dist, dist + 1) for dy in range(-dist, dist + 1)
-                       if abs(dx) + abs(dy) <= dist and (dx, dy) != (0, 0)]
-            for i in self.agent_ids:
-                x, y = i % row, i // row
-                links[i] = [((y + dy) % rows) * row + (x + dx) % row for dx, dy in pattern]
-        elif mode == "no_message":
-            links = {i: [] for i in self.agent_ids}
-        else:
-            raise ValueError("Cluster property: unknown agents_comm_mode '{}'.".format(mode))
-        return links
+        links = build_comm_links(self.default_env_prop["cluster_prop"])
+        return {} if links is None else links
 
     def _neighbours(self, i):
         cp = self.default_env_prop["cluster_prop"]
         if cp["agents_comm_mode"] == "random_sample":
-            nb_comm = int(min(cp["nb_agents_comm"], cp["nb_agents"] - 1))
-            return random.sample([j for j in self.agent_ids if j != i], k=nb_comm)
+            return random.sample([j for j in self.agent_ids if j != i], k=nb_comm(cp))
         return self._links[i]
 
     def _message(self, j, empty):

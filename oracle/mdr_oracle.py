@@ -601,6 +601,58 @@ class OracleEnv:
             np.broadcast_to((self.P / den)[:, None], (E, N)),
         ])
 
+    def circular_links(self, nb_comm):
+        """agents_comm_mode 'neighbours' (env 816-828): floor(c/2) before, ceil(c/2) after, circular."""
+        n = self.N
+        before, after = nb_comm // 2, nb_comm - nb_comm // 2
+        i = np.arange(n)[:, None]
+        return np.concatenate([(i - before + np.arange(before)[None, :]) % n,
+                               (i + 1 + np.arange(after)[None, :]) % n], axis=1).astype(np.int64)
+
+    def norm_state(self, config, links=None):
+        """utils.normStateDict (utils.py:740-880) for every house -> float64 [E, N, F], messages from
+        SingleHouse.message (env 624-662) gathered through `links` ([N, c] sender ids; None = 'neighbours')."""
+        env = config["default_env_prop"]
+        sp, mp = env["state_properties"], env["message_properties"]
+        house, hvac = config["default_house_prop"], config["default_hvac_prop"]
+        s = self.spec
+        E, N = self.E, self.N
+        c = int(min(s.nb_agents_comm, s.cfg_nb_agents - 1))
+        if s.comm_mode == "no_message":
+            links = np.zeros((N, 0), dtype=np.int64)
+        elif links is None:
+            links = self.circular_links(c)
+        den = s.norm_reg_sig * s.cfg_nb_agents
+        cal = self._time(self.k)
+        ones = np.ones((E, N))
+        cols = [(self.Ta - 20) / 5, (self.Tm - 20) / 5, (self.target - 20) / 5]
+        if sp["thermal"]:
+            cols.append(((self.OD - 20) / 5)[:, None] * ones)
+        cols.append(self.deadband)
+        if sp["day"]:
+            cols += [np.sin(cal["yday"] * 2 * np.pi / 365)[:, None] * ones, np.cos(cal["yday"] * 2 * np.pi / 365)[:, None] * ones]
+        if sp["hour"]:
+            cols += [np.sin(cal["hour"] * 2 * np.pi / 24)[:, None] * ones, np.cos(cal["hour"] * 2 * np.pi / 24)[:, None] * ones]
+        if sp["solar_gain"]:
+            cols.append((self.solar / 1000)[:, None] * ones)
+        cols.append(self.capacity / hvac["cooling_capacity"])
+        if sp["thermal"]:
+            cols += [self.Ua / house["Ua"], self.Cm / house["Cm"], self.Ca / house["Ca"], self.Hm / house["Hm"]]
+        if sp["hvac"]:
+            cols += [self.COP / hvac["COP"], self.latent / hvac["latent_cooling_fraction"]]
+        cols += [self.on.astype(float), self.lock.astype(float), self.sso / self.lockout, self.lockout / self.lockout,
+                 (self.S / den)[:, None] * ones, (self.P / den)[:, None] * ones]
+        for m in range(links.shape[1]):
+            j = links[:, m]
+            cols += [(self.Ta - self.target)[:, j] / 5, self.sso[:, j] / self.lockout,
+                     np.where(self.on, self.Pmax, 0.0)[:, j] / s.norm_reg_sig, self.Pmax[:, j] / s.norm_reg_sig]
+            if mp["thermal"]:
+                cols += [self.Ua[:, j] / house["Ua"], self.Cm[:, j] / house["Cm"], self.Ca[:, j] / house["Ca"], self.Hm[:, j] / house["Hm"]]
+            if mp["hvac"]:
+                cols += [self.COP[:, j] / hvac["COP"], self.latent[:, j] / hvac["latent_cooling_fraction"],
+                         self.capacity[:, j] / hvac["cooling_capacity"]]
+        return np.stack([np.broadcast_to(cc, (E, N)) for cc in cols], axis=-1)
+
     def bangbang_actions(self):
         """agents/bangbang_controllers.py:41-61: on iff house_temp > target."""
         return self.Ta > self.target

@@ -151,6 +151,9 @@ def run_scenario(name, patches, seed, T, policy, perlin=False, norm_steps=(0, 1,
     arrays["od"] = np.array(od, dtype=np.float64)
     arrays["S"] = np.array(S, dtype=np.float64)
     arrays["norm_state"] = np.array(norm, dtype=np.float64)
+    comm = env.cluster.agent_communicators
+    if comm and all(len(comm[i]) == len(comm[0]) for i in range(N)):
+        arrays["links"] = np.array([comm[i] for i in range(N)], dtype=np.int32).reshape(N, -1)
     arrays["meta"] = np.array(json.dumps(meta))
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **arrays)
@@ -221,6 +224,27 @@ def main():
     # S8: random phase offset of the outdoor sinusoid
     run_scenario("s8_phase_offset", {CL + "nb_agents": 8, CL + "temp_mode": "shifting_sinusoidal_heatwave",
                                      PG + "signal_mode": "flat"}, 51, 200, "bangbang")
+    # S10: every optional normStateDict / message column (state_properties, message_properties all True)
+    ST, MS = "default_env_prop.state_properties.", "default_env_prop.message_properties."
+    allflags = {ST + k: True for k in ("hour", "day", "solar_gain", "thermal", "hvac")}
+    allflags.update({MS + "thermal": True, MS + "hvac": True})
+    run_scenario("s10_obs_all_columns", dict(allflags, **{
+        CL + "nb_agents": 12, "noise_house_prop.noise_mode": "big_noise", "noise_hvac_prop.noise_mode": "big_noise",
+        "default_env_prop.time_step": 60, "default_env_prop.start_datetime_mode": "fixed",
+        "default_env_prop.start_datetime": "2021-03-10 10:45:00", PG + "signal_mode": "sinusoidals"}),
+        71, 90, "mixed", norm_steps=(0, 1, 20, 50, -1))
+    run_scenario("s10_obs_thermal_only", {
+        ST + "thermal": True, MS + "hvac": True, CL + "nb_agents": 9, CL + "nb_agents_comm": 4,
+        "noise_house_prop.noise_mode": "house_big_noise", PG + "signal_mode": "flat"}, 72, 40, "mixed", norm_steps=(0, 7, -1))
+    # S11: the other static communication topologies (env 806-902)
+    run_scenario("s11_comm_closed_groups", {CL + "nb_agents": 14, CL + "nb_agents_comm": 3, CL + "agents_comm_mode": "closed_groups",
+                                            PG + "signal_mode": "flat"}, 81, 30, "mixed", norm_steps=(0, 5, -1))
+    run_scenario("s11_comm_neighbours_2D", {CL + "nb_agents": 25, CL + "agents_comm_mode": "neighbours_2D",
+                                            PG + "signal_mode": "flat"}, 82, 30, "mixed", norm_steps=(0, 5, -1))
+    run_scenario("s11_comm_random_fixed", {CL + "nb_agents": 10, CL + "nb_agents_comm": 4, CL + "agents_comm_mode": "random_fixed",
+                                           PG + "signal_mode": "flat"}, 83, 30, "mixed", norm_steps=(0, 5, -1))
+    run_scenario("s11_comm_no_message", {CL + "nb_agents": 6, CL + "agents_comm_mode": "no_message",
+                                         PG + "signal_mode": "flat"}, 84, 30, "mixed", norm_steps=(0, 5, -1))
     # N == 1 (config.py's literal default nb_agents) and no neighbours
     run_scenario("s9_single_house", {CL + "nb_agents": 1, PG + "signal_mode": "sinusoidals"}, 61, 200, "bangbang")
 

@@ -43,7 +43,8 @@ def test_library_is_built_and_exports_header_symbols():
     assert lib.mdr_partials_per_env(1024) == 1 and lib.mdr_partials_per_env(1025) == 5 and lib.mdr_partials_per_env(10**6) == 977
 
 
-@pytest.mark.parametrize("cname,cls", [("mdr_config", nat.MdrConfig), ("mdr_buffers", nat.MdrBuffers), ("mdr_episode", nat.MdrEpisode)])
+@pytest.mark.parametrize("cname,cls", [("mdr_config", nat.MdrConfig), ("mdr_buffers", nat.MdrBuffers), ("mdr_episode", nat.MdrEpisode),
+                                        ("mdr_obs_spec", nat.MdrObsSpec)])
 def test_ctypes_mirror_matches_header(cname, cls):
     assert _struct_fields(_header(), cname) == [f[0] for f in cls._fields_]
 

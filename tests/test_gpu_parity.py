@@ -280,3 +280,34 @@ def test_errors_map_to_reference_exceptions():
     env = mdr.BatchedDemandResponseEnv(_cfg(8), device="cuda:0")
     with pytest.raises(RuntimeError):  # step before reset
         env.step_bangbang()
+
+
+def test_long_horizon_training_episode_length():
+    """One full training episode (16,384 steps = 18.2 simulated hours, config.py:572-587) in fp32 against the fp64
+    oracle with the oracle's own mostly-bang-bang action record: the error must stay bounded, not grow."""
+    E, N, T = 4, 256, 16384
+    cfg = _cfg(N, **{"noise_house_prop.noise_mode": "big_noise", "noise_hvac_prop.noise_mode": "big_noise",
+                     "default_env_prop.power_grid_prop.signal_mode": "perlin"})
+    env, ora = _oracle_pair(cfg, E, seed=404)
+    rng = np.random.default_rng(4)
+    acts = np.empty((T, E, N), dtype=np.uint8)
+    worst_T, worst_r = 0.0, 0.0
+    dev_acts = torch.empty((T, E, N), dtype=torch.uint8, device="cuda:0")
+    chunk = 1024
+    for c0 in range(0, T, chunk):
+        ref_Ta, ref_r = [], []
+        for t in range(c0, c0 + chunk):           # oracle first: its decisions become the recorded actions
+            a = ora.bangbang_actions() ^ (rng.random((E, N)) < 0.1)
+            acts[t] = a
+            ref_r.append(ora.step(a).copy())
+            ref_Ta.append(ora.Ta.copy())
+        dev_acts[c0:c0 + chunk] = torch.from_numpy(acts[c0:c0 + chunk]).cuda()
+        for t in range(c0, c0 + chunk):
+            _, reward, _, _ = env.step(dev_acts[t])
+            if (t + 1) % 256 == 0:
+                i = t - c0
+                worst_T = max(worst_T, float(np.max(np.abs(env.house_temp().cpu().numpy() / ref_Ta[i] - 1))))
+                worst_r = max(worst_r, float(np.max(np.abs(reward.cpu().numpy() - ref_r[i]) / (1e-5 + 1e-5 * np.abs(ref_r[i])))))
+        _compare_state(env, ora, reward, ref_r[-1])
+    assert worst_T < 5e-6, worst_T           # observed ~5e-7
+    assert worst_r < 1.0, worst_r
