@@ -176,6 +176,8 @@ typedef struct mdr_obs_spec {
   const int32_t *links;            /* device int32 [N][nb_comm] sender ids (ClusterHouses.agent_communicators,
                                       env 806-902), shared by all envs; NULL = circular "neighbours" (816-828) */
   double comm_defect_prob;         /* per-link probability of an all-zero message (env 992-1002) */
+  int64_t out_plane_stride;        /* MDR_OBS_PLANES: elements between feature planes; 0 = nb_envs * nb_houses.  A stride
+                                      that is not a multiple of 2 MiB keeps the F concurrently written planes off one HBM channel */
   /* normalisation defaults (default_house_prop / default_hvac_prop / reward_prop.norm_reg_sig) */
   double def_Ua, def_Cm, def_Ca, def_Hm, def_COP, def_capacity, def_latent, norm_reg_sig;
 } mdr_obs_spec_t;

@@ -91,6 +91,7 @@ class MdrObsSpec(C.Structure):
         ("nb_comm", C.c_int32),
         ("links", _i32p),
         ("comm_defect_prob", C.c_double),
+        ("out_plane_stride", C.c_int64),
         ("def_Ua", C.c_double), ("def_Cm", C.c_double), ("def_Ca", C.c_double), ("def_Hm", C.c_double),
         ("def_COP", C.c_double), ("def_capacity", C.c_double), ("def_latent", C.c_double), ("norm_reg_sig", C.c_double),
     ]

@@ -333,14 +333,26 @@ class BatchedDemandResponseEnv:
         Feature order is normStateDict's; F = 11 (+ optional state columns) + nb_comm * 4 (+ optional message columns)."""
         spec = self._obs_spec(layout)
         F = int(self._lib.mdr_obs_vector_length(C.byref(spec)))
-        shape = (F, self.nb_envs, self.nb_houses) if layout == "planes" else (self.nb_envs, self.nb_houses, F)
+        E, N = self.nb_envs, self.nb_houses
+        shape = (F, E, N) if layout == "planes" else (E, N, F)
         if out is None:
             cache = self.__dict__.setdefault("_obs_vec", {})
             out = cache.get(layout)
             if out is None or tuple(out.shape) != shape:
-                out = cache[layout] = torch.empty(shape, dtype=torch.float32, device=self.device)
-        if tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous():
-            raise ValueError("out must be a contiguous float32 tensor of shape %s" % (shape,))
+                if layout == "planes":   # pad the plane stride (+2304 B) so the F planes do not alias one HBM channel
+                    stride = E * N + (576 if (E * N * 4) % (1 << 16) == 0 else 0)
+                    out = torch.empty(F * stride, dtype=torch.float32, device=self.device).as_strided((F, E, N), (stride, N, 1))
+                else:
+                    out = torch.empty(shape, dtype=torch.float32, device=self.device)
+                cache[layout] = out
+        if tuple(out.shape) != shape or out.dtype != torch.float32:
+            raise ValueError("out must be a float32 tensor of shape %s" % (shape,))
+        if layout == "planes":
+            if out.stride(2) != 1 or out.stride(1) != N or out.stride(0) < E * N:
+                raise ValueError("planes output needs strides (>= E*N, N, 1)")
+            spec.out_plane_stride = out.stride(0)
+        elif not out.is_contiguous():
+            raise ValueError("rows output must be contiguous")
         with torch.cuda.device(self.device):
             rc = self._lib.mdr_env_obs_vector(self._handle, C.byref(spec), C.c_void_p(out.data_ptr()), self._stream())
             nat.check(self._lib, self._handle, rc, "mdr_env_obs_vector")

@@ -419,6 +419,8 @@ int mdr_env_obs_vector(mdr_env_t* env, const mdr_obs_spec_t* spec, float* out, v
   a.links = spec->links;
   a.out = out;
   a.plane = (int64_t)c.nb_envs * c.nb_houses;
+  a.out_plane = spec->out_plane_stride > 0 ? spec->out_plane_stride : a.plane;
+  if (a.out_plane < a.plane) return fail(env, MDR_ERR_INVALID, "out_plane_stride smaller than nb_envs * nb_houses");
   a.k = env->k;
   a.E = c.nb_envs; a.N = c.nb_houses; a.c = spec->nb_comm; a.F = mdr::obs_vector_length(*spec); a.dt = c.time_step;
   a.f_hour = spec->state_hour; a.f_day = spec->state_day; a.f_solar = spec->state_solar_gain;

@@ -87,6 +87,7 @@ struct ObsArgs {
   const int32_t* links;     // [N][c] or nullptr (circular neighbours)
   float* out;
   int64_t plane;            // E * N
+  int64_t out_plane;        // stride between output feature planes (>= plane)
   int64_t k;                // steps taken (time index)
   int E, N, c, F, dt;
   int f_hour, f_day, f_solar, f_thermal, f_hvac, m_thermal, m_hvac;

@@ -495,9 +495,198 @@ __global__ __launch_bounds__(256) void k_step_finish(StepArgs a) {
 //   (Ta-20)/5, (Tm-20)/5, (target-20)/5, [(OD-20)/5], deadband, [sin,cos day], [sin,cos hour], [solar/1000],
 //   capacity/def, [Ua,Cm,Ca,Hm/def], [COP,latent/def], on, lock, sso/L, 1, S/norm, P/norm,
 //   then per sender j: diff_j/5, sso_j/L_own, curr_j/norm_reg, max_j/norm_reg, [Ua..Hm_j/def], [COP,latent,cap_j/def]
-// One thread per house; a sender's fields are read straight from global memory (senders are neighbouring
-// houses of the same env, so these are L1/L2 hits - HBM sees each state array once).
 // =================================================================================================
+struct MsgFields {  // SingleHouse.message (env 624-662), already normalised except sso (needs the receiver's lockout)
+  float diff, sso, curr, pmax, Ua, Cm, Ca, Hm, COP, latent, cap;
+};
+
+__device__ __forceinline__ MsgFields sender_from_global(const ObsArgs& a, int64_t s) {
+  MsgFields m;
+  const float pmax = a.P_max[s];
+  m.diff = (a.Ta[s] - a.target[s]) * 0.2f;
+  m.sso = (float)a.sso[s];
+  m.curr = ((a.flags[s] & 1u) ? pmax : 0.0f) * a.inv_norm_reg;
+  m.pmax = pmax * a.inv_norm_reg;
+  if (a.m_thermal) {
+    m.Ua = a.Ua[s] * a.inv_Ua;
+    m.Cm = a.Cm[s] * a.inv_Cm;
+    m.Ca = a.Ca[s] * a.inv_Ca;
+    m.Hm = a.Hm[s] * a.inv_Hm;
+  }
+  if (a.m_hvac) {
+    m.COP = a.COP[s] * a.inv_COP;
+    m.latent = a.latent[s] * a.inv_latent;
+    m.cap = a.capacity[s] * a.inv_cap;
+  }
+  return m;
+}
+
+// sender id of message slot m of house h: link table, or circular neighbours (env 816-828)
+__device__ __forceinline__ int sender_id(const ObsArgs& a, int h, int m) {
+  if (a.links != nullptr) return a.links[(int64_t)h * a.c + m];
+  const int before = a.c / 2;
+  int j = (m < before ? h - before + m : h + 1 + (m - before)) % a.N;
+  return j < 0 ? j + a.N : j;
+}
+
+// Emits the F features of houses h .. h+VEC-1 of env e through put(v[VEC]) in normStateDict order;
+// sender(m, q) yields message slot m of house h+q.
+template <int VEC, bool WITH_MSG = true, typename Put, typename Sender>
+__device__ __forceinline__ void obs_features(const ObsArgs& a, int e, int h, int64_t i, Put&& put, Sender&& sender) {
+  float v[VEC], w[VEC], L[VEC];
+  int li[VEC];
+  unsigned fl[VEC];
+  auto scaled = [&](const float* __restrict__ p, float shift, float scale) {
+    load_vec<VEC>(p, i, w);
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) v[q] = (w[q] + shift) * scale;
+    put(v);
+  };
+  auto all = [&](float x) {
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) v[q] = x;
+    put(v);
+  };
+  load_vec<VEC>(a.lockout, i, li);
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) L[q] = (float)li[q];
+  scaled(a.Ta, a.obs_tshift, 0.2f);
+  scaled(a.Tm, a.obs_tshift, 0.2f);
+  scaled(a.target, a.obs_tshift, 0.2f);
+  if (a.f_thermal) all((a.od_now[e] + a.obs_tshift) * 0.2f);
+  scaled(a.deadband, 0.0f, 1.0f);
+  if (a.f_day || a.f_hour) {
+    const Civil c = civil_from_epoch(a.t0[e] + a.k * (int64_t)a.dt);
+    if (a.f_day) {   // utils.py:806-809: tm_yday * 2 pi / 365
+      const double ang = (double)c.yday * 6.283185307179586476925286766559 / 365.0;
+      all((float)sin(ang));
+      all((float)cos(ang));
+    }
+    if (a.f_hour) {  // utils.py:810-813: integer hour * 2 pi / 24
+      const double ang = (double)c.hour * 6.283185307179586476925286766559 / 24.0;
+      all((float)sin(ang));
+      all((float)cos(ang));
+    }
+  }
+  if (a.f_solar) all(a.k > 0 ? a.solar_now[e] * 1e-3f : 0.0f);   // current_solar_gain is 0 until the first step (env 573)
+  scaled(a.capacity, 0.0f, a.inv_cap);
+  if (a.f_thermal) {
+    scaled(a.Ua, 0.0f, a.inv_Ua);
+    scaled(a.Cm, 0.0f, a.inv_Cm);
+    scaled(a.Ca, 0.0f, a.inv_Ca);
+    scaled(a.Hm, 0.0f, a.inv_Hm);
+  }
+  if (a.f_hvac) {
+    scaled(a.COP, 0.0f, a.inv_COP);
+    scaled(a.latent, 0.0f, a.inv_latent);
+  }
+  load_bytes<VEC>(a.flags, i, fl);
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) v[q] = (fl[q] & 1u) ? 1.0f : 0.0f;
+  put(v);
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) v[q] = (fl[q] & 2u) ? 1.0f : 0.0f;
+  put(v);
+  load_vec<VEC>(a.sso, i, li);
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) v[q] = (float)li[q] / L[q];
+  put(v);
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) v[q] = L[q] / L[q];
+  put(v);
+  all((float)(a.sig_now[e] * a.inv_obs_norm));
+  all((float)(a.P[e] * a.inv_obs_norm));
+  if (!WITH_MSG) return;
+  u32x4 rnd[VEC];
+  for (int m = 0; m < a.c; ++m) {
+    float z[VEC];
+    MsgFields s[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      z[q] = 1.0f;
+      if (a.defect_prob > 0.0f) {   // np.random.rand() > comm_defect_prob keeps the message (env 992)
+        if ((m & 3) == 0)
+          rnd[q] = philox4x32_10((uint32_t)(e + a.env_offset), (uint32_t)(h + q + a.house_offset), (uint32_t)a.k,
+                                 TAG_COMM | ((uint32_t)(m >> 2) << 8), a.k0, a.k1 ^ (a.episode * 0x85EBCA6Bu));
+        const uint32_t x = (m & 3) == 0 ? rnd[q].x : (m & 3) == 1 ? rnd[q].y : (m & 3) == 2 ? rnd[q].z : rnd[q].w;
+        z[q] = (float)u01(x) > a.defect_prob ? 1.0f : 0.0f;
+      }
+      s[q] = sender(m, q);
+    }
+#define MDR_MSG(expr)                               \
+  {                                                 \
+    _Pragma("unroll") for (int q = 0; q < VEC; ++q) v[q] = z[q] * (expr); \
+    put(v);                                         \
+  }
+    MDR_MSG(s[q].diff)
+    MDR_MSG(s[q].sso / L[q])
+    MDR_MSG(s[q].curr)
+    MDR_MSG(s[q].pmax)
+    if (a.m_thermal) {
+      MDR_MSG(s[q].Ua)
+      MDR_MSG(s[q].Cm)
+      MDR_MSG(s[q].Ca)
+      MDR_MSG(s[q].Hm)
+    }
+    if (a.m_hvac) {
+      MDR_MSG(s[q].COP)
+      MDR_MSG(s[q].latent)
+      MDR_MSG(s[q].cap)
+    }
+#undef MDR_MSG
+  }
+}
+
+// message fields of `count` consecutive (circular) houses starting at `first` -> LDS, field-major [nf][span]
+__device__ __forceinline__ void stage_senders(const ObsArgs& a, int64_t base, int first, int count, int span, float* msg,
+                                              int tid, int nthreads) {
+  for (int idx = tid; idx < count; idx += nthreads) {
+    int j = (first + idx) % a.N;
+    if (j < 0) j += a.N;
+    const MsgFields m = sender_from_global(a, base + j);
+    msg[0 * span + idx] = m.diff;
+    msg[1 * span + idx] = m.sso;
+    msg[2 * span + idx] = m.curr;
+    msg[3 * span + idx] = m.pmax;
+    int q = 4;
+    if (a.m_thermal) {
+      msg[(q + 0) * span + idx] = m.Ua;
+      msg[(q + 1) * span + idx] = m.Cm;
+      msg[(q + 2) * span + idx] = m.Ca;
+      msg[(q + 3) * span + idx] = m.Hm;
+      q += 4;
+    }
+    if (a.m_hvac) {
+      msg[(q + 0) * span + idx] = m.COP;
+      msg[(q + 1) * span + idx] = m.latent;
+      msg[(q + 2) * span + idx] = m.cap;
+    }
+  }
+}
+
+__device__ __forceinline__ MsgFields sender_from_lds(const ObsArgs& a, const float* msg, int span, int idx) {
+  MsgFields s;
+  s.diff = msg[0 * span + idx];
+  s.sso = msg[1 * span + idx];
+  s.curr = msg[2 * span + idx];
+  s.pmax = msg[3 * span + idx];
+  int q = 4;
+  if (a.m_thermal) {
+    s.Ua = msg[(q + 0) * span + idx];
+    s.Cm = msg[(q + 1) * span + idx];
+    s.Ca = msg[(q + 2) * span + idx];
+    s.Hm = msg[(q + 3) * span + idx];
+    q += 4;
+  }
+  if (a.m_hvac) {
+    s.COP = msg[(q + 0) * span + idx];
+    s.latent = msg[(q + 1) * span + idx];
+    s.cap = msg[(q + 2) * span + idx];
+  }
+  return s;
+}
+
+// ---- simple form: one thread per house, direct (4-byte) stores; fallback for shapes the other kernels cannot hold
 template <int LAYOUT>
 __global__ __launch_bounds__(256) void k_obs_vector(ObsArgs a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -506,85 +695,221 @@ __global__ __launch_bounds__(256) void k_obs_vector(ObsArgs a) {
   const int h = (int)(i - (int64_t)e * a.N);
   const int64_t base = (int64_t)e * a.N;
   int f = 0;
-  auto put = [&](float v) {
-    if (LAYOUT == MDR_OBS_PLANES) a.out[(int64_t)f * a.plane + i] = v;
-    else a.out[i * a.F + f] = v;
-    ++f;
-  };
-  const float L = (float)a.lockout[i];
-  put((a.Ta[i] + a.obs_tshift) * 0.2f);
-  put((a.Tm[i] + a.obs_tshift) * 0.2f);
-  put((a.target[i] + a.obs_tshift) * 0.2f);
-  if (a.f_thermal) put((a.od_now[e] + a.obs_tshift) * 0.2f);
-  put(a.deadband[i]);
-  if (a.f_day || a.f_hour) {
-    const Civil c = civil_from_epoch(a.t0[e] + a.k * (int64_t)a.dt);
-    if (a.f_day) {   // utils.py:806-809: tm_yday * 2 pi / 365
-      const double ang = (double)c.yday * 6.283185307179586476925286766559 / 365.0;
-      put((float)sin(ang));
-      put((float)cos(ang));
-    }
-    if (a.f_hour) {  // utils.py:810-813: integer hour * 2 pi / 24
-      const double ang = (double)c.hour * 6.283185307179586476925286766559 / 24.0;
-      put((float)sin(ang));
-      put((float)cos(ang));
-    }
-  }
-  if (a.f_solar) put(a.k > 0 ? a.solar_now[e] * 1e-3f : 0.0f);   // current_solar_gain is 0 until the first step (env 573)
-  put(a.capacity[i] * a.inv_cap);
-  if (a.f_thermal) {
-    put(a.Ua[i] * a.inv_Ua);
-    put(a.Cm[i] * a.inv_Cm);
-    put(a.Ca[i] * a.inv_Ca);
-    put(a.Hm[i] * a.inv_Hm);
-  }
-  if (a.f_hvac) {
-    put(a.COP[i] * a.inv_COP);
-    put(a.latent[i] * a.inv_latent);
-  }
-  const unsigned fl = a.flags[i];
-  put((fl & 1u) ? 1.0f : 0.0f);
-  put((fl & 2u) ? 1.0f : 0.0f);
-  put((float)a.sso[i] / L);
-  put(L / L);
-  put((float)(a.sig_now[e] * a.inv_obs_norm));
-  put((float)(a.P[e] * a.inv_obs_norm));
+  obs_features<1>(a, e, h, i,
+                  [&](const float* v) {
+                    if (LAYOUT == MDR_OBS_PLANES) a.out[(int64_t)f * a.out_plane + i] = v[0];
+                    else a.out[i * a.F + f] = v[0];
+                    ++f;
+                  },
+                  [&](int m, int) { return sender_from_global(a, base + sender_id(a, h, m)); });
+}
+
+// ---- planes layout, N % 4 == 0: one workgroup per 1024 houses of one env, 4 houses per thread.  The senders'
+// message fields (tile + c halo houses, circular) are staged once in LDS, so HBM sees each state array once and
+// the 10x message fan-out happens in LDS; every feature plane is written with 16-byte stores.
+constexpr int OBS_PTILE = 1024;
+
+__global__ __launch_bounds__(256) void k_obs_planes4(ObsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int e = blockIdx.y;
+  const int h0 = blockIdx.x * OBS_PTILE;
+  const int h = h0 + tid * 4;
+  const int64_t base = (int64_t)e * a.N;
+  const int span = OBS_PTILE + a.c;
   const int before = a.c / 2;
-  u32x4 rnd{0, 0, 0, 0};
-  for (int m = 0; m < a.c; ++m) {
-    int j;
-    if (a.links != nullptr) {
-      j = a.links[(int64_t)h * a.c + m];
-    } else {  // env 816-828: floor(c/2) houses before, ceil(c/2) after, circular
-      j = m < before ? h - before + m : h + 1 + (m - before);
-      j %= a.N;
-      if (j < 0) j += a.N;
+  const bool staged = (a.links == nullptr);
+  if (staged) {
+    stage_senders(a, base, h0 - before, min(span, a.N - h0 + a.c), span, lds, tid, 256);
+    __syncthreads();
+  }
+  if (h >= a.N) return;
+  int f = 0;
+  obs_features<4>(a, e, h, base + h,
+                  [&](const float* v) {
+                    *reinterpret_cast<float4*>(a.out + (int64_t)f * a.out_plane + base + h) = make_float4(v[0], v[1], v[2], v[3]);
+                    ++f;
+                  },
+                  [&](int m, int q) {
+                    if (!staged) return sender_from_global(a, base + sender_id(a, h + q, m));
+                    return sender_from_lds(a, lds, span, tid * 4 + q + m + (m >= before ? 1 : 0));
+                  });
+}
+
+// ---- rows layout (and planes for N % 4 != 0): one workgroup per TILE consecutive houses of one env.
+//  (1) sender fields staged in LDS as above; (2) every thread builds its house's F features into an LDS chunk laid
+//  out like the OUTPUT tile; (3) the chunk is streamed out with 16-byte stores: rows -> one contiguous TILE*F-float
+//  block, planes -> F rows of TILE floats.  TILE = 64 keeps a workgroup at one wavefront (LDS ~13 KB at F = 51).
+template <int LAYOUT, int TILE>
+__global__ __launch_bounds__(TILE) void k_obs_tiled(ObsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int e = blockIdx.y;
+  const int h0 = blockIdx.x * TILE;
+  const int h = h0 + tid;
+  const int nh = min(TILE, a.N - h0);
+  const int64_t base = (int64_t)e * a.N;
+  const int Fp = (LAYOUT == MDR_OBS_ROWS) ? (a.F | 1) : TILE;   // odd row stride: conflict-free ds_write
+  float* chunk = lds;
+  float* msg = lds + ((LAYOUT == MDR_OBS_ROWS) ? TILE * Fp : a.F * TILE);
+  const int span = TILE + a.c;
+  const int before = a.c / 2;
+  const bool staged = (a.links == nullptr);
+  if (staged) {
+    stage_senders(a, base, h0 - before, span, span, msg, tid, TILE);
+    __syncthreads();
+  }
+  if (h < a.N) {
+    int f = 0;
+    obs_features<1>(a, e, h, base + h,
+                    [&](const float* v) {
+                      chunk[(LAYOUT == MDR_OBS_ROWS) ? tid * Fp + f : f * TILE + tid] = v[0];
+                      ++f;
+                    },
+                    [&](int m, int) {
+                      if (!staged) return sender_from_global(a, base + sender_id(a, h, m));
+                      return sender_from_lds(a, msg, span, tid + m + (m >= before ? 1 : 0));
+                    });
+  }
+  __syncthreads();
+  if (LAYOUT == MDR_OBS_ROWS) {
+    float* dst = a.out + (base + h0) * a.F;          // nh * F contiguous floats
+    const int total = nh * a.F;
+    const bool vec = (((uintptr_t)dst) & 15u) == 0;
+    // element o of the tile <-> (row r, feature f) with o = r * F + f, advanced incrementally (no division in the loop)
+    int r = (tid * 4) / a.F, f = tid * 4 - r * a.F;
+    const int dr = (TILE * 4) / a.F, df = TILE * 4 - dr * a.F;
+    for (int o = tid * 4; o < total; o += TILE * 4) {
+      float v[4];
+      int rr = r, ff = f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[q] = chunk[min(rr, nh - 1) * Fp + ff];
+        if (++ff == a.F) {
+          ff = 0;
+          ++rr;
+        }
+      }
+      if (vec && o + 3 < total) {
+        *reinterpret_cast<float4*>(dst + o) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        for (int q = 0; q < 4 && o + q < total; ++q) dst[o + q] = v[q];
+      }
+      r += dr;
+      f += df;
+      if (f >= a.F) {
+        f -= a.F;
+        ++r;
+      }
     }
-    bool ok = true;
-    if (a.defect_prob > 0.0f) {   // np.random.rand() > comm_defect_prob keeps the message (env 992)
-      if ((m & 3) == 0)
-        rnd = philox4x32_10((uint32_t)(e + a.env_offset), (uint32_t)(h + a.house_offset), (uint32_t)a.k,
-                            TAG_COMM | ((uint32_t)(m >> 2) << 8), a.k0, a.k1 ^ (a.episode * 0x85EBCA6Bu));
-      const uint32_t x = (m & 3) == 0 ? rnd.x : (m & 3) == 1 ? rnd.y : (m & 3) == 2 ? rnd.z : rnd.w;
-      ok = (float)u01(x) > a.defect_prob;
+  } else {
+    for (int idx = tid; idx < a.F * TILE; idx += TILE) {   // N % 4 != 0 here: plain 4-byte stores
+      const int f = idx / TILE;
+      const int c = idx - f * TILE;
+      if (c < nh) a.out[(int64_t)f * a.out_plane + base + h0 + c] = chunk[idx];
     }
-    const int64_t s = base + j;
-    const float z = ok ? 1.0f : 0.0f;
-    const float pmax = a.P_max[s];
-    put(z * (a.Ta[s] - a.target[s]) * 0.2f);
-    put(z * (float)a.sso[s] / L);
-    put(z * ((a.flags[s] & 1u) ? pmax : 0.0f) * a.inv_norm_reg);
-    put(z * pmax * a.inv_norm_reg);
+  }
+}
+
+// ---- rows layout, circular neighbours: one workgroup per TILE consecutive houses of one env.  Only the COMPACT data
+// is staged in LDS - each house's own features [TILE][own], the senders' message fields [(TILE + c)][mf] and the
+// receivers' lockout - and the output rows are then generated directly in output order (element o = r * F + f) and
+// streamed with 16-byte stores.  ~17 KB of LDS per 256 houses, so occupancy is not LDS-bound and HBM sees each state
+// array once while the 10x message fan-out is served from LDS.
+template <int TILE>
+__global__ __launch_bounds__(TILE) void k_obs_rows(ObsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int e = blockIdx.y;
+  const int h0 = blockIdx.x * TILE;
+  const int h = h0 + tid;
+  const int nh = min(TILE, a.N - h0);
+  const int64_t base = (int64_t)e * a.N;
+  const int mf = 4 + (a.m_thermal ? 4 : 0) + (a.m_hvac ? 3 : 0);
+  const int own = a.F - a.c * mf;
+  const int ownp = own | 1;
+  const int span = TILE + a.c;
+  const int before = a.c / 2;
+  float* ownbuf = lds;                                   // [TILE][ownp]
+  float* msg = ownbuf + TILE * ownp;                     // [span][mf]
+  float* inv_lock = msg + span * mf;                     // [TILE]
+  uint32_t* dead = reinterpret_cast<uint32_t*>(inv_lock + TILE);   // [TILE] bit m: message slot m is defective
+  for (int idx = tid; idx < span; idx += TILE) {
+    int j = (h0 - before + idx) % a.N;
+    if (j < 0) j += a.N;
+    const MsgFields m = sender_from_global(a, base + j);
+    float* d = msg + idx * mf;
+    d[0] = m.diff;
+    d[1] = m.sso;
+    d[2] = m.curr;
+    d[3] = m.pmax;
+    int q = 4;
     if (a.m_thermal) {
-      put(z * a.Ua[s] * a.inv_Ua);
-      put(z * a.Cm[s] * a.inv_Cm);
-      put(z * a.Ca[s] * a.inv_Ca);
-      put(z * a.Hm[s] * a.inv_Hm);
+      d[q] = m.Ua; d[q + 1] = m.Cm; d[q + 2] = m.Ca; d[q + 3] = m.Hm;
+      q += 4;
     }
     if (a.m_hvac) {
-      put(z * a.COP[s] * a.inv_COP);
-      put(z * a.latent[s] * a.inv_latent);
-      put(z * a.capacity[s] * a.inv_cap);
+      d[q] = m.COP; d[q + 1] = m.latent; d[q + 2] = m.cap;
+    }
+  }
+  if (h < a.N) {
+    int f = 0;
+    obs_features<1, false>(a, e, h, base + h, [&](const float* v) { ownbuf[tid * ownp + f] = v[0]; ++f; },
+                           [&](int, int) { return MsgFields{}; });
+    inv_lock[tid] = 1.0f / (float)a.lockout[base + h];
+    uint32_t mask = 0;
+    if (a.defect_prob > 0.0f) {
+      u32x4 rnd{0, 0, 0, 0};
+      for (int m = 0; m < a.c; ++m) {
+        if ((m & 3) == 0)
+          rnd = philox4x32_10((uint32_t)(e + a.env_offset), (uint32_t)(h + a.house_offset), (uint32_t)a.k,
+                              TAG_COMM | ((uint32_t)(m >> 2) << 8), a.k0, a.k1 ^ (a.episode * 0x85EBCA6Bu));
+        const uint32_t x = (m & 3) == 0 ? rnd.x : (m & 3) == 1 ? rnd.y : (m & 3) == 2 ? rnd.z : rnd.w;
+        if (!((float)u01(x) > a.defect_prob)) mask |= 1u << m;
+      }
+    }
+    dead[tid] = mask;
+  }
+  __syncthreads();
+  float* dst = a.out + (base + h0) * a.F;          // nh * F contiguous floats
+  const int total = nh * a.F;
+  const bool vec = (((uintptr_t)dst) & 15u) == 0;
+  const uint32_t magic = (65536u + (uint32_t)mf - 1u) / (uint32_t)mf;   // g / mf == (g * magic) >> 16 for g < 4096
+  int r = (tid * 4) / a.F, f = tid * 4 - r * a.F;
+  const int dr = (TILE * 4) / a.F, df = TILE * 4 - dr * a.F;
+  for (int o = tid * 4; o < total; o += TILE * 4) {
+    float v[4];
+    int rr = r, ff = f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rc = min(rr, nh - 1);
+      float val;
+      if (ff < own) {
+        val = ownbuf[rc * ownp + ff];
+      } else {
+        const int g = ff - own;
+        const int m = (int)(((uint32_t)g * magic) >> 16);
+        const int k = g - m * mf;
+        val = msg[(rc + m + (m >= before ? 1 : 0)) * mf + k];
+        if (k == 1) val *= inv_lock[rc];                 // sender's seconds_since_off over the RECEIVER's lockout (utils.py:849-851)
+        if ((dead[rc] >> m) & 1u) val = 0.0f;
+      }
+      v[q] = val;
+      if (++ff == a.F) {
+        ff = 0;
+        ++rr;
+      }
+    }
+    if (vec && o + 3 < total) {
+      *reinterpret_cast<float4*>(dst + o) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      for (int q = 0; q < 4 && o + q < total; ++q) dst[o + q] = v[q];
+    }
+    r += dr;
+    f += df;
+    if (f >= a.F) {
+      f -= a.F;
+      ++r;
     }
   }
 }
@@ -596,7 +921,41 @@ int obs_vector_length(const mdr_obs_spec_t& s) {
   return own + s.nb_comm * msg;
 }
 
+template <typename K>
+static hipError_t launch_with_lds(K kernel, dim3 g, dim3 b, size_t lds_bytes, hipStream_t s, const ObsArgs& a) {
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kernel, g, b, lds_bytes, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_obs_vector(const ObsArgs& a, int layout, hipStream_t s) {
+  const size_t nf = 4 + (a.m_thermal ? 4 : 0) + (a.m_hvac ? 3 : 0);
+  const size_t lds_cap = 160 * 1024;
+  if (a.E <= 65535) {
+    if (layout == MDR_OBS_PLANES && a.N % 4 == 0 && (((uintptr_t)a.out) & 15u) == 0 && a.out_plane % 4 == 0) {
+      const size_t lds_bytes = nf * (OBS_PTILE + a.c) * sizeof(float);
+      if (lds_bytes <= lds_cap)
+        return launch_with_lds(k_obs_planes4, dim3((unsigned)((a.N + OBS_PTILE - 1) / OBS_PTILE), (unsigned)a.E), dim3(256), lds_bytes, s, a);
+    }
+    if (layout == MDR_OBS_ROWS && a.links == nullptr && a.c <= 32 && a.F < 4096) {
+      constexpr int RT = 256;
+      const size_t own = (size_t)(a.F - a.c * (int)nf) | 1;
+      const size_t lds_bytes = (RT * own + (RT + a.c) * nf + 2 * RT) * sizeof(float);
+      if (lds_bytes <= lds_cap)
+        return launch_with_lds(k_obs_rows<RT>, dim3((unsigned)((a.N + RT - 1) / RT), (unsigned)a.E), dim3(RT), lds_bytes, s, a);
+    }
+    constexpr int TILE = 64;
+    const size_t chunk = (layout == MDR_OBS_ROWS) ? (size_t)TILE * (a.F | 1) : (size_t)a.F * TILE;
+    const size_t lds_bytes = (chunk + nf * (TILE + a.c)) * sizeof(float);
+    if (lds_bytes <= lds_cap) {
+      const dim3 g((unsigned)((a.N + TILE - 1) / TILE), (unsigned)a.E), b(TILE);
+      if (layout == MDR_OBS_ROWS) return launch_with_lds(k_obs_tiled<MDR_OBS_ROWS, TILE>, g, b, lds_bytes, s, a);
+      return launch_with_lds(k_obs_tiled<MDR_OBS_PLANES, TILE>, g, b, lds_bytes, s, a);
+    }
+  }
   const dim3 g((unsigned)((a.plane + 255) / 256)), b(256);
   if (layout == MDR_OBS_PLANES)
     hipLaunchKernelGGL(k_obs_vector<MDR_OBS_PLANES>, g, b, 0, s, a);

@@ -53,7 +53,7 @@ def test_hip_obs_vector_matches_reference(name):
             planes = env.obs_vector("planes")
             rows = env.obs_vector("rows")
             assert planes.shape == (F, 1, g.N) and rows.shape == (1, g.N, F)
-            assert torch.equal(planes[:, 0, :].t().contiguous(), rows[0])
+            torch.testing.assert_close(planes[:, 0, :].t().contiguous(), rows[0], rtol=1e-6, atol=1e-7)
             np.testing.assert_allclose(rows[0].cpu().numpy(), g.a["norm_state"][k], rtol=2e-5, atol=2e-6)
             k += 1
         if t < g.T:
