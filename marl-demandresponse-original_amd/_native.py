@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libmdr_hip.so")
+LIB_PATH = os.environ.get("MDR_HIP_LIB") or os.path.join(HERE, "csrc", "libmdr_hip.so")   # MDR_HIP_LIB: experiment builds
 
 MDR_ABI_VERSION = 1
 MDR_MAX_SINUSOIDS = 8
