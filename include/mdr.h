@@ -215,6 +215,24 @@ int mdr_env_step(mdr_env_t *env, uint8_t *actions, int action_source, void *stre
 /* `nb_steps` consecutive steps without returning to the host (device-resident rollout). */
 int mdr_env_rollout(mdr_env_t *env, uint8_t *actions, int action_source, int32_t nb_steps, void *stream);
 
+/* Device-resident closed-loop rollout: `nb_steps` consecutive env steps with the bang-bang rule in ONE launch per
+ * table chunk.  State and per-episode parameters stay in registers between steps, so per step only the per-env
+ * scalars are read; HBM sees the state once per launch instead of once per step.  This is the loop of
+ * main-deploy.py:99-148 (BangBangController + metric accumulation) and of monteCarlo.py:193-201.  The bound buffers
+ * end in exactly the state `nb_steps` calls of mdr_env_step(..., MDR_ACTIONS_BANGBANG) leave (bit for bit:
+ * state, last reward, last observation planes, last actions, P).  Optional accumulators (NULL = skip):  */
+typedef struct mdr_rollout_out {
+  uint32_t struct_size;
+  uint32_t reserved0;
+  double *power_trace;             /* [nb_steps][E]   cluster_hvac_power after each step */
+  float *reward_sum;               /* [E][N]  += per-agent reward of every step (fp32, in step order) */
+  double *sq_temp_error_sum;       /* [E]     += sum over steps and houses of (house_temp - target)^2, main-deploy.py:127,138 */
+  double *sq_signal_error_sum;     /* [E]     += sum over steps of (reg_signal - cluster_hvac_power)^2, main-deploy.py:145-152 */
+} mdr_rollout_out_t;
+/* Returns MDR_ERR_UNSUPPORTED for shapes that need the split path (N > 2048, or N > 512 with N % 4 != 0) and
+ * for sharded houses: use mdr_env_rollout there. */
+int mdr_env_rollout_fused(mdr_env_t *env, uint8_t *actions, int32_t nb_steps, const mdr_rollout_out_t *out, void *stream);
+
 /* Sharded houses (one env spans several devices): step_begin updates the local houses and leaves the local
  * reductions in tot_sum/tot_max; the caller all-reduces them (SUM / MAX); step_end writes rewards and the
  * two power observation columns from the reduced values. */

@@ -97,12 +97,19 @@ class MdrObsSpec(C.Structure):
     ]
 
 
+class MdrRolloutOut(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("reserved0", C.c_uint32),
+        ("power_trace", _f64p), ("reward_sum", _f32p), ("sq_temp_error_sum", _f64p), ("sq_signal_error_sum", _f64p),
+    ]
+
+
 OBS_PLANES, OBS_ROWS = 0, 1
 
 EXPORTS = (
     "mdr_abi_version", "mdr_status_string", "mdr_last_error", "mdr_partials_per_env",
     "mdr_env_create", "mdr_env_destroy", "mdr_env_bind", "mdr_env_reset", "mdr_env_load_episode",
-    "mdr_env_set_od_table", "mdr_env_begin_episode", "mdr_env_step", "mdr_env_rollout",
+    "mdr_env_set_od_table", "mdr_env_begin_episode", "mdr_env_step", "mdr_env_rollout", "mdr_env_rollout_fused",
     "mdr_env_step_begin", "mdr_env_step_end", "mdr_obs_vector_length", "mdr_env_obs_vector",
     "mdr_env_cursor", "mdr_env_set_cursor",
 )
@@ -139,6 +146,7 @@ def load():
         "mdr_env_begin_episode": (C.c_int, [vp, vp]),
         "mdr_env_step": (C.c_int, [vp, vp, C.c_int, vp]),
         "mdr_env_rollout": (C.c_int, [vp, vp, C.c_int, i32, vp]),
+        "mdr_env_rollout_fused": (C.c_int, [vp, vp, i32, C.POINTER(MdrRolloutOut), vp]),
         "mdr_env_step_begin": (C.c_int, [vp, vp, C.c_int, vp]),
         "mdr_env_step_end": (C.c_int, [vp, vp]),
         "mdr_obs_vector_length": (i32, [C.POINTER(MdrObsSpec)]),

@@ -282,6 +282,34 @@ class BatchedDemandResponseEnv:
             rc = self._lib.mdr_env_rollout(self._handle, C.c_void_p(self._actions_ptr(actions)), src, int(nb_steps), self._stream())
             nat.check(self._lib, self._handle, rc, "mdr_env_rollout")
 
+    def rollout_fused(self, nb_steps: int, power_trace: bool = False, accumulate: bool = True):
+        """`nb_steps` bang-bang steps with the houses held in registers between steps (one launch per time-table
+        chunk).  Ends in the same state as ``rollout(nb_steps)`` bit for bit.  Returns a dict with the accumulators
+        of main-deploy.py:124-152: ``reward_sum`` [E,N], ``sq_temp_error_sum`` [E], ``sq_signal_error_sum`` [E] and,
+        if asked, ``power_trace`` [nb_steps, E].  Falls back to ``rollout`` (no accumulators) for unsupported shapes."""
+        E, N = self.nb_envs, self.nb_houses
+        out = nat.MdrRolloutOut()
+        out.struct_size = C.sizeof(nat.MdrRolloutOut)
+        res = {}
+        with torch.cuda.device(self.device):
+            if accumulate:
+                res["reward_sum"] = torch.zeros((E, N), dtype=torch.float32, device=self.device)
+                res["sq_temp_error_sum"] = torch.zeros(E, dtype=torch.float64, device=self.device)
+                res["sq_signal_error_sum"] = torch.zeros(E, dtype=torch.float64, device=self.device)
+                out.reward_sum = res["reward_sum"].data_ptr()
+                out.sq_temp_error_sum = res["sq_temp_error_sum"].data_ptr()
+                out.sq_signal_error_sum = res["sq_signal_error_sum"].data_ptr()
+            if power_trace:
+                res["power_trace"] = torch.zeros((nb_steps, E), dtype=torch.float64, device=self.device)
+                out.power_trace = res["power_trace"].data_ptr()
+            rc = self._lib.mdr_env_rollout_fused(self._handle, C.c_void_p(self.t["actions"].data_ptr()), int(nb_steps),
+                                                 C.byref(out), self._stream())
+            if rc == nat.MDR_ERR_UNSUPPORTED:
+                self.rollout(nb_steps)
+                return None
+            nat.check(self._lib, self._handle, rc, "mdr_env_rollout_fused")
+        return res
+
     # ------------------------------------------------------------------ full normStateDict vector
     def _obs_spec(self, layout: str) -> nat.MdrObsSpec:
         from .comm import build_comm_links, nb_comm

@@ -1,5 +1,6 @@
 // C-ABI host side of libmdr_hip.so (include/mdr.h).  No device allocation, no hidden synchronisation:
 // each call validates, fills a kernel argument block and enqueues launches on the caller's stream.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -356,6 +357,36 @@ int mdr_env_rollout(mdr_env_t* env, uint8_t* actions, int action_source, int32_t
   for (int32_t i = 0; i < nb_steps; ++i) {
     int rc = mdr_env_step(env, actions, action_source, stream);
     if (rc != MDR_OK) return rc;
+  }
+  return MDR_OK;
+}
+
+int mdr_env_rollout_fused(mdr_env_t* env, uint8_t* actions, int32_t nb_steps, const mdr_rollout_out_t* out, void* stream) {
+  if (!env) return MDR_ERR_INVALID;
+  if (nb_steps < 0) return fail(env, MDR_ERR_INVALID, "nb_steps must be >= 0");
+  if (out && out->struct_size != sizeof(mdr_rollout_out_t)) return fail(env, MDR_ERR_INVALID, "mdr_rollout_out_t size mismatch (ABI)");
+  if (env->cfg.nb_houses_total != env->cfg.nb_houses || !mdr::rollout_fused_supported(env->plan))
+    return fail(env, MDR_ERR_UNSUPPORTED, "fused rollout needs an env per workgroup or sub-wave group (N <= 2048 with N % 4 == 0, else N <= 512) and unsharded houses");
+  if (env->split_pending) return fail(env, MDR_ERR_INVALID, "step_begin without step_end");
+  const int E = env->cfg.nb_envs;
+  int32_t done = 0;
+  while (done < nb_steps) {
+    mdr::StepArgs a;
+    int rc = step_args(env, actions, MDR_ACTIONS_BANGBANG, (hipStream_t)stream, &a);   // refills the tables if the cursor left them
+    if (rc != MDR_OK) return rc;
+    const int64_t room = env->cfg.table_steps - (env->k - env->j0);   // steps the current tables still cover
+    mdr::RolloutArgs r{};
+    r.nsteps = (int)std::min<int64_t>(room, nb_steps - done);
+    if (out) {
+      r.power_trace = out->power_trace ? out->power_trace + (int64_t)done * E : nullptr;
+      r.reward_sum = out->reward_sum;
+      r.sq_temp_error_sum = out->sq_temp_error_sum;
+      r.sq_signal_error_sum = out->sq_signal_error_sum;
+    }
+    hipError_t e = mdr::launch_rollout_fused(a, r, env->plan, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(env, e, "rollout_fused");
+    env->k += r.nsteps;
+    done += r.nsteps;
   }
   return MDR_OK;
 }

@@ -99,6 +99,15 @@ struct ObsArgs {
   float inv_norm_reg, inv_cap, inv_Ua, inv_Cm, inv_Ca, inv_Hm, inv_COP, inv_latent;
 };
 
+// Accumulators of the fused multi-step rollout (all optional)
+struct RolloutArgs {
+  double* power_trace;
+  float* reward_sum;
+  double* sq_temp_error_sum;
+  double* sq_signal_error_sum;
+  int nsteps;
+};
+
 enum StepKind { STEP_FUSED = 0, STEP_GROUP = 1, STEP_SPLIT = 2 };
 struct StepPlan {
   int kind, vec, threads, tiles;
@@ -112,6 +121,8 @@ hipError_t launch_load(const EpisodeArgs& a, const mdr_episode_t& ep, hipStream_
 hipError_t launch_tables(const TableArgs& a, hipStream_t s);
 hipError_t launch_reset_obs(const StepArgs& a, hipStream_t s);  // uses sig_old = table row 0
 hipError_t launch_step(const StepArgs& a, const StepPlan& p, hipStream_t s);
+bool rollout_fused_supported(const StepPlan& p);
+hipError_t launch_rollout_fused(const StepArgs& a, const RolloutArgs& r, const StepPlan& p, hipStream_t s);
 hipError_t launch_obs_vector(const ObsArgs& a, int layout, hipStream_t s);
 int obs_vector_length(const mdr_obs_spec_t& spec);
 hipError_t launch_step_begin_split(const StepArgs& a, hipStream_t s);

@@ -187,6 +187,12 @@ __device__ __forceinline__ float temp_penalty(const StepArgs& a, float pen, doub
   return a.mix_i * pen + a.mix_c * common + a.mix_m * max_pen;
 }
 
+// r_i = -(alpha_temp * pen_i / norm_T + alpha_sig * sig / norm_S)  (env 364-372); one explicit fma so that every
+// kernel rounds it identically
+__device__ __forceinline__ float reward_value(const StepArgs& a, float pen, double sum_pen, float max_pen, float sig_term) {
+  return -__fmaf_rn(a.c_temp, temp_penalty(a, pen, sum_pen, max_pen), sig_term);
+}
+
 // signal part of the reward with the OLD signal (env 196, 234-251), fp64 per env
 __device__ __forceinline__ float signal_term(const StepArgs& a, double P, double S_old) {
   const double d = (P - S_old) * a.inv_n_total;
@@ -371,7 +377,7 @@ __device__ __forceinline__ void store_reward_power(const StepArgs& a, int64_t i,
   float r[VEC], c5[VEC], c6[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
-    r[v] = -(a.c_temp * temp_penalty(a, pen[v], sum_pen, max_pen) + sig_term);  // env 364-372
+    r[v] = reward_value(a, pen[v], sum_pen, max_pen, sig_term);
     c5[v] = o_sig;
     c6[v] = o_pow;
   }
@@ -424,6 +430,173 @@ __global__ __launch_bounds__(THREADS) void k_step_fused(StepArgs a) {
   }
 }
 
+// Per-env table rows for the multi-step kernels: a window of W consecutive steps lives in W lanes (lane l holds the
+// row of step s0 + l) and is read back with a shuffle; the next window is loaded one window ahead, so the dependent
+// global-load latency is paid once per W steps and overlaps W steps of arithmetic.
+struct EnvRow {
+  float od, solar;
+  double sig_old, sig_new;
+};
+
+__device__ __forceinline__ EnvRow window_load(const StepArgs& a, int e, int s_first, int nsteps, int lane_in_window) {
+  const int sr = min(s_first + lane_in_window, nsteps - 1);
+  const int64_t row = (int64_t)sr * a.E + e;
+  return EnvRow{a.od_old[row], a.solar_new[row], a.sig_old[row], a.sig_new[row]};
+}
+
+__device__ __forceinline__ EnvRow window_get(const EnvRow& w, int src_lane) {
+  return EnvRow{__shfl(w.od, src_lane, 64), __shfl(w.solar, src_lane, 64), __shfl(w.sig_old, src_lane, 64),
+                __shfl(w.sig_new, src_lane, 64)};
+}
+
+// ---- (1b) multi-step closed loop: the same workgroup-per-env mapping, but the houses stay in registers for
+// `nsteps` steps (bang-bang rule in-kernel).  Per step only the env's table scalars are read; the state is read
+// once and written once per launch.  One barrier per step (LDS partials are double-buffered by step parity).
+template <int VEC, int TILES, int THREADS, bool WINDOW>
+__global__ __launch_bounds__(THREADS) void k_rollout_fused(StepArgs a, RolloutArgs ro) {
+  __shared__ double lds[2][3 * (THREADS / 64)];
+  const int e = blockIdx.x;
+  const int64_t base = (int64_t)e * a.N;
+  HouseIn hs[TILES][VEC];
+  HouseOut o[TILES][VEC];
+  float rsum[TILES][VEC];
+  unsigned act[TILES][VEC];
+  bool live[TILES];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+    const int h = (t * THREADS + (int)threadIdx.x) * VEC;
+    live[t] = h < a.N;
+    if (live[t]) {
+      const int64_t i = base + h;
+      float Ta[VEC], Tm[VEC], k01[VEC], s0[VEC], k10[VEC], s1[VEC], iu[VEC], q[VEC], pm[VEC], tg[VEC], db[VEC];
+      int sso[VEC], lk[VEC];
+      unsigned fl[VEC];
+      load_vec<VEC>(a.Ta, i, Ta);
+      load_vec<VEC>(a.Tm, i, Tm);
+      load_vec<VEC>(a.sso, i, sso);
+      load_bytes<VEC>(a.flags, i, fl);
+      load_vec<VEC>(a.k01, i, k01);
+      load_vec<VEC>(a.s0, i, s0);
+      load_vec<VEC>(a.k10, i, k10);
+      load_vec<VEC>(a.s1, i, s1);
+      load_vec<VEC>(a.inv_Ua, i, iu);
+      load_vec<VEC>(a.Q_hvac, i, q);
+      load_vec<VEC>(a.P_max, i, pm);
+      load_vec<VEC>(a.target, i, tg);
+      load_vec<VEC>(a.deadband, i, db);
+      load_vec<VEC>(a.lockout, i, lk);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        hs[t][v] = HouseIn{Ta[v], Tm[v], sso[v], fl[v], k01[v], s0[v], k10[v], s1[v], iu[v], q[v], pm[v], tg[v], db[v], lk[v]};
+        rsum[t][v] = 0.0f;
+      }
+      if (ro.reward_sum) load_vec<VEC>(ro.reward_sum, i, rsum[t]);   // continue the caller's running sum in step order
+    }
+  }
+  double terr = 0.0, serr = 0.0;
+  Red3 tot{0.0, 0.0, 0.0f};
+  float sig_term = 0.0f;
+  // WINDOW: few workgroups in flight (latency-bound) -> shuffle-window prefetch; otherwise the rows are plain
+  // wave-uniform (scalar) loads whose latency the other resident waves hide, at no VALU cost.
+  const int wl = threadIdx.x & 63;
+  EnvRow cur{}, nxt{}, er{};
+  if (WINDOW) {
+    cur = window_load(a, e, 0, ro.nsteps, wl);
+    nxt = window_load(a, e, 64, ro.nsteps, wl);
+  }
+  for (int s = 0; s < ro.nsteps; ++s) {
+    const int64_t row = (int64_t)s * a.E + e;
+    if (WINDOW) {
+      if ((s & 63) == 0 && s > 0) {
+        cur = nxt;
+        nxt = window_load(a, e, s + 64, ro.nsteps, wl);
+      }
+      er = window_get(cur, s & 63);
+    } else {
+      er = EnvRow{a.od_old[row], a.solar_new[row], a.sig_old[row], a.sig_new[row]};
+    }
+    const float od_old = er.od;
+    const float solar = er.solar;
+    Red3 acc{0.0, 0.0, 0.0f};
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      if (live[t]) {
+        float p = 0.0f, ps = 0.0f, te = 0.0f;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const bool cmd = hs[t][v].Ta > hs[t][v].target;   // agents/bangbang_controllers.py:49-59
+          act[t][v] = cmd ? 1u : 0u;
+          o[t][v] = house_step(hs[t][v], cmd, od_old, solar, a.dt);
+          hs[t][v].Ta = o[t][v].Ta;
+          hs[t][v].Tm = o[t][v].Tm;
+          hs[t][v].sso = o[t][v].sso;
+          hs[t][v].flags = o[t][v].flags;
+          p += o[t][v].power;
+          ps += o[t][v].pen;
+          acc.max_pen = fmaxf(acc.max_pen, o[t][v].pen);
+          const float d = o[t][v].Ta - hs[t][v].target;
+          te = fmaf(d, d, te);
+        }
+        acc.sum_p += (double)p;
+        acc.sum_pen += (double)ps;
+        terr += (double)te;
+      }
+    }
+    tot = block_reduce<THREADS>(acc, lds[s & 1]);
+    sig_term = signal_term(a, tot.sum_p, er.sig_old);
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+      if (live[t]) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+          rsum[t][v] = __fadd_rn(rsum[t][v], reward_value(a, o[t][v].pen, tot.sum_pen, tot.max_pen, sig_term));
+      }
+    if (threadIdx.x == 0) {
+      if (ro.power_trace) ro.power_trace[row] = tot.sum_p;
+      const double d = er.sig_new - tot.sum_p;
+      serr += d * d;
+    }
+  }
+  if (ro.nsteps <= 0) return;
+  // final state, and the last step's outputs exactly as k_step_fused leaves them
+  const float o_sig = (float)(er.sig_new * a.inv_obs_norm);
+  const float o_pow = (float)(tot.sum_p * a.inv_obs_norm);
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+    if (!live[t]) continue;
+    const int64_t i = base + (t * THREADS + (int)threadIdx.x) * VEC;
+    float nTa[VEC], nTm[VEC], pen[VEC];
+    int nsso[VEC], lk[VEC];
+    unsigned nfl[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      nTa[v] = hs[t][v].Ta;
+      nTm[v] = hs[t][v].Tm;
+      nsso[v] = hs[t][v].sso;
+      nfl[v] = hs[t][v].flags;
+      lk[v] = hs[t][v].lockout;
+      pen[v] = o[t][v].pen;
+    }
+    store_vec<VEC>(a.Ta, i, nTa);
+    store_vec<VEC>(a.Tm, i, nTm);
+    store_vec<VEC>(a.sso, i, nsso);
+    store_bytes<VEC>(a.flags, i, nfl);
+    if (a.actions != nullptr) store_bytes<VEC>(a.actions, i, act[t]);
+    store_obs_local<VEC>(a, i, o[t], lk);
+    store_reward_power<VEC>(a, i, pen, tot.sum_pen, tot.max_pen, sig_term, o_sig, o_pow);
+    if (ro.reward_sum) store_vec<VEC>(ro.reward_sum, i, rsum[t]);
+  }
+  if (ro.sq_temp_error_sum) {   // one more reduction; the parity of the LDS buffer continues the step sequence
+    Red3 r{terr, 0.0, 0.0f};
+    r = block_reduce<THREADS>(r, lds[ro.nsteps & 1]);
+    if (threadIdx.x == 0) ro.sq_temp_error_sum[e] += r.sum_p;
+  }
+  if (threadIdx.x == 0) {
+    a.P[e] = tot.sum_p;
+    if (ro.sq_signal_error_sum) ro.sq_signal_error_sum[e] += serr;
+  }
+}
+
 // ---- (2) small envs: GROUP lanes per env (N <= GROUP <= 64), several envs per wavefront --------
 template <int GROUP>
 __global__ __launch_bounds__(256) void k_step_group(StepArgs a) {
@@ -449,6 +622,90 @@ __global__ __launch_bounds__(256) void k_step_group(StepArgs a) {
     if (lane == 0) a.P[e] = tot.sum_p;
     store_reward_power<1>(a, i, &o[0].pen, tot.sum_pen, tot.max_pen, sig_term, (float)(a.sig_new[e] * a.inv_obs_norm),
                           (float)(tot.sum_p * a.inv_obs_norm));
+  }
+}
+
+// ---- (2b) multi-step closed loop for small envs: GROUP lanes per env, one house per lane, no LDS, no barrier
+template <int GROUP, bool WINDOW>
+__global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs ro) {
+  const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / GROUP;
+  const int lane = threadIdx.x % GROUP;
+  const bool env_ok = gid < a.E;
+  const int e = env_ok ? (int)gid : a.E - 1;
+  const bool active = env_ok && lane < a.N;
+  const int64_t i = (int64_t)e * a.N + lane;
+  HouseIn hs{};
+  HouseOut o{};
+  int lockout[1] = {1};
+  if (active) {
+    hs = HouseIn{a.Ta[i], a.Tm[i], a.sso[i], a.flags[i], a.k01[i], a.s0[i], a.k10[i], a.s1[i], a.inv_Ua[i],
+                 a.Q_hvac[i], a.P_max[i], a.target[i], a.deadband[i], a.lockout[i]};
+    lockout[0] = hs.lockout;
+  }
+  float rsum = (active && ro.reward_sum) ? ro.reward_sum[i] : 0.0f, sig_term = 0.0f;
+  double terr = 0.0, serr = 0.0;
+  unsigned act = 0;
+  Red3 tot{0.0, 0.0, 0.0f};
+  const int gbase = (threadIdx.x & 63) & ~(GROUP - 1);   // first lane of this env's group inside the wavefront
+  EnvRow cur{}, nxt{}, er{};
+  if (WINDOW) {
+    cur = window_load(a, e, 0, ro.nsteps, lane);
+    nxt = window_load(a, e, GROUP, ro.nsteps, lane);
+  }
+  for (int s = 0; s < ro.nsteps; ++s) {
+    const int64_t row = (int64_t)s * a.E + e;
+    if (WINDOW) {
+      if ((s & (GROUP - 1)) == 0 && s > 0) {
+        cur = nxt;
+        nxt = window_load(a, e, s + GROUP, ro.nsteps, lane);
+      }
+      er = window_get(cur, gbase + (s & (GROUP - 1)));
+    } else {
+      er = EnvRow{a.od_old[row], a.solar_new[row], a.sig_old[row], a.sig_new[row]};
+    }
+    Red3 acc{0.0, 0.0, 0.0f};
+    if (active) {
+      const bool cmd = hs.Ta > hs.target;
+      act = cmd ? 1u : 0u;
+      o = house_step(hs, cmd, er.od, er.solar, a.dt);
+      hs.Ta = o.Ta;
+      hs.Tm = o.Tm;
+      hs.sso = o.sso;
+      hs.flags = o.flags;
+      acc.sum_p = (double)o.power;
+      acc.sum_pen = (double)o.pen;
+      acc.max_pen = o.pen;
+      const float d = o.Ta - hs.target;
+      terr += (double)(d * d);
+    }
+    tot = lanes_reduce<GROUP>(acc);
+    sig_term = signal_term(a, tot.sum_p, er.sig_old);
+    if (active) {
+      rsum = __fadd_rn(rsum, reward_value(a, o.pen, tot.sum_pen, tot.max_pen, sig_term));
+      if (lane == 0) {
+        if (ro.power_trace) ro.power_trace[row] = tot.sum_p;
+        const double d = er.sig_new - tot.sum_p;
+        serr += d * d;
+      }
+    }
+  }
+  if (ro.nsteps <= 0) return;
+  Red3 tr{terr, 0.0, 0.0f};
+  tr = lanes_reduce<GROUP>(tr);
+  if (!active) return;
+  a.Ta[i] = hs.Ta;
+  a.Tm[i] = hs.Tm;
+  a.sso[i] = hs.sso;
+  a.flags[i] = (uint8_t)hs.flags;
+  if (a.actions != nullptr) a.actions[i] = (uint8_t)act;
+  store_obs_local<1>(a, i, &o, lockout);
+  store_reward_power<1>(a, i, &o.pen, tot.sum_pen, tot.max_pen, sig_term, (float)(er.sig_new * a.inv_obs_norm),
+                        (float)(tot.sum_p * a.inv_obs_norm));
+  if (ro.reward_sum) ro.reward_sum[i] = rsum;
+  if (lane == 0) {
+    a.P[e] = tot.sum_p;
+    if (ro.sq_temp_error_sum) ro.sq_temp_error_sum[e] += tr.sum_p;
+    if (ro.sq_signal_error_sum) ro.sq_signal_error_sum[e] += serr;
   }
 }
 
@@ -1093,6 +1350,48 @@ hipError_t launch_step_end_split(const StepArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_step_finish<4>, g, b, 0, s, a);
   else
     hipLaunchKernelGGL(k_step_finish<1>, g, b, 0, s, a);
+  return hipGetLastError();
+}
+
+bool rollout_fused_supported(const StepPlan& p) { return p.kind == STEP_GROUP || (p.kind == STEP_FUSED && p.tiles <= 2); }
+
+hipError_t launch_rollout_fused(const StepArgs& a, const RolloutArgs& r, const StepPlan& p, hipStream_t s) {
+  if (!rollout_fused_supported(p)) return hipErrorInvalidValue;
+  if (p.kind == STEP_GROUP) {
+    const int64_t lanes = (int64_t)a.E * p.threads;
+    const dim3 gg((unsigned)((lanes + 255) / 256)), b(256);
+    const bool win = lanes < (int64_t)64 * 8 * 256;   // fewer than ~8 wavefronts per CU: latency-bound
+#define MDR_ROLLG(G)                                                          \
+  if (win) hipLaunchKernelGGL((k_rollout_group<G, true>), gg, b, 0, s, a, r); \
+  else hipLaunchKernelGGL((k_rollout_group<G, false>), gg, b, 0, s, a, r);    \
+  break;
+    switch (p.threads) {
+      case 1: MDR_ROLLG(1)
+      case 2: MDR_ROLLG(2)
+      case 4: MDR_ROLLG(4)
+      case 8: MDR_ROLLG(8)
+      case 16: MDR_ROLLG(16)
+      case 32: MDR_ROLLG(32)
+      default: MDR_ROLLG(64)
+    }
+#undef MDR_ROLLG
+    return hipGetLastError();
+  }
+  const dim3 g((unsigned)a.E);
+  const bool win = (int64_t)a.E * p.threads < (int64_t)64 * 8 * 256;
+#define MDR_ROLL(V, T, TH)                                                                  \
+  do {                                                                                      \
+    if (win) hipLaunchKernelGGL((k_rollout_fused<V, T, TH, true>), g, dim3(TH), 0, s, a, r); \
+    else hipLaunchKernelGGL((k_rollout_fused<V, T, TH, false>), g, dim3(TH), 0, s, a, r);    \
+  } while (0)
+  if (p.vec == 4) {
+    if (p.threads == 64) { if (p.tiles == 1) MDR_ROLL(4, 1, 64); else MDR_ROLL(4, 2, 64); }
+    else if (p.threads == 128) { if (p.tiles == 1) MDR_ROLL(4, 1, 128); else MDR_ROLL(4, 2, 128); }
+    else { if (p.tiles == 1) MDR_ROLL(4, 1, 256); else MDR_ROLL(4, 2, 256); }
+  } else {
+    if (p.tiles == 1) MDR_ROLL(1, 1, 256); else MDR_ROLL(1, 2, 256);
+  }
+#undef MDR_ROLL
   return hipGetLastError();
 }
 

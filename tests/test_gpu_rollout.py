@@ -1,0 +1,69 @@
+"""The fused multi-step rollout (houses resident in registers across steps) must end bit-for-bit where the same
+number of single bang-bang steps ends, and its accumulators must equal the stepwise sums (main-deploy.py:124-152)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(n, **patches):
+    import mdr_amd
+    cfg = mdr_amd.default_config()
+    cfg["default_env_prop"]["cluster_prop"]["nb_agents"] = n
+    cfg["default_env_prop"]["power_grid_prop"]["base_power_mode"] = "constant"
+    cfg["noise_house_prop"]["noise_mode"] = "big_noise"
+    cfg["noise_hvac_prop"]["noise_mode"] = "big_noise"
+    for dotted, v in patches.items():
+        node = cfg
+        parts = dotted.split(".")
+        for p in parts[:-1]:
+            node = node[p]
+        node[parts[-1]] = v
+    return cfg
+
+
+@pytest.mark.parametrize("E,N,mode", [(6, 1024, "individual_L2"), (3, 2048, "mixture"), (5, 256, "common_L2"), (4, 300, "individual_L2"),
+                                      (40, 50, "individual_L2"), (70, 10, "common_max"), (9, 1, "individual_L2"), (3, 64, "mixture")])
+def test_fused_rollout_equals_single_steps(E, N, mode):
+    import mdr_amd
+    cfg = _cfg(N, **{"default_env_prop.reward_prop.temp_penalty_mode": mode, "default_house_prop.deadband": 0.5})
+    T = 150                                   # crosses two table refills at K = 64
+    a = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=8)
+    b = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=8)
+    a.reset(episode=0)
+    b.reset(episode=0)
+    res = a.rollout_fused(T, power_trace=True)
+    assert res is not None
+    rsum = torch.zeros((E, N), dtype=torch.float32, device="cuda:0")
+    terr = torch.zeros(E, dtype=torch.float64, device="cuda:0")
+    serr = torch.zeros(E, dtype=torch.float64, device="cuda:0")
+    trace = []
+    for t in range(T):
+        _, reward, _, info = b.step_bangbang()
+        rsum += reward
+        d = (b.t["Ta"] - b.t["target"]).double()
+        terr += (d * d).sum(dim=1)
+        serr += (b.reg_signal() - info["cluster_hvac_power"]) ** 2
+        trace.append(info["cluster_hvac_power"].clone())
+    for k in ("Ta", "Tm", "sso", "flags", "reward", "obs", "P", "actions"):
+        assert torch.equal(a.t[k], b.t[k]), k
+    assert a.steps_taken == b.steps_taken == T
+    assert torch.equal(res["power_trace"], torch.stack(trace))
+    assert torch.equal(res["reward_sum"], rsum)
+    torch.testing.assert_close(res["sq_signal_error_sum"], serr, rtol=1e-12, atol=0)
+    torch.testing.assert_close(res["sq_temp_error_sum"], terr, rtol=1e-6, atol=0)   # fp32 squares, different summation tree
+    a.rollout_fused(10)                        # keeps going from where it stopped
+    b.rollout(10)
+    assert torch.equal(a.t["Ta"], b.t["Ta"]) and torch.equal(a.t["reward"], b.t["reward"])
+
+
+def test_fused_rollout_unsupported_shapes_fall_back():
+    import mdr_amd
+    env = mdr_amd.BatchedDemandResponseEnv(_cfg(5000), nb_envs=2, device="cuda:0", seed=1)
+    twin = mdr_amd.BatchedDemandResponseEnv(_cfg(5000), nb_envs=2, device="cuda:0", seed=1)
+    env.reset(episode=0)
+    twin.reset(episode=0)
+    assert env.rollout_fused(20) is None       # split-path shape: plain rollout ran instead
+    twin.rollout(20)
+    assert torch.equal(env.t["Ta"], twin.t["Ta"]) and env.steps_taken == 20

@@ -49,7 +49,7 @@ def report(name, us, houses, bytes_per_house):
 
 
 def main():
-    what = sys.argv[1:] or ["step", "obs", "c2", "c1", "c5", "reset"]
+    what = sys.argv[1:] or ["step", "obs", "c2", "c1", "c5", "fused", "reset"]
     if "step" in what:
         env = mdr_amd.BatchedDemandResponseEnv(cfg_for(1024), nb_envs=4096, seed=1)
         env.reset()
@@ -85,6 +85,14 @@ def main():
         env.reset()
         report("1 env x 125k houses (C5 per-GPU share), split path", timeit(lambda: env.rollout(50), 10) / 50, n8, 111)
         del env
+    if "fused" in what:
+        for (E, N, K) in ((4096, 1024, 64), (4096, 1024, 1024), (1024, 50, 1024), (1, 10, 1024), (32768, 50, 1024)):
+            env = mdr_amd.BatchedDemandResponseEnv(cfg_for(N), nb_envs=E, seed=1, table_steps=K)
+            env.reset()
+            steps = 1024
+            us = timeit(lambda: env.rollout_fused(steps, accumulate=True), 3, warm=1) / steps
+            report("fused multi-step rollout %dx%d, table_steps=%d (per step)" % (E, N, K), us, E * N, 0)
+            del env
     if "reset" in what:
         env = mdr_amd.BatchedDemandResponseEnv(cfg_for(1024), nb_envs=4096, seed=1)
         report("C3 reset (sample + derive + tables)", timeit(lambda: env.reset(), 5, warm=1), 4096 * 1024, 114)
