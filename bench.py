@@ -57,10 +57,19 @@ def cpu_baseline(cfg_full, seconds):
     cfg = copy.deepcopy(cfg_full)
     cfg["default_env_prop"]["power_grid_prop"]["signal_mode"] = "sinusoidals"   # deterministic family the port restates
     rate, steps, el = loop_port.time_baseline(cfg, seconds=seconds)
-    return {"value": rate, "unit": "house-steps/s", "cores": 1, "kind": "port",
-            "sample": "oracle/loop_port.py (object-per-house pure-Python restatement, obs dicts + 10-neighbour "
-                      "messages as the reference builds them), 1 env x %d houses x %d bang-bang steps, %.1f s"
-                      % (N_HOUSES, steps, el)}
+    out = {"value": rate, "unit": "house-steps/s", "cores": 1, "kind": "port",
+           "sample": "oracle/loop_port.py (object-per-house pure-Python restatement, obs dicts + 10-neighbour "
+                     "messages as the reference builds them), 1 env x %d houses x %d bang-bang steps, %.1f s"
+                     % (N_HOUSES, steps, el)}
+    try:   # the same per-house arithmetic compiled (oracle/mdr_oracle_c.c): what one core does without the interpreter
+        from oracle import c_port
+        crate, csteps, cel = c_port.time_baseline(cfg, nb_envs=4, seconds=min(4.0, seconds))
+        out["c_port_value"] = crate
+        out["c_port_sample"] = "oracle/mdr_oracle_c.c (plain C, literal closed-form update, gcc -O2), 4 envs x %d houses x %d steps, %.1f s, 1 core" % (N_HOUSES, csteps, cel)
+    except Exception as exc:   # no compiler on the box: the Python port above still stands
+        out["c_port_value"] = None
+        out["c_port_sample"] = "unavailable: %s" % exc
+    return out
 
 
 def traffic_from_profiles():
