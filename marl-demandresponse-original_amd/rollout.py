@@ -1,0 +1,113 @@
+"""Device-resident PPO rollout collection on top of the batched env.
+
+What train_ppo.py:60-108 does per step for ONE env - ``normStateDict`` -> ``PPO.select_action`` (actor forward on
+a batch of 1, ``Categorical.sample``) -> ``env.step`` -> ``store_transition`` - is done here for all E x N agents
+at once with tensors that never leave the GPU:
+
+    obs rows [E*N, F]  (HIP: mdr_env_obs_vector)  ->  actor MLP (rocBLAS GEMMs via torch)  ->  multinomial
+    ->  actions uint8 [E, N]  ->  mdr_env_step  ->  reward [E, N]
+
+PyTorch is used for the policy network only (tiny dense layers: plain library GEMMs); the env arithmetic stays in
+libmdr_hip.so.  ``ActorMLP`` / ``CriticMLP`` keep the reference's module layout (agents/network.py:14-57:
+``fc`` ModuleList, ReLU, softmax head) so a reference ``actor.pth`` state_dict loads unchanged.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class ActorMLP(nn.Module):
+    """agents/network.py:14-33 - Linear/ReLU stack with a softmax head; state_dict keys ``fc.<i>.weight|bias``."""
+
+    def __init__(self, num_state: int, num_action: int = 2, layers: Sequence[int] = (100, 100)):
+        super().__init__()
+        dims = [num_state] + [int(x) for x in layers]
+        self.layers = list(layers)
+        self.fc = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
+        self.fc.append(nn.Linear(dims[-1], num_action))
+
+    def forward(self, x):
+        for lin in self.fc[:-1]:
+            x = F.relu(lin(x))
+        return F.softmax(self.fc[-1](x), dim=1)
+
+
+class CriticMLP(nn.Module):
+    """agents/network.py:36-57."""
+
+    def __init__(self, num_state: int, layers: Sequence[int] = (100, 100)):
+        super().__init__()
+        dims = [num_state] + [int(x) for x in layers]
+        self.layers = list(layers)
+        self.fc = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
+        self.fc.append(nn.Linear(dims[-1], 1))
+
+    def forward(self, x):
+        for lin in self.fc[:-1]:
+            x = F.relu(lin(x))
+        return self.fc[-1](x)
+
+
+def discounted_returns(reward: torch.Tensor, done: torch.Tensor, gamma: float,
+                       bootstrap: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The Monte-Carlo return scan of PPO.update (agents/ppo.py:123-134) along dim 0 of ``reward`` [T, ...]:
+    R_t = r_t + gamma * R_{t+1}; where ``done[t]`` the running return restarts from ``bootstrap[t]`` (the critic's value
+    of the next state, or 0 with zero_eoepisode_return) before adding r_t."""
+    T = reward.shape[0]
+    out = torch.empty_like(reward)
+    running = torch.zeros_like(reward[0])
+    for t in range(T - 1, -1, -1):
+        if bootstrap is not None:
+            running = torch.where(done[t], bootstrap[t], running)
+        else:
+            running = torch.where(done[t], torch.zeros_like(running), running)
+        running = reward[t] + gamma * running
+        out[t] = running
+    return out
+
+
+@torch.no_grad()
+def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.99, critic: Optional[nn.Module] = None,
+                        generator: Optional[torch.Generator] = None, store_states: bool = True) -> Dict[str, torch.Tensor]:
+    """Roll ``nb_steps`` with actions sampled from ``actor`` for every agent of every env.
+
+    Returns tensors with the agents flattened as [T, E*N, ...] in the reference's per-agent order:
+    ``state`` [T+1, E*N, F] (``state[t+1]`` is ``next_state[t]``; omitted if ``store_states`` is False), ``action`` int64,
+    ``a_prob`` (probability of the taken action - the reference stores the probability, not its log: agents/ppo.py:75),
+    ``reward``, ``done`` (True on the last step: train_ppo.py:84) and ``return`` (discounted_returns)."""
+    E, N = env.nb_envs, env.nb_houses
+    F_len = env.obs_vector_length()
+    dev = env.device
+    T = int(nb_steps)
+    states = torch.empty((T + 1, E * N, F_len), dtype=torch.float32, device=dev) if store_states else None
+    action = torch.empty((T, E * N), dtype=torch.int64, device=dev)
+    a_prob = torch.empty((T, E * N), dtype=torch.float32, device=dev)
+    reward = torch.empty((T, E * N), dtype=torch.float32, device=dev)
+    obs = env.obs_vector("rows").view(E * N, F_len)
+    for t in range(T):
+        if store_states:
+            states[t].copy_(obs)
+        probs = actor(obs)
+        a = torch.multinomial(probs, 1, generator=generator).squeeze(1)        # Categorical(action_prob).sample()
+        action[t] = a
+        a_prob[t] = probs.gather(1, a[:, None]).squeeze(1)
+        _, r, _, _ = env.step(a.to(torch.uint8).view(E, N))
+        reward[t] = r.reshape(-1)
+        obs = env.obs_vector("rows").view(E * N, F_len)
+    if store_states:
+        states[T].copy_(obs)
+    done = torch.zeros((T, E * N), dtype=torch.bool, device=dev)
+    done[T - 1] = True
+    bootstrap = None
+    if critic is not None:
+        bootstrap = torch.zeros((T, E * N), dtype=torch.float32, device=dev)
+        bootstrap[T - 1] = critic(obs).squeeze(1)
+    out = {"action": action, "a_prob": a_prob, "reward": reward, "done": done,
+           "return": discounted_returns(reward, done, gamma, bootstrap)}
+    if store_states:
+        out["state"] = states
+    return out

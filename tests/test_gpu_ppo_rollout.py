@@ -1,0 +1,68 @@
+"""Row f-2: device-resident PPO rollout collection (batched actor forward, sampling, transition tensors, returns)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(E, N):
+    import mdr_amd
+    cfg = mdr_amd.default_config()
+    cfg["default_env_prop"]["cluster_prop"]["nb_agents"] = N
+    cfg["default_env_prop"]["power_grid_prop"]["base_power_mode"] = "constant"
+    env = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=3)
+    env.reset(episode=0)
+    return env
+
+
+def test_actor_layout_matches_reference_state_dict_keys():
+    from mdr_amd.rollout import ActorMLP, CriticMLP
+    a = ActorMLP(51, 2, [100, 100])
+    assert list(a.state_dict().keys()) == ["fc.0.weight", "fc.0.bias", "fc.1.weight", "fc.1.bias", "fc.2.weight", "fc.2.bias"]
+    assert a.state_dict()["fc.0.weight"].shape == (100, 51) and a.state_dict()["fc.2.weight"].shape == (2, 100)
+    assert CriticMLP(51, [100, 100]).state_dict()["fc.2.weight"].shape == (1, 100)
+    p = a(torch.randn(7, 51))
+    torch.testing.assert_close(p.sum(1), torch.ones(7))
+
+
+def test_collect_rollout_shapes_sampling_and_returns():
+    from mdr_amd.rollout import ActorMLP, CriticMLP, collect_ppo_rollout, discounted_returns
+    E, N, T = 64, 50, 12
+    env = _env(E, N)
+    F = env.obs_vector_length()
+    assert F == 51
+    torch.manual_seed(0)
+    actor = ActorMLP(F).cuda()
+    critic = CriticMLP(F).cuda()
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    ro = collect_ppo_rollout(env, actor, T, gamma=0.9, critic=critic, generator=gen)
+    assert ro["state"].shape == (T + 1, E * N, F) and ro["action"].shape == (T, E * N)
+    assert env.steps_taken == T
+    # the stored probability is the actor's probability of the action that was taken, on the stored state
+    p = actor(ro["state"][3])
+    torch.testing.assert_close(p.gather(1, ro["action"][3][:, None]).squeeze(1), ro["a_prob"][3])
+    # actions are drawn from those probabilities
+    p1 = torch.stack([actor(ro["state"][t])[:, 1] for t in range(T)])
+    assert abs(ro["action"].float().mean().item() - p1.mean().item()) < 0.01
+    # state[t+1] is what the env shows after step t: its reward column dependencies are consistent with the env
+    torch.testing.assert_close(ro["state"][T], env.obs_vector("rows").view(E * N, F))
+    # returns: the reference's backward loop (agents/ppo.py:123-134) on one agent
+    r = ro["reward"][:, 5].cpu().numpy()
+    v = critic(ro["state"][T][5:6]).item()
+    R, ref = v, []
+    for t in reversed(range(T)):
+        if t != T - 1:
+            pass
+        R = r[t] + 0.9 * R
+        ref.insert(0, R)
+    np.testing.assert_allclose(ro["return"][:, 5].cpu().numpy(), ref, rtol=1e-5)
+    # done restarts the running return
+    rew = torch.tensor([[1.0], [2.0], [3.0], [4.0]])
+    done = torch.tensor([[False], [True], [False], [True]])
+    got = discounted_returns(rew, done, 0.5)
+    assert got.squeeze(1).tolist() == [1 + 0.5 * 2, 2.0, 3 + 0.5 * 4, 4.0]
+    # same generator seed -> same rollout
+    env2 = _env(E, N)
+    ro2 = collect_ppo_rollout(env2, actor, T, gamma=0.9, critic=critic, generator=torch.Generator(device="cuda").manual_seed(1))
+    assert torch.equal(ro["action"], ro2["action"]) and torch.equal(ro["reward"], ro2["reward"])
