@@ -64,6 +64,8 @@ TAG_HOUSE_THERMO = 3  # x0..x3 -> triangular factors for Ua, Cm, Ca, Hm
 TAG_ENV_START = 4     # x0 -> days ; x1 -> seconds ; x2 -> phase ; x3 -> artificial ratio
 TAG_OD_NOISE = 5      # counter word 1 = time index ; x0,x1 -> gauss
 TAG_PERLIN = 6        # counter word 1 = lattice index ; x0 -> gradient
+TAG_COMM = 7          # message-link defects (kernel k_obs_*): not restated in the oracle (statistical test only)
+TAG_INTERP = 8        # counter word 1 = draw index q, word 2 = time index ; x0 -> house sampled for the base power
 ENV_LEVEL = 0xFFFFFFFF
 
 
@@ -276,6 +278,56 @@ def perlin_octaves(x_over_period, gradient_fn, nb_octaves, octaves_step):
 
 
 # --------------------------------------------------------------------------- #
+# Interpolated base power (monteCarlo/interpolation.py:113-142, env/MA_DemandResponse.py:1195-1234)
+# --------------------------------------------------------------------------- #
+INTERP_KEYS = ("Ua_ratio", "Cm_ratio", "Ca_ratio", "Hm_ratio", "air_temp", "mass_temp", "OD_temp", "HVAC_power", "hour", "date")
+INTERP_NEAREST = (0, 1, 2, 3, 7)      # thermal ratios and HVAC power: nearest grid value (interpolation.py:121-134)
+INTERP_LINEAR = (4, 5, 6, 8, 9)       # air, mass, OD temperature differences, hour, date: multilinear (interpn)
+
+
+class InterpGrid:
+    """PowerInterpolator.interpolateGridFast restated for arrays of points.
+
+    values: flat array in the reference's C order over the 10 axes of `axes` (dict key -> grid coordinates)."""
+
+    def __init__(self, values, axes: dict, keys=INTERP_KEYS):
+        self.keys = list(keys)
+        if tuple(self.keys) != INTERP_KEYS:
+            raise ValueError("interpolation grid axes must be " + ", ".join(INTERP_KEYS))
+        self.axes = [np.asarray(axes[k], dtype=np.float64) for k in self.keys]
+        self.dims = [len(a) for a in self.axes]
+        self.values = np.asarray(values, dtype=np.float64).reshape(self.dims)
+
+    def clip(self, point):
+        """utils.clipInterpolationPoint (utils.py:1214-1221) on [..., 10] points."""
+        out = np.array(point, dtype=np.float64, copy=True)
+        for d, ax in enumerate(self.axes):
+            out[..., d] = np.clip(out[..., d], ax.min(), ax.max())
+        return out
+
+    def lookup(self, point):
+        p = self.clip(point)
+        idx = [None] * 10
+        for d in INTERP_NEAREST:
+            idx[d] = np.argmin(np.abs(self.axes[d][None, :] - p[..., d].reshape(-1, 1)), axis=1).reshape(p.shape[:-1])
+        lo, w = {}, {}
+        for d in INTERP_LINEAR:
+            ax = self.axes[d]
+            i = np.clip(np.searchsorted(ax, p[..., d], side="right") - 1, 0, len(ax) - 2)
+            lo[d] = i
+            w[d] = (p[..., d] - ax[i]) / (ax[i + 1] - ax[i])
+        total = np.zeros(p.shape[:-1])
+        for corner in range(32):
+            weight = np.ones(p.shape[:-1])
+            for bit, d in enumerate(INTERP_LINEAR):
+                up = (corner >> bit) & 1
+                idx[d] = lo[d] + up
+                weight = weight * (w[d] if up else 1.0 - w[d])
+            total = total + weight * self.values[tuple(idx)]
+        return total
+
+
+# --------------------------------------------------------------------------- #
 # Config parsing (schema: config.py of the reference, SURVEY Appendix D)
 # --------------------------------------------------------------------------- #
 PENALTY_MODES = ("individual_L2", "common_L2", "common_max", "mixture")
@@ -350,8 +402,8 @@ def parse_config(config: dict, nb_envs: int = 1) -> OracleSpec:
     tp = cl["temp_parameters"][cl["temp_mode"]]
     if env["start_datetime_mode"] not in ("random", "fixed"):
         raise ValueError("start_datetime_mode must be random or fixed")
-    if pg["base_power_mode"] != "constant":
-        raise ValueError("oracle supports base_power_mode='constant' only (interpolation grid is a missing blob)")
+    if pg["base_power_mode"] not in ("constant", "interpolation"):
+        raise ValueError("The base_power_mode parameter in the config file can only be 'constant' or 'interpolation'")
     mode = pg["signal_mode"]
     if not (mode in ("flat", "sinusoidals", "regular_steps") or "perlin" in mode):
         raise ValueError("Invalid power grid signal mode: {}".format(mode))
@@ -414,6 +466,11 @@ class OracleEnv:
         self.episode = 0
         self.seed = 0
         self.od_table = None
+        self.interp_grid = None       # InterpGrid, required when base_power_mode == "interpolation"
+        ip = config["default_env_prop"]["power_grid_prop"]["base_power_parameters"].get("interpolation", {})
+        self.interp_period = ip.get("interp_update_period", 300)
+        self.interp_nb_agents = ip.get("interp_nb_agents", 100)
+        self.default_ratios = (self.spec.Ua, self.spec.Cm, self.spec.Ca, self.spec.Hm)
         self.group_reduce = None  # hook for sharded runs: fn(sumP, sumPen, maxPen) -> global values
         norm_t = float(deadband_l2(np.float64(s.target), 0.0, np.float64(s.target + 1)))
         norm_s = float(deadband_l2(np.float64(s.norm_reg_sig), 0.0, np.float64(0.75 * s.norm_reg_sig)))
@@ -493,6 +550,8 @@ class OracleEnv:
         self.P = np.zeros(E)                              # env 796-801 (all off)
         self.solar = np.zeros(E)
         self.OD = self._od_temp(0)                        # env 793
+        self.base_power = np.zeros(E)                     # env 1190
+        self.tsli = self.interp_period + 1                # env 1155
         self.S = self._signal(0)                          # env 133
 
     # ---- per-env time functions ------------------------------------------- #
@@ -521,7 +580,14 @@ class OracleEnv:
         s = self.spec
         c = self._time(j)
         n_hvac = self.N_total
-        base = np.full(self.E, s.avg_power_per_hvac * n_hvac, dtype=np.float64)   # env 1249
+        if s.base_power_mode == "constant":
+            base = np.full(self.E, s.avg_power_per_hvac * n_hvac, dtype=np.float64)   # env 1249
+        else:                                                                         # env 1250-1255
+            self.tsli += s.dt
+            if self.tsli >= self.interp_period:
+                self.base_power = self._interpolate_power(j, c)
+                self.tsli = 0
+            base = self.base_power
         sod = c["sod"].astype(np.float64)
         mode = s.signal_mode
         if mode == "flat":
@@ -547,6 +613,36 @@ class OracleEnv:
             sig = np.maximum(0.0, base + base * amp * noise)
         sig = sig * self.ratio                               # env 1312
         return np.minimum(sig, self.max_power)               # env 1314
+
+    def _interpolate_power(self, j, cal):
+        """PowerGrid.interpolatePower (env 1195-1234): sum of the grid's bang-bang average power over (a sample of)
+        the houses, scaled back to the whole cluster."""
+        if self.interp_grid is None:
+            raise ValueError("base_power_mode='interpolation' needs an interpolation grid (OracleEnv.interp_grid)")
+        s = self.spec
+        E, N = self.E, self.N
+        if N <= self.interp_nb_agents:
+            ids = np.broadcast_to(np.arange(N)[None, :], (E, N))
+            factor = 1.0
+        else:   # random.choices(all_ids, k=interp_nb_agents) -> Philox stream TAG_INTERP
+            k0, k1 = seed_key(self.seed)
+            q = np.arange(self.interp_nb_agents)[None, :]
+            x = philox4x32_10(self._env_ids()[:, None], q, j, TAG_INTERP | (self.episode << 8), k0, k1)
+            ids = mulhi_pick(x[0], N)
+            factor = float(N) / self.interp_nb_agents
+        rows = np.arange(E)[:, None]
+        g = lambda a: a[rows, ids]
+        if s.solar_on:   # env 1198-1202: tm_yday and seconds since midnight
+            date = np.broadcast_to(cal["yday"].astype(np.float64)[:, None], ids.shape)
+            hour = np.broadcast_to(cal["sod"].astype(np.float64)[:, None], ids.shape)
+        else:
+            date = np.zeros(ids.shape)
+            hour = np.zeros(ids.shape)
+        target = g(self.target)
+        point = np.stack([g(self.Ua) / s.Ua, g(self.Cm) / s.Cm, g(self.Ca) / s.Ca, g(self.Hm) / s.Hm,
+                          g(self.Ta) - target, g(self.Tm) - target, self.OD[:, None] - target, g(self.capacity),
+                          hour, date], axis=-1)
+        return self.interp_grid.lookup(point).sum(axis=1) * factor
 
     # ---- the step ----------------------------------------------------------- #
     def step(self, actions):

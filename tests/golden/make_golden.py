@@ -81,7 +81,36 @@ def capture_params(env):
     )
 
 
-def run_scenario(name, patches, seed, T, policy, perlin=False, norm_steps=(0, 1, -1)):
+INTERP_DIR = "/tmp/mdr_golden_interp"
+
+
+def make_small_grid(seed):
+    """A small synthetic 10-D base-power grid in the reference's file formats (mergedGridSearchResultFinal.npy is a
+    missing blob): the reference's own PowerInterpolator then reads it through the config paths."""
+    import csv
+    os.makedirs(INTERP_DIR, exist_ok=True)
+    axes = {"Ua_ratio": [0.9, 1, 1.1], "Cm_ratio": [0.9, 1.1], "Ca_ratio": [0.95, 1.05], "Hm_ratio": [0.9, 1.1],
+            "air_temp": [-4, -1, 0.3, 4], "mass_temp": [-4, 0, 4], "OD_temp": [1, 9, 15],
+            "HVAC_power": [10000, 15000], "hour": [0.0, 27000.0, 46800.0, 86399.0],
+            "date": [0, 171, 364]}
+    rng = np.random.default_rng(seed)
+    dims = [len(v) for v in axes.values()]
+    # smooth-ish positive field (whole watts) so that interpolation weights matter
+    values = np.round(3000.0 + 2500.0 * np.sin(np.arange(int(np.prod(dims))) * 0.37) + rng.uniform(0, 400, int(np.prod(dims))))
+    np.savez_compressed(os.path.join(OUT, "interp_grid_small.npz"), values=values.astype(np.int16), axes=np.array(json.dumps(axes)))
+    np.save(os.path.join(INTERP_DIR, "grid.npy"), values)
+    with open(os.path.join(INTERP_DIR, "params.json"), "w") as f:
+        json.dump(axes, f)
+    with open(os.path.join(INTERP_DIR, "keys.csv"), "w") as f:
+        csv.writer(f).writerow(list(axes.keys()))
+    ip = PG + "base_power_parameters.interpolation."
+    patches = {PG + "base_power_mode": "interpolation", ip + "path_datafile": os.path.join(INTERP_DIR, "grid.npy"),
+               ip + "path_parameter_dict": os.path.join(INTERP_DIR, "params.json"),
+               ip + "path_dict_keys": os.path.join(INTERP_DIR, "keys.csv")}
+    return patches, dict(interp_grid_file=np.array("interp_grid_small.npz"))
+
+
+def run_scenario(name, patches, seed, T, policy, perlin=False, norm_steps=(0, 1, -1), extra=None):
     ref = ref_harness.load_reference()
     cfg = copy.deepcopy({k: ref["config_dict"][k] for k in ENV_KEYS})
     patch(cfg, "default_env_prop.power_grid_prop.base_power_mode", "constant")  # the interpolation grid is a missing blob
@@ -102,6 +131,7 @@ def run_scenario(name, patches, seed, T, policy, perlin=False, norm_steps=(0, 1,
     rec = capture_params(env)
     od = [env.cluster.current_OD_temp]
     S = [float(env.power_grid.current_signal)]
+    base_power = [float(env.power_grid.base_power)]
     act_rng = np.random.default_rng(seed + 1000)
     actors = {i: ref["BangBangController"]({"id": i}, cfg) for i in range(N)}
     norm = []
@@ -140,6 +170,7 @@ def run_scenario(name, patches, seed, T, policy, perlin=False, norm_steps=(0, 1,
         out["solar"].append(float(env.cluster.houses[0].current_solar_gain))
         od.append(env.cluster.current_OD_temp)
         S.append(float(env.power_grid.current_signal))
+        base_power.append(float(env.power_grid.base_power))
         assert not any(done.values())
         if (t + 1) in want_norm:
             norm.append(np.array([ref["utils"].normStateDict(obs[i], cfg) for i in range(N)]))
@@ -154,6 +185,9 @@ def run_scenario(name, patches, seed, T, policy, perlin=False, norm_steps=(0, 1,
     comm = env.cluster.agent_communicators
     if comm and all(len(comm[i]) == len(comm[0]) for i in range(N)):
         arrays["links"] = np.array([comm[i] for i in range(N)], dtype=np.int32).reshape(N, -1)
+    if extra:
+        arrays.update(extra)
+        arrays["base_power"] = np.array(base_power, dtype=np.float64)
     arrays["meta"] = np.array(json.dumps(meta))
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **arrays)
@@ -245,6 +279,18 @@ def main():
                                            PG + "signal_mode": "flat"}, 83, 30, "mixed", norm_steps=(0, 5, -1))
     run_scenario("s11_comm_no_message", {CL + "nb_agents": 6, CL + "agents_comm_mode": "no_message",
                                          PG + "signal_mode": "flat"}, 84, 30, "mixed", norm_steps=(0, 5, -1))
+    # S12: base_power_mode "interpolation" (the reference's DEFAULT, env 1195-1255) on a small synthetic grid
+    gp, gx = make_small_grid(5)
+    run_scenario("s12_interp_default_like", dict(gp, **{
+        CL + "nb_agents": 12, "noise_house_prop.noise_mode": "small_noise", "noise_hvac_prop.noise_mode": "big_noise",
+        PG + "signal_mode": "sinusoidals"}), 91, 200, "mixed", extra=gx)
+    run_scenario("s12_interp_no_solar_dt7", dict(gp, **{
+        CL + "nb_agents": 9, "noise_house_prop.noise_mode": "house_small_noise", "default_house_prop.solar_gain_bool": False,
+        "default_env_prop.time_step": 7, PG + "signal_mode": "flat"}), 92, 120, "mixed", extra=gx)
+    run_scenario("s12_interp_perlin_noon", dict(gp, **{
+        CL + "nb_agents": 16, "noise_house_prop.noise_mode": "big_noise", "default_env_prop.start_datetime_mode": "fixed",
+        "default_env_prop.start_datetime": "2021-06-20 07:20:00", PG + "signal_mode": "perlin"}), 93, 180, "bangbang",
+        perlin=True, extra=gx)
     # N == 1 (config.py's literal default nb_agents) and no neighbours
     run_scenario("s9_single_house", {CL + "nb_agents": 1, PG + "signal_mode": "sinusoidals"}, 61, 200, "bangbang")
 

@@ -9,7 +9,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "s*.npz")))
 
 
 def _intkeys(cfg):
@@ -41,6 +41,13 @@ class Golden:
         p["phase"] = np.array([a["p_phase"]], dtype=np.float64)
         p["ratio"] = np.array([a["p_ratio"]], dtype=np.float64)
         return p
+
+    def interp_grid(self):
+        """(values, axes dict) of the synthetic base-power grid of an interpolation-mode fixture, or None."""
+        if "interp_grid_file" not in self.a:
+            return None
+        z = np.load(os.path.join(GOLDEN_DIR, str(self.a["interp_grid_file"])), allow_pickle=False)
+        return z["values"].astype(np.float64), json.loads(str(z["axes"]))
 
     def od_table(self):
         return self.a["od"][:, None]       # [T+1, E=1]

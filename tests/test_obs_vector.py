@@ -11,6 +11,8 @@ from tests import golden_util as gu
 def _replay(g):
     env = mo.OracleEnv(g.config, nb_envs=1)
     env.seed, env.episode = g.seed, 0
+    if g.interp_grid() is not None:
+        env.interp_grid = mo.InterpGrid(*g.interp_grid())
     env.load_episode(g.params(), od_table=g.od_table())
     return env
 

@@ -13,6 +13,8 @@ def test_c_port_reproduces_reference(name):
     a = g.a
     ora = mo.OracleEnv(g.config, nb_envs=1)
     ora.seed, ora.episode = g.seed, 0
+    if g.interp_grid() is not None:
+        ora.interp_grid = mo.InterpGrid(*g.interp_grid())
     ora.load_episode(g.params(), od_table=g.od_table())
     port = c_port.CPort(ora)
     for t in range(g.T):

@@ -11,6 +11,8 @@ from tests import golden_util as gu
 def replay(g, use_perlin_seed=True):
     env = mo.OracleEnv(g.config, nb_envs=1)
     env.seed, env.episode = g.seed, 0        # selects the Perlin lattice the fixture was made with
+    if g.interp_grid() is not None:
+        env.interp_grid = mo.InterpGrid(*g.interp_grid())
     env.load_episode(g.params(), od_table=g.od_table())
     return env
 
@@ -34,6 +36,8 @@ def test_oracle_reproduces_reference(name):
         np.testing.assert_allclose(env.Tm[0], a["Tm"][t], rtol=1e-10, atol=0)
         np.testing.assert_allclose(r[0], a["reward"][t], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(env.S[0], a["S"][t + 1], rtol=1e-11, atol=1e-8)
+        if "base_power" in a:
+            np.testing.assert_allclose(env.base_power[0], a["base_power"][t + 1], rtol=1e-11)
         worst["Ta"] = max(worst["Ta"], float(np.max(np.abs(env.Ta[0] / a["Ta"][t] - 1))))
     assert worst["Ta"] < 1e-10
 
