@@ -32,6 +32,8 @@ extern "C" {
 #define MDR_MAX_SINUSOIDS 8
 #define MDR_MAX_CAPACITIES 16
 #define MDR_OBS_COLUMNS 7
+#define MDR_INTERP_AXES 10
+#define MDR_INTERP_MAX_AXIS 16
 
 typedef struct mdr_env mdr_env_t; /* opaque handle */
 
@@ -109,7 +111,8 @@ typedef struct mdr_config {
   double norm_temp_penalty;        /* deadbandL2(T0, 0, T0+1), env 346-350 */
   double norm_sig_penalty;         /* deadbandL2(R, 0, 0.75 R), env 352-356 */
   int32_t penalty_mode;            /* mdr_penalty_mode */
-  int32_t reserved0;
+  int32_t base_power_mode;         /* 0 = "constant" (avg_power_per_hvac * nb_agents, env 1249);
+                                      1 = "interpolation" (env 1250-1255): needs mdr_env_set_interp_grid */
   double mix_ind_L2, mix_common_L2, mix_common_max;
   /* normStateDict: reg_signal and cluster_hvac_power are divided by norm_reg_sig * nb_agents (utils.py:832-841) */
   double obs_power_norm;
@@ -146,6 +149,7 @@ typedef struct mdr_buffers {
   double *tab_signal;              /* regulation signal, W */
   /* scratch for the split (multi-workgroup per env) path: [E][mdr_partials_per_env()][3] */
   double *partials;
+  double *base_power;              /* [E] PowerGrid.base_power (written in interpolation mode) */
 } mdr_buffers_t;
 
 /* Raw episode parameters for mdr_env_load_episode (replay of an episode sampled elsewhere).
@@ -206,6 +210,24 @@ int mdr_env_load_episode(mdr_env_t *env, const mdr_episode_t *episode, uint64_t 
 /* Optional: replace the modelled outdoor temperature by a table, double [rows][E] deg C (row = time index);
  * NULL restores the model.  Takes effect at the next mdr_env_begin_episode / table refill. */
 int mdr_env_set_od_table(mdr_env_t *env, const double *od_table, int64_t rows);
+/* The 10-D bang-bang average-power grid of monteCarlo/ (PowerInterpolator, monteCarlo/interpolation.py:21-47).
+ * Axis order is the reference's interp_dict_keys.csv: Ua_ratio, Cm_ratio, Ca_ratio, Hm_ratio, air_temp, mass_temp,
+ * OD_temp, HVAC_power, hour (seconds), date (days).  `values` is device memory, C order over the axes. */
+typedef struct mdr_interp_grid {
+  uint32_t struct_size;
+  int32_t update_period;           /* interp_update_period, seconds (config.py:347) */
+  int32_t nb_agents;               /* interp_nb_agents: at most this many houses are evaluated per update (config.py:348) */
+  int32_t reserved0;
+  const double *values;
+  int32_t dims[MDR_INTERP_AXES];
+  double axes[MDR_INTERP_AXES][MDR_INTERP_MAX_AXIS];
+} mdr_interp_grid_t;
+/* Required before reset/load_episode when config.base_power_mode == 1.  PowerGrid.interpolatePower (env 1195-1234)
+ * then runs on the device every ceil(update_period / time_step) steps: per house nearest grid value in the four
+ * thermal ratios and HVAC power, 5-D multilinear in (air, mass, OD temperature minus target, hour, date) after
+ * clipping (utils.clipInterpolationPoint), summed over all houses (or nb_agents sampled ones, scaled). */
+int mdr_env_set_interp_grid(mdr_env_t *env, const mdr_interp_grid_t *grid);
+
 /* build_environment, part 2 (env 125-133): with max_power[E] final (all-reduced by the caller when houses
  * are sharded), build the time tables from time index 0: OD temp (env 793), initial signal (env 133). */
 int mdr_env_begin_episode(mdr_env_t *env, void *stream);

@@ -49,7 +49,7 @@ class MdrConfig(C.Structure):
         ("artificial_ratio", C.c_double), ("artificial_signal_ratio_range", C.c_double),
         ("alpha_temp", C.c_double), ("alpha_sig", C.c_double),
         ("norm_temp_penalty", C.c_double), ("norm_sig_penalty", C.c_double),
-        ("penalty_mode", C.c_int32), ("reserved0", C.c_int32),
+        ("penalty_mode", C.c_int32), ("base_power_mode", C.c_int32),
         ("mix_ind_L2", C.c_double), ("mix_common_L2", C.c_double), ("mix_common_max", C.c_double),
         ("obs_power_norm", C.c_double),
     ]
@@ -68,7 +68,7 @@ class MdrBuffers(C.Structure):
         ("t0", _i64p), ("phase", _f64p), ("ratio", _f64p), ("max_power", _f64p),
         ("P", _f64p), ("tot_sum", _f64p), ("tot_max", _f64p),
         ("tab_od", _f32p), ("tab_solar", _f32p), ("tab_signal", _f64p),
-        ("partials", _f64p),
+        ("partials", _f64p), ("base_power", _f64p),
     ]
 
 
@@ -97,6 +97,18 @@ class MdrObsSpec(C.Structure):
     ]
 
 
+MDR_INTERP_AXES, MDR_INTERP_MAX_AXIS = 10, 16
+
+
+class MdrInterpGrid(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("update_period", C.c_int32), ("nb_agents", C.c_int32), ("reserved0", C.c_int32),
+        ("values", _f64p),
+        ("dims", C.c_int32 * MDR_INTERP_AXES),
+        ("axes", (C.c_double * MDR_INTERP_MAX_AXIS) * MDR_INTERP_AXES),
+    ]
+
+
 class MdrRolloutOut(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("reserved0", C.c_uint32),
@@ -109,7 +121,7 @@ OBS_PLANES, OBS_ROWS = 0, 1
 EXPORTS = (
     "mdr_abi_version", "mdr_status_string", "mdr_last_error", "mdr_partials_per_env",
     "mdr_env_create", "mdr_env_destroy", "mdr_env_bind", "mdr_env_reset", "mdr_env_load_episode",
-    "mdr_env_set_od_table", "mdr_env_begin_episode", "mdr_env_step", "mdr_env_rollout", "mdr_env_rollout_fused",
+    "mdr_env_set_od_table", "mdr_env_set_interp_grid", "mdr_env_begin_episode", "mdr_env_step", "mdr_env_rollout", "mdr_env_rollout_fused",
     "mdr_env_step_begin", "mdr_env_step_end", "mdr_obs_vector_length", "mdr_env_obs_vector",
     "mdr_env_cursor", "mdr_env_set_cursor",
 )
@@ -143,6 +155,7 @@ def load():
         "mdr_env_reset": (C.c_int, [vp, u64, u32, vp]),
         "mdr_env_load_episode": (C.c_int, [vp, C.POINTER(MdrEpisode), u64, u32, vp]),
         "mdr_env_set_od_table": (C.c_int, [vp, vp, i64]),
+        "mdr_env_set_interp_grid": (C.c_int, [vp, C.POINTER(MdrInterpGrid)]),
         "mdr_env_begin_episode": (C.c_int, [vp, vp]),
         "mdr_env_step": (C.c_int, [vp, vp, C.c_int, vp]),
         "mdr_env_rollout": (C.c_int, [vp, vp, C.c_int, i32, vp]),

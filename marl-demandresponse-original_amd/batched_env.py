@@ -43,7 +43,7 @@ class BatchedDemandResponseEnv:
     def __init__(self, config: dict, nb_envs: int = 1, device=None, seed: int = 0, test: bool = False,
                  table_steps: int = 64, env_offset: int = 0,
                  house_shard: Optional[Tuple[int, int]] = None, process_group=None,
-                 stagger_bytes: int = 2304):
+                 stagger_bytes: int = 2304, interp_grid=None):
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedDemandResponseEnv needs a ROCm device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -59,6 +59,8 @@ class BatchedDemandResponseEnv:
         self.process_group = process_group
         self.env_offset = int(env_offset)
         self.table_steps = int(table_steps)
+        if self.spec.base_power_mode == 1:   # tables are rebuilt at every interpolatePower call (env 1250-1255)
+            self.table_steps = max(self.table_steps, -(-self.spec.interp_update_period // self.spec.time_step))
         self.seed = int(seed)
         self.episode = -1
         self._od_table = None
@@ -74,6 +76,8 @@ class BatchedDemandResponseEnv:
             raise
         self._allocate()
         self._bind()
+        if self.spec.base_power_mode == 1:
+            self._install_interp_grid(interp_grid)
         self.done = torch.zeros((self.nb_envs, self.nb_houses), dtype=torch.bool, device=self.device)
 
     # ------------------------------------------------------------------ setup
@@ -104,6 +108,7 @@ class BatchedDemandResponseEnv:
             c.capacity_list[i] = v
         if len(s.sin_periods) > nat.MDR_MAX_SINUSOIDS:
             raise ValueError("more than %d sinusoids" % nat.MDR_MAX_SINUSOIDS)
+        c.base_power_mode = s.base_power_mode
         c.nb_sinusoids = len(s.sin_periods)
         for i, (p, r) in enumerate(zip(s.sin_periods, s.sin_amplitude_ratios)):
             c.sin_periods[i], c.sin_amplitude_ratios[i] = p, r
@@ -116,7 +121,7 @@ class BatchedDemandResponseEnv:
         items += [(n, torch.int32, (E, N)) for n in _HOUSE_I32]
         items += [(n, torch.uint8, (E, N)) for n in _HOUSE_U8]
         items += [("obs", torch.float32, (nat.MDR_OBS_COLUMNS, E, N))]
-        items += [("t0", torch.int64, (E,))] + [(n, torch.float64, (E,)) for n in ("phase", "ratio", "max_power", "P", "tot_max")]
+        items += [("t0", torch.int64, (E,))] + [(n, torch.float64, (E,)) for n in ("phase", "ratio", "max_power", "P", "tot_max", "base_power")]
         items += [("tot_sum", torch.float64, (2, E))]
         items += [("tab_od", torch.float32, (K1, E)), ("tab_solar", torch.float32, (K1, E)), ("tab_signal", torch.float64, (K1, E))]
         items += [("partials", torch.float64, (E, nblk, 3))]
@@ -147,6 +152,30 @@ class BatchedDemandResponseEnv:
             setattr(b, fname, self.t[fname].data_ptr())
         self._buffers = b
         nat.check(self._lib, self._handle, self._lib.mdr_env_bind(self._handle, C.byref(b)), "mdr_env_bind")
+
+    def _install_interp_grid(self, interp_grid):
+        """PowerGrid.__init__ in interpolation mode (env 1130-1165): load the grid and hand it to the library."""
+        from .config import INTERP_KEYS, load_interp_grid
+        values, axes = interp_grid if interp_grid is not None else load_interp_grid(self.spec.interp_paths)
+        if tuple(axes.keys()) != INTERP_KEYS:
+            raise ValueError("interpolation grid axes must be " + ", ".join(INTERP_KEYS))
+        dims = [len(axes[k]) for k in INTERP_KEYS]
+        values = np.ascontiguousarray(np.asarray(values, dtype=np.float64).reshape(-1))
+        if values.size != int(np.prod(dims)):
+            raise ValueError("interpolation grid has %d values, axes imply %d" % (values.size, int(np.prod(dims))))
+        if max(dims) > nat.MDR_INTERP_MAX_AXIS:
+            raise ValueError("interpolation axes longer than %d" % nat.MDR_INTERP_MAX_AXIS)
+        self._interp_values = torch.from_numpy(values).to(self.device)
+        g = nat.MdrInterpGrid()
+        g.struct_size = C.sizeof(nat.MdrInterpGrid)
+        g.update_period, g.nb_agents = self.spec.interp_update_period, self.spec.interp_nb_agents
+        g.values = self._interp_values.data_ptr()
+        for d, k in enumerate(INTERP_KEYS):
+            g.dims[d] = dims[d]
+            for i, v in enumerate(axes[k]):
+                g.axes[d][i] = float(v)
+        self._interp_grid_host = (values, {k: list(axes[k]) for k in INTERP_KEYS})
+        nat.check(self._lib, self._handle, self._lib.mdr_env_set_interp_grid(self._handle, C.byref(g)), "mdr_env_set_interp_grid")
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -450,7 +479,8 @@ class BatchedDemandResponseEnv:
                                          seed=self.seed, test=self.test, table_steps=self.table_steps,
                                          env_offset=self.env_offset,
                                          house_shard=(self.house_offset, self.nb_houses) if self.sharded else None,
-                                         process_group=self.process_group, stagger_bytes=self._stagger)
+                                         process_group=self.process_group, stagger_bytes=self._stagger,
+                                         interp_grid=getattr(self, "_interp_grid_host", None))
         if self.episode >= 0:
             other.load_state_dict(self.state_dict())
         return other

@@ -219,6 +219,10 @@ class EnvSpec:
     nb_agents_comm: int
     agents_comm_mode: str
     comm_defect_prob: float
+    base_power_mode: int = 0           # 0 constant, 1 interpolation (env 1248-1255)
+    interp_update_period: int = 300
+    interp_nb_agents: int = 100
+    interp_paths: dict = field(default_factory=dict)
     state_properties: dict = field(default_factory=dict)
     message_properties: dict = field(default_factory=dict)
 
@@ -252,10 +256,7 @@ def flatten_config(config: dict, test: bool = False) -> EnvSpec:
         raise ValueError("start_datetime_mode in default_env_prop in config.py must be random or fixed. "
                          "Current value: {}.".format(env["start_datetime_mode"]))
     base_mode = grid["base_power_mode"]
-    if base_mode == "interpolation":
-        raise ValueError("base_power_mode 'interpolation' needs monteCarlo/mergedGridSearchResultFinal.npy, which the "
-                         "reference does not ship; use base_power_mode='constant' (as monteCarlo.py:173 does).")
-    if base_mode != "constant":
+    if base_mode not in ("constant", "interpolation"):
         raise ValueError("The base_power_mode parameter in the config file can only be 'constant' or 'interpolation'. "
                          "It is currently: {}".format(base_mode))
     mode = grid["signal_mode"]
@@ -321,5 +322,42 @@ def flatten_config(config: dict, test: bool = False) -> EnvSpec:
         norm_reg_sig=norm_reg, obs_power_norm=norm_reg * int(cluster["nb_agents"]),   # utils.py:832-841
         nb_agents_comm=int(cluster["nb_agents_comm"]), agents_comm_mode=cluster["agents_comm_mode"],
         comm_defect_prob=float(cluster["comm_defect_prob"]),
+        base_power_mode=1 if base_mode == "interpolation" else 0,
+        interp_update_period=int(grid["base_power_parameters"].get("interpolation", {}).get("interp_update_period", 300)),
+        interp_nb_agents=int(grid["base_power_parameters"].get("interpolation", {}).get("interp_nb_agents", 100)),
+        interp_paths={k: v for k, v in grid["base_power_parameters"].get("interpolation", {}).items() if k.startswith("path_")},
         state_properties=dict(env["state_properties"]), message_properties=dict(env["message_properties"]),
     )
+
+
+INTERP_KEYS = ("Ua_ratio", "Cm_ratio", "Ca_ratio", "Hm_ratio", "air_temp", "mass_temp", "OD_temp", "HVAC_power", "hour", "date")
+
+
+class InterpolationGridMissing(FileNotFoundError):
+    pass
+
+
+def load_interp_grid(paths: dict):
+    """Read the base-power grid the way PowerGrid.__init__ / PowerInterpolator.__init__ do (env 1130-1150;
+    monteCarlo/interpolation.py:21-47): a flat .npy, the JSON of axis values and the CSV with the axis order, at the
+    paths given in config (relative to the current directory, like the reference).  Returns (values, axes dict)."""
+    import csv
+    import json
+    import os
+
+    import numpy as np
+    data, pdict, keys = paths.get("path_datafile"), paths.get("path_parameter_dict"), paths.get("path_dict_keys")
+    for p in (data, pdict, keys):
+        if not p or not os.path.isfile(p):
+            raise InterpolationGridMissing(
+                "base_power_mode='interpolation' needs the bang-bang average-power grid (%r). The reference does not ship "
+                "monteCarlo/mergedGridSearchResultFinal.npy; regenerate it on the GPU with "
+                "`python tools/regenerate_interp_grid.py`, pass interp_grid=(values, axes), or set base_power_mode='constant'." % p)
+    with open(pdict) as f:
+        axes = json.load(f)
+    with open(keys) as f:
+        order = list(csv.reader(f))[0]
+    if tuple(order) != INTERP_KEYS:
+        raise ValueError("interpolation grid axes must be %s, got %s" % (", ".join(INTERP_KEYS), order))
+    values = np.load(data, allow_pickle=False)
+    return values, {k: axes[k] for k in order}

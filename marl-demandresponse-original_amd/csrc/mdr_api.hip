@@ -24,6 +24,9 @@ struct mdr_env {
   int64_t od_ext_rows = 0;
   mdr::StepPlan plan;
   int64_t nblk = 1;
+  mdr_interp_grid_t interp{};   // base_power_mode == 1
+  bool has_interp = false;
+  int64_t interp_steps = 0;     // U: env steps between two interpolatePower calls = ceil(update_period / time_step)
   std::string err;
 };
 
@@ -75,6 +78,9 @@ std::string validate(const mdr_config_t& c) {
     return "Unknown temperature penalty mode";
   if (c.penalty_mode == MDR_PENALTY_MIXTURE && !(c.mix_ind_L2 + c.mix_common_L2 + c.mix_common_max != 0.0))
     return "mixture weights sum to zero";
+  if (c.base_power_mode != 0 && c.base_power_mode != 1) return "base_power_mode can only be 0 (constant) or 1 (interpolation)";
+  if (c.base_power_mode == 1 && c.nb_houses_total != c.nb_houses)
+    return "base_power_mode interpolation is not available for sharded houses";
   if (!(c.norm_temp_penalty > 0.0) || !(c.norm_sig_penalty > 0.0) || !(c.obs_power_norm > 0.0))
     return "normalisation constants must be positive";
   if ((int64_t)c.nb_envs * (int64_t)c.nb_houses > (int64_t)1 << 40) return "E * N too large";
@@ -167,6 +173,7 @@ int fill_tables(mdr_env* env, int64_t j0, hipStream_t s) {
   t.area_shading = c.window_area * c.shading_coeff;
   t.n_total = c.nb_houses_total;
   t.avg_power_per_hvac = c.avg_power_per_hvac;
+  t.base_power = c.base_power_mode == 1 ? env->buf.base_power : nullptr;
   t.signal_mode = c.signal_mode;
   t.nb_sin = c.nb_sinusoids;
   t.perlin_octaves = c.perlin_nb_octaves;
@@ -184,6 +191,40 @@ int fill_tables(mdr_env* env, int64_t j0, hipStream_t s) {
   env->j0 = j0;
   return MDR_OK;
 }
+
+
+// PowerGrid.step in interpolation mode (env 1250-1255) at time index j: the outdoor temperature row has to exist
+// before interpolatePower can read it, and the signal rows need the new base power, hence fill - interpolate - fill.
+int refresh_interp(mdr_env* env, int64_t j, hipStream_t s) {
+  const mdr_config_t& c = env->cfg;
+  int rc = fill_tables(env, j, s);
+  if (rc != MDR_OK) return rc;
+  mdr::InterpArgs a{};
+  a.values = env->interp.values;
+  for (int d = 0; d < MDR_INTERP_AXES; ++d) {
+    a.dims[d] = env->interp.dims[d];
+    for (int i = 0; i < MDR_INTERP_MAX_AXIS; ++i) a.axes[d][i] = env->interp.axes[d][i];
+  }
+  const mdr_buffers_t& b = env->buf;
+  a.Ta = b.Ta; a.Tm = b.Tm; a.target = b.target; a.Ua = b.Ua; a.Cm = b.Cm; a.Ca = b.Ca; a.Hm = b.Hm; a.capacity = b.capacity;
+  a.od_now = b.tab_od;   // row 0 == time index j
+  a.t0 = b.t0;
+  a.base_power = b.base_power;
+  a.E = c.nb_envs; a.N = c.nb_houses; a.dt = c.time_step; a.nb_agents = env->interp.nb_agents; a.solar_on = c.solar_gain;
+  a.j = j;
+  a.env_offset = c.env_offset;
+  a.k0 = (uint32_t)(env->seed & 0xFFFFFFFFull); a.k1 = (uint32_t)(env->seed >> 32); a.episode = env->episode;
+  a.def_Ua = c.Ua; a.def_Cm = c.Cm; a.def_Ca = c.Ca; a.def_Hm = c.Hm;
+  hipError_t e = mdr::launch_interp_base(a, s);
+  if (e != hipSuccess) return hip_fail(env, e, "interp_base");
+  return fill_tables(env, j, s);
+}
+
+bool interp_mode(const mdr_env* env) { return env->cfg.base_power_mode == 1; }
+
+// Called after a step that brought the cursor onto an interpolation update: new base power, new tables from the
+// current time index, and the reg_signal observation plane of the step just taken re-written with the final signal.
+int interp_boundary(mdr_env* env, hipStream_t s, double* sq_signal_error_sum);
 
 // Builds the argument block of step k -> k+1, refilling the time tables when the cursor leaves them.
 int step_args(mdr_env* env, uint8_t* actions, int action_source, hipStream_t s, mdr::StepArgs* out) {
@@ -227,6 +268,22 @@ int step_args(mdr_env* env, uint8_t* actions, int action_source, hipStream_t s, 
   a.inv_n_total = 1.0 / (double)c.nb_houses_total;
   a.inv_obs_norm = 1.0 / c.obs_power_norm;
   *out = a;
+  return MDR_OK;
+}
+
+int interp_boundary(mdr_env* env, hipStream_t s, double* sq_signal_error_sum) {
+  if (!interp_mode(env) || env->k % env->interp_steps != 0) return MDR_OK;
+  int rc = refresh_interp(env, env->k, s);
+  if (rc != MDR_OK) return rc;
+  mdr::StepArgs a;
+  rc = step_args(env, nullptr, MDR_ACTIONS_BANGBANG, s, &a);   // sig_old == row 0 == the signal of the current time index
+  if (rc != MDR_OK) return rc;
+  hipError_t e = mdr::launch_patch_signal_plane(a, s);
+  if (e != hipSuccess) return hip_fail(env, e, "patch_signal_plane");
+  if (sq_signal_error_sum) {
+    e = mdr::launch_signal_error(a, sq_signal_error_sum, s);
+    if (e != hipSuccess) return hip_fail(env, e, "signal_error");
+  }
   return MDR_OK;
 }
 
@@ -322,11 +379,34 @@ int mdr_env_set_od_table(mdr_env_t* env, const double* od_table, int64_t rows) {
   return MDR_OK;
 }
 
+int mdr_env_set_interp_grid(mdr_env_t* env, const mdr_interp_grid_t* grid) {
+  if (!env || !grid) return MDR_ERR_INVALID;
+  if (grid->struct_size != sizeof(mdr_interp_grid_t)) return fail(env, MDR_ERR_INVALID, "mdr_interp_grid_t size mismatch (ABI)");
+  if (!grid->values) return fail(env, MDR_ERR_INVALID, "interpolation grid values is NULL");
+  if (grid->update_period < 1 || grid->nb_agents < 1) return fail(env, MDR_ERR_INVALID, "interp_update_period and interp_nb_agents must be >= 1");
+  for (int d = 0; d < MDR_INTERP_AXES; ++d) {
+    const bool linear = !(d < 4 || d == 7);
+    if (grid->dims[d] < (linear ? 2 : 1) || grid->dims[d] > MDR_INTERP_MAX_AXIS) return fail(env, MDR_ERR_INVALID, "interpolation axis length out of range");
+    for (int i = 1; i < grid->dims[d]; ++i)
+      if (!(grid->axes[d][i] > grid->axes[d][i - 1])) return fail(env, MDR_ERR_INVALID, "interpolation axes must be strictly ascending");
+  }
+  env->interp = *grid;
+  env->has_interp = true;
+  env->interp_steps = (grid->update_period + env->cfg.time_step - 1) / env->cfg.time_step;
+  if (env->cfg.table_steps < env->interp_steps)
+    return fail(env, MDR_ERR_INVALID, "table_steps must be >= ceil(interp_update_period / time_step) in interpolation mode");
+  return MDR_OK;
+}
+
 int mdr_env_begin_episode(mdr_env_t* env, void* stream) {
   if (!env) return MDR_ERR_INVALID;
   if (!env->bound || !env->has_episode) return fail(env, MDR_ERR_UNBOUND, "call reset or load_episode first");
+  if (interp_mode(env)) {
+    if (!env->has_interp) return fail(env, MDR_ERR_UNBOUND, "base_power_mode interpolation: call mdr_env_set_interp_grid first");
+    if (!env->buf.base_power) return fail(env, MDR_ERR_UNBOUND, "buffer 'base_power' is NULL");
+  }
   env->k = 0;
-  int rc = fill_tables(env, 0, (hipStream_t)stream);
+  int rc = interp_mode(env) ? refresh_interp(env, 0, (hipStream_t)stream) : fill_tables(env, 0, (hipStream_t)stream);
   if (rc != MDR_OK) return rc;
   env->has_tables = true;
   mdr::StepArgs a;
@@ -348,7 +428,7 @@ int mdr_env_step(mdr_env_t* env, uint8_t* actions, int action_source, void* stre
   hipError_t e = mdr::launch_step(a, env->plan, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "step");
   env->k += 1;
-  return MDR_OK;
+  return interp_boundary(env, (hipStream_t)stream, nullptr);
 }
 
 int mdr_env_rollout(mdr_env_t* env, uint8_t* actions, int action_source, int32_t nb_steps, void* stream) {
@@ -374,9 +454,11 @@ int mdr_env_rollout_fused(mdr_env_t* env, uint8_t* actions, int32_t nb_steps, co
     mdr::StepArgs a;
     int rc = step_args(env, actions, MDR_ACTIONS_BANGBANG, (hipStream_t)stream, &a);   // refills the tables if the cursor left them
     if (rc != MDR_OK) return rc;
-    const int64_t room = env->cfg.table_steps - (env->k - env->j0);   // steps the current tables still cover
+    int64_t room = env->cfg.table_steps - (env->k - env->j0);   // steps the current tables still cover
+    if (interp_mode(env)) room = std::min<int64_t>(room, env->interp_steps - (env->k - env->j0));   // stop at the next update
     mdr::RolloutArgs r{};
     r.nsteps = (int)std::min<int64_t>(room, nb_steps - done);
+    r.defer_last_signal_error = interp_mode(env) && ((env->k + r.nsteps) % env->interp_steps == 0);
     if (out) {
       r.power_trace = out->power_trace ? out->power_trace + (int64_t)done * E : nullptr;
       r.reward_sum = out->reward_sum;
@@ -387,6 +469,8 @@ int mdr_env_rollout_fused(mdr_env_t* env, uint8_t* actions, int32_t nb_steps, co
     if (e != hipSuccess) return hip_fail(env, e, "rollout_fused");
     env->k += r.nsteps;
     done += r.nsteps;
+    rc = interp_boundary(env, (hipStream_t)stream, out ? out->sq_signal_error_sum : nullptr);
+    if (rc != MDR_OK) return rc;
   }
   return MDR_OK;
 }

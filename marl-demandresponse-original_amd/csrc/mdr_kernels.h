@@ -46,10 +46,27 @@ struct TableArgs {
   double area_shading;
   int64_t n_total;
   double avg_power_per_hvac;
+  const double* base_power;   // [E] per-env base power (interpolation mode) or nullptr (constant mode)
   int signal_mode, nb_sin, perlin_octaves;
   double sin_periods[MDR_MAX_SINUSOIDS], sin_ratios[MDR_MAX_SINUSOIDS];
   double steps_amp, steps_period;
   double perlin_amp, perlin_step, perlin_period;
+};
+
+// PowerGrid.interpolatePower on the device (k_interp_base)
+struct InterpArgs {
+  const double* values;
+  int dims[MDR_INTERP_AXES];
+  double axes[MDR_INTERP_AXES][MDR_INTERP_MAX_AXIS];
+  const float *Ta, *Tm, *target, *Ua, *Cm, *Ca, *Hm, *capacity;
+  const float* od_now;      // table row of the current time index (OD temp minus temp_ref)
+  const int64_t* t0;
+  double* base_power;       // [E] out
+  int E, N, dt, nb_agents, solar_on;
+  int64_t j;                // time index of the update
+  int64_t env_offset;
+  uint32_t k0, k1, episode;
+  double def_Ua, def_Cm, def_Ca, def_Hm;
 };
 
 // One env step
@@ -106,6 +123,7 @@ struct RolloutArgs {
   double* sq_temp_error_sum;
   double* sq_signal_error_sum;
   int nsteps;
+  int defer_last_signal_error;   // the last step's reg_signal is not final yet (interpolation update due): the host adds it
 };
 
 enum StepKind { STEP_FUSED = 0, STEP_GROUP = 1, STEP_SPLIT = 2 };
@@ -119,6 +137,9 @@ int64_t split_blocks(int N);
 hipError_t launch_sample(const EpisodeArgs& a, hipStream_t s);
 hipError_t launch_load(const EpisodeArgs& a, const mdr_episode_t& ep, hipStream_t s);
 hipError_t launch_tables(const TableArgs& a, hipStream_t s);
+hipError_t launch_interp_base(const InterpArgs& a, hipStream_t s);
+hipError_t launch_patch_signal_plane(const StepArgs& a, hipStream_t s);   // obs plane 5 <- sig_old row
+hipError_t launch_signal_error(const StepArgs& a, double* sq_signal_error_sum, hipStream_t s);   // += (sig_old - P)^2
 hipError_t launch_reset_obs(const StepArgs& a, hipStream_t s);  // uses sig_old = table row 0
 hipError_t launch_step(const StepArgs& a, const StepPlan& p, hipStream_t s);
 bool rollout_fused_supported(const StepPlan& p);

@@ -119,6 +119,103 @@ __global__ __launch_bounds__(256) void k_reset_obs(StepArgs a) {
 }
 
 // =================================================================================================
+// Interpolated base power: PowerGrid.interpolatePower (env 1195-1234) + PowerInterpolator.interpolateGridFast
+// (monteCarlo/interpolation.py:113-142).  One workgroup per env; thread q evaluates sampled house q.
+// =================================================================================================
+__device__ __forceinline__ int nearest_index(const double* ax, int n, double v) {   // np.argmin(|ax - v|): first minimum
+  int best = 0;
+  double bd = fabs(ax[0] - v);
+  for (int i = 1; i < n; ++i) {
+    const double d = fabs(ax[i] - v);
+    if (d < bd) {
+      bd = d;
+      best = i;
+    }
+  }
+  return best;
+}
+
+__global__ __launch_bounds__(128) void k_interp_base(InterpArgs a) {
+  __shared__ double lds[3 * 2];
+  const int e = blockIdx.x;
+  const int64_t base = (int64_t)e * a.N;
+  const bool all = a.N <= a.nb_agents;
+  const int count = all ? a.N : a.nb_agents;
+  const Civil c = civil_from_epoch(a.t0[e] + a.j * (int64_t)a.dt);
+  // env 1198-1207: tm_yday and seconds since midnight, or (0, 0) when the solar gain is not modelled
+  const double date = a.solar_on ? (double)c.yday : 0.0;
+  const double hour = a.solar_on ? (double)c.sod : 0.0;
+  // strides of the C-ordered grid
+  int64_t stride[MDR_INTERP_AXES];
+  stride[MDR_INTERP_AXES - 1] = 1;
+  for (int d = MDR_INTERP_AXES - 2; d >= 0; --d) stride[d] = stride[d + 1] * a.dims[d + 1];
+  double sum = 0.0;
+  for (int q = threadIdx.x; q < count; q += 128) {
+    int h = q;
+    if (!all) {   // random.choices(all_ids, k = interp_nb_agents), env 1214
+      const u32x4 r = philox4x32_10((uint32_t)(e + a.env_offset), (uint32_t)q, (uint32_t)a.j, TAG_INTERP | (a.episode << 8), a.k0, a.k1);
+      h = (int)mulhi_pick(r.x, (uint32_t)a.N);
+    }
+    const int64_t i = base + h;
+    const double tgt = (double)a.target[i];   // all temperatures here are relative to temp_ref: differences are unaffected
+    double p[MDR_INTERP_AXES];
+    p[0] = (double)a.Ua[i] / a.def_Ua;
+    p[1] = (double)a.Cm[i] / a.def_Cm;
+    p[2] = (double)a.Ca[i] / a.def_Ca;
+    p[3] = (double)a.Hm[i] / a.def_Hm;
+    p[4] = (double)a.Ta[i] - tgt;
+    p[5] = (double)a.Tm[i] - tgt;
+    p[6] = (double)a.od_now[e] - tgt;
+    p[7] = (double)a.capacity[i];
+    p[8] = hour;
+    p[9] = date;
+    int64_t off = 0;
+    int lo[5];
+    double w[5];
+    int nl = 0;
+#pragma unroll
+    for (int d = 0; d < MDR_INTERP_AXES; ++d) {
+      const double* ax = a.axes[d];
+      const int n = a.dims[d];
+      const double v = fmin(fmax(p[d], ax[0]), ax[n - 1]);   // utils.clipInterpolationPoint (axes are ascending)
+      if (d < 4 || d == 7) {
+        off += (int64_t)nearest_index(ax, n, v) * stride[d];
+      } else {   // interval index as scipy.interpolate.interpn: searchsorted(right) - 1 clipped to [0, n - 2]
+        int k = 0;
+        while (k < n - 2 && v >= ax[k + 1]) ++k;
+        lo[nl] = k;
+        w[nl] = (v - ax[k]) / (ax[k + 1] - ax[k]);
+        ++nl;
+      }
+    }
+    const int ld[5] = {4, 5, 6, 8, 9};
+    double acc = 0.0;
+    for (int corner = 0; corner < 32; ++corner) {
+      double weight = 1.0;
+      int64_t o = off;
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        const int up = (corner >> b) & 1;
+        weight *= up ? w[b] : 1.0 - w[b];
+        o += (int64_t)(lo[b] + up) * stride[ld[b]];
+      }
+      acc += weight * a.values[o];
+    }
+    sum += acc;
+  }
+  Red3 r{sum, 0.0, 0.0f};
+  r = block_reduce<128>(r, lds);
+  if (threadIdx.x == 0) a.base_power[e] = r.sum_p * (all ? 1.0 : (double)a.N / (double)a.nb_agents);
+}
+
+// obs plane 5 (reg_signal / norm) <- the freshly computed signal of the current time index (sig_old row)
+__global__ __launch_bounds__(256) void k_patch_signal_plane(StepArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.plane) return;
+  a.obs[5 * a.plane + i] = (float)(a.sig_old[i / a.N] * a.inv_obs_norm);
+}
+
+// =================================================================================================
 // Per-env time tables: outdoor temperature, solar gain, regulation signal for K+1 consecutive time
 // indices, in fp64, one thread per (row, env).  These are functions of (env, time) only - the step
 // kernel reads them as wave-uniform scalars.
@@ -148,8 +245,8 @@ __global__ __launch_bounds__(256) void k_fill_tables(TableArgs a) {
   // utils.house_solar_gain (utils.py:1277-1350); identical for every house of the env
   a.tab_solar[i] = a.solar_on ? (float)(a.area_shading * solar_cooling_load(c.hour, c.minute, c.month, c.day)) : 0.0f;
 
-  // PowerGrid.step (env 1236-1316), constant base power (env 1249)
-  const double base = a.avg_power_per_hvac * (double)a.n_total;
+  // PowerGrid.step (env 1236-1316): constant base power (env 1249) or the last interpolated one (env 1250-1255)
+  const double base = a.base_power ? a.base_power[e] : a.avg_power_per_hvac * (double)a.n_total;
   const double sod = (double)c.sod;
   double sig;
   if (a.signal_mode == MDR_SIGNAL_FLAT) {
@@ -554,7 +651,7 @@ __global__ __launch_bounds__(THREADS) void k_rollout_fused(StepArgs a, RolloutAr
     if (threadIdx.x == 0) {
       if (ro.power_trace) ro.power_trace[row] = tot.sum_p;
       const double d = er.sig_new - tot.sum_p;
-      serr += d * d;
+      if (!(ro.defer_last_signal_error && s == ro.nsteps - 1)) serr += d * d;
     }
   }
   if (ro.nsteps <= 0) return;
@@ -685,7 +782,7 @@ __global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs r
       if (lane == 0) {
         if (ro.power_trace) ro.power_trace[row] = tot.sum_p;
         const double d = er.sig_new - tot.sum_p;
-        serr += d * d;
+        if (!(ro.defer_last_signal_error && s == ro.nsteps - 1)) serr += d * d;
       }
     }
   }
@@ -1276,6 +1373,28 @@ hipError_t launch_load(const EpisodeArgs& a, const mdr_episode_t& ep, hipStream_
   hipLaunchKernelGGL(k_load_houses, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, ep);
   hipLaunchKernelGGL(k_load_envs, dim3((unsigned)((a.E + 255) / 256)), dim3(256), 0, s, a, ep);
   hipLaunchKernelGGL(k_env_max_power, dim3((unsigned)a.E), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_interp_base(const InterpArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_interp_base, dim3((unsigned)a.E), dim3(128), 0, s, a);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_signal_error(StepArgs a, double* acc) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.E) return;
+  const double d = a.sig_old[e] - a.P[e];
+  acc[e] += d * d;
+}
+
+hipError_t launch_signal_error(const StepArgs& a, double* acc, hipStream_t s) {
+  hipLaunchKernelGGL(k_signal_error, dim3((unsigned)((a.E + 255) / 256)), dim3(256), 0, s, a, acc);
+  return hipGetLastError();
+}
+
+hipError_t launch_patch_signal_plane(const StepArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_patch_signal_plane, dim3((unsigned)((a.plane + 255) / 256)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

@@ -106,13 +106,14 @@ class _GridView:
     current_signal = property(lambda self: float(self._env._host["S"]))
     max_power = property(lambda self: float(self._env._host["max_power"]))
     artificial_ratio = property(lambda self: float(self._env._host["ratio"]))
-    base_power = property(lambda self: self._env._batched.spec.avg_power_per_hvac * self._env.nb_agents)
+    base_power = property(lambda self: (self._env._batched.t["base_power"][0].item() if self._env._batched.spec.base_power_mode == 1
+                                        else self._env._batched.spec.avg_power_per_hvac * self._env.nb_agents))
 
 
 class MADemandResponseEnv:
     """Multi agent demand response environment (drop-in for env/MA_DemandResponse.py:37)."""
 
-    def __init__(self, config, test=False, device=None, seed=None, table_steps=64):
+    def __init__(self, config, test=False, device=None, seed=None, table_steps=64, interp_grid=None):
         self.test = test
         self.config = config
         self.default_env_prop = config["default_env_prop"]
@@ -122,7 +123,7 @@ class MADemandResponseEnv:
         self.noise_hvac_prop = config["noise_hvac_prop_test" if test else "noise_hvac_prop"]
         self._fixed_seed = seed
         self._batched = BatchedDemandResponseEnv(config, nb_envs=1, device=device, seed=0, test=test,
-                                                 table_steps=table_steps)
+                                                 table_steps=table_steps, interp_grid=interp_grid)
         self.nb_agents = self._batched.nb_agents
         self.agent_ids = list(range(self.nb_agents))
         self.time_step = _dt.timedelta(seconds=self._batched.spec.time_step)

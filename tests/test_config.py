@@ -29,7 +29,13 @@ def test_default_config_equals_reference_snapshot():
 
 def test_flatten_matches_reference_norms_and_modes():
     cfg = mdr_amd.default_config()
-    with pytest.raises(ValueError):        # default base_power_mode needs the missing interpolation grid
+    s = mdr_amd.flatten_config(cfg)        # the default base_power_mode is "interpolation" (config.py:326)
+    assert s.base_power_mode == 1 and s.interp_update_period == 300 and s.interp_nb_agents == 100
+    from mdr_amd.config import InterpolationGridMissing, load_interp_grid
+    with pytest.raises(InterpolationGridMissing):   # the grid blob is not shipped by the reference
+        load_interp_grid(s.interp_paths)
+    cfg["default_env_prop"]["power_grid_prop"]["base_power_mode"] = "cubic"
+    with pytest.raises(ValueError):
         mdr_amd.flatten_config(cfg)
     cfg["default_env_prop"]["power_grid_prop"]["base_power_mode"] = "constant"
     s = mdr_amd.flatten_config(cfg)

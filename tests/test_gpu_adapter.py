@@ -38,14 +38,14 @@ def norm_state_vector(s, cfg):
 
 def make_env(g):
     import mdr_amd
-    env = mdr_amd.MADemandResponseEnv(g.config, device="cuda:0", seed=g.seed)
+    env = mdr_amd.MADemandResponseEnv(g.config, device="cuda:0", seed=g.seed, interp_grid=g.interp_grid())
     p = {k: v[0] if v.ndim > 1 else v for k, v in g.params().items()}
     obs = env.load_episode({k: np.asarray(v)[None] if np.asarray(v).ndim == 1 and k not in ("t0", "phase", "ratio") else v
                             for k, v in p.items()}, od_table=g.od_table(), seed=g.seed)
     return env, obs
 
 
-@pytest.mark.parametrize("name", ["s1_c1_sinusoidals", "s3_c3_heterogeneous", "s9_single_house"])
+@pytest.mark.parametrize("name", ["s1_c1_sinusoidals", "s3_c3_heterogeneous", "s9_single_house", "s12_interp_default_like"])
 def test_dict_surface_matches_reference(name):
     g = gu.Golden(name)
     a = g.a
@@ -72,7 +72,7 @@ def test_dict_surface_matches_reference(name):
         assert [obs[i]["hvac_seconds_since_off"] for i in range(g.N)] == list(a["sso"][t])
         np.testing.assert_allclose([obs[i]["house_temp"] for i in range(g.N)], a["Ta"][t], rtol=1e-5)
         np.testing.assert_allclose([rew[i] for i in range(g.N)], a["reward"][t], rtol=1e-5, atol=1e-5)
-        assert obs[0]["reg_signal"] == pytest.approx(a["S"][t + 1], rel=1e-9)
+        assert obs[0]["reg_signal"] == pytest.approx(a["S"][t + 1], rel=3e-6 if g.interp_grid() else 1e-9)
         assert obs[0]["OD_temp"] == pytest.approx(a["od"][t + 1], abs=5e-6)
         assert obs[0]["house_solar_gain"] == pytest.approx(a["solar"][t], rel=1e-6, abs=1e-4)
         assert obs[0]["datetime"] == env.datetime == env.start_datetime + (t + 1) * env.time_step
@@ -83,7 +83,9 @@ def test_dict_surface_matches_reference(name):
     # neighbours are circular: floor(c/2) before, ceil(c/2) after (env 816-828)
     if g.N == 10:
         assert env.cluster.agent_communicators[1] == [7, 8, 9, 0, 2, 3, 4, 5, 6]
-    assert env.power_grid.current_signal == pytest.approx(a["S"][T], rel=1e-9)
+    assert env.power_grid.current_signal == pytest.approx(a["S"][T], rel=3e-6 if g.interp_grid() else 1e-9)
+    if g.interp_grid():
+        assert env.power_grid.base_power == pytest.approx(a["base_power"][T], rel=3e-6)
     assert env.cluster.houses[0].hvac.seconds_since_off == a["sso"][T - 1][0]
 
 

@@ -67,3 +67,24 @@ def test_fused_rollout_unsupported_shapes_fall_back():
     assert env.rollout_fused(20) is None       # split-path shape: plain rollout ran instead
     twin.rollout(20)
     assert torch.equal(env.t["Ta"], twin.t["Ta"]) and env.steps_taken == 20
+
+
+def test_fused_rollout_in_interpolation_mode():
+    """Chunks stop at every interpolatePower update (75 steps); the deferred signal-error term uses the final signal."""
+    import mdr_amd
+    from tests import golden_util as gu
+    grid = gu.Golden("s12_interp_default_like").interp_grid()
+    cfg = _cfg(256, **{"default_env_prop.power_grid_prop.base_power_mode": "interpolation",
+                       "default_env_prop.power_grid_prop.signal_mode": "perlin"})
+    a = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=6, device="cuda:0", seed=4, interp_grid=grid)
+    b = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=6, device="cuda:0", seed=4, interp_grid=grid)
+    a.reset(episode=0)
+    b.reset(episode=0)
+    res = a.rollout_fused(200)
+    serr = torch.zeros(6, dtype=torch.float64, device="cuda:0")
+    for t in range(200):
+        _, _, _, info = b.step_bangbang()
+        serr += (b.reg_signal() - info["cluster_hvac_power"]) ** 2
+    for k in ("Ta", "Tm", "sso", "flags", "reward", "obs", "P", "base_power", "tab_signal"):
+        assert torch.equal(a.t[k], b.t[k]), k
+    torch.testing.assert_close(res["sq_signal_error_sum"], serr, rtol=1e-12, atol=0)

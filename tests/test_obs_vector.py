@@ -41,7 +41,7 @@ def test_hip_obs_vector_matches_reference(name):
     import torch
     import mdr_amd
     g = gu.Golden(name)
-    env = mdr_amd.BatchedDemandResponseEnv(g.config, nb_envs=1, device="cuda:0", seed=g.seed)
+    env = mdr_amd.BatchedDemandResponseEnv(g.config, nb_envs=1, device="cuda:0", seed=g.seed, interp_grid=g.interp_grid())
     env.load_episode(g.params(), od_table=g.od_table(), seed=g.seed, episode=0)
     if "links" in g.a and g.config["default_env_prop"]["cluster_prop"]["agents_comm_mode"] == "random_fixed":
         env.set_comm_links(g.a["links"])
