@@ -43,7 +43,7 @@ class BatchedDemandResponseEnv:
     def __init__(self, config: dict, nb_envs: int = 1, device=None, seed: int = 0, test: bool = False,
                  table_steps: int = 64, env_offset: int = 0,
                  house_shard: Optional[Tuple[int, int]] = None, process_group=None,
-                 stagger_bytes: int = 2304, interp_grid=None):
+                 stagger_bytes: int = 2304, interp_grid=None, regenerate_missing_grid: bool = True):
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedDemandResponseEnv needs a ROCm device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -64,6 +64,7 @@ class BatchedDemandResponseEnv:
         self.seed = int(seed)
         self.episode = -1
         self._od_table = None
+        self._regenerate_missing_grid = bool(regenerate_missing_grid)
         self._stagger = int(stagger_bytes)
         self._handle = C.c_void_p()
         self._cfg = self._make_config()
@@ -155,8 +156,21 @@ class BatchedDemandResponseEnv:
 
     def _install_interp_grid(self, interp_grid):
         """PowerGrid.__init__ in interpolation mode (env 1130-1165): load the grid and hand it to the library."""
-        from .config import INTERP_KEYS, load_interp_grid
-        values, axes = interp_grid if interp_grid is not None else load_interp_grid(self.spec.interp_paths)
+        from .config import DEFAULT_INTERP_AXES, INTERP_KEYS, InterpolationGridMissing, load_interp_grid
+        if interp_grid is not None:
+            values, axes = interp_grid
+        else:
+            try:
+                values, axes = load_interp_grid(self.spec.interp_paths)
+            except InterpolationGridMissing as exc:
+                if not self._regenerate_missing_grid:
+                    raise
+                import warnings
+                from .montecarlo import generate_grid
+                warnings.warn("interpolation grid %r not found (the reference does not ship it): regenerating the "
+                              "4,199,040-point bang-bang grid on the GPU; run tools/regenerate_interp_grid.py once to keep "
+                              "it on disk" % self.spec.interp_paths.get("path_datafile"))
+                values, axes = generate_grid(device=self.device), DEFAULT_INTERP_AXES
         if tuple(axes.keys()) != INTERP_KEYS:
             raise ValueError("interpolation grid axes must be " + ", ".join(INTERP_KEYS))
         dims = [len(axes[k]) for k in INTERP_KEYS]

@@ -330,6 +330,16 @@ def flatten_config(config: dict, test: bool = False) -> EnvSpec:
     )
 
 
+# The grid axes monteCarlo/monteCarlo.py:77-115 generates (= monteCarlo/interp_parameters_dict.json of the reference):
+# hours in seconds, dates in days after 1 January 2021.  tests/test_config.py checks them against a snapshot.
+DEFAULT_INTERP_AXES = {
+    "Ua_ratio": [0.9, 1, 1.1], "Cm_ratio": [0.9, 1, 1.1], "Ca_ratio": [0.9, 1, 1.1], "Hm_ratio": [0.9, 1, 1.1],
+    "air_temp": [-4, -2, -1, -0.3, 0, 0.3, 1, 2, 4], "mass_temp": [-4, -2, 0, 2, 4],
+    "OD_temp": [1, 3, 5, 7, 9, 11, 13, 15], "HVAC_power": [10000, 15000],
+    "hour": [h * 3600 for h in (0.0, 3.0, 6.0, 7.0, 7.5, 11.0, 13.0, 16.0, 17.0, 17.5, 21.0, 24 - 1.0 / 3600)],
+    "date": [0, 79, 171, 263, 354, 364],
+}
+
 INTERP_KEYS = ("Ua_ratio", "Cm_ratio", "Ca_ratio", "Hm_ratio", "air_temp", "mass_temp", "OD_temp", "HVAC_power", "hour", "date")
 
 

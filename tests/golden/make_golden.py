@@ -196,6 +196,62 @@ def run_scenario(name, patches, seed, T, policy, perlin=False, norm_steps=(0, 1,
     return arrays
 
 
+def montecarlo_points():
+    """monteCarlo.py:133-201 run through the reference env for a handful of grid points: the bang-bang 'stabilised
+    average power' that fills mergedGridSearchResultFinal.npy (the missing blob).  The config edits restate
+    eval_parameters_bangbang_average_consumption; the env and the controller are the reference's own."""
+    import datetime as dt
+    ref = ref_harness.load_reference()
+    with open(os.path.join(ref_harness.REFERENCE_ROOT, "monteCarlo", "interp_parameters_dict.json")) as f:
+        axes = json.load(f)
+    with open(os.path.join(OUT, "reference_interp_axes.json"), "w") as f:
+        json.dump(axes, f)
+    keys = list(axes.keys())
+    rng = np.random.default_rng(123)
+    points, results = [], []
+    NB_STEPS, NB_AVG = 75, 10          # monteCarlo.py:23-24
+    for n in range(48):
+        idx = [int(rng.integers(len(axes[k]))) for k in keys]
+        p = {k: axes[k][i] for k, i in zip(keys, idx)}
+        cfg = copy.deepcopy({k: ref["config_dict"][k] for k in ENV_KEYS})
+        date = dt.date(2021, 1, 1) + dt.timedelta(days=p["date"])
+        hour = p["hour"]
+        cfg["noise_house_prop"]["noise_mode"] = "no_noise"
+        cfg["noise_hvac_prop"]["noise_mode"] = "no_noise"
+        cfg["default_env_prop"]["cluster_prop"]["nb_agents"] = 1
+        cfg["default_hvac_prop"]["cooling_capacity"] = p["HVAC_power"]
+        cfg["default_env_prop"]["start_datetime_mode"] = "fixed"
+        cfg["default_hvac_prop"]["lockout_duration"] = 1
+        cfg["default_env_prop"]["start_datetime"] = str(dt.datetime(date.year, date.month, date.day, int(hour // 3600),
+                                                                    int(hour % 3600 // 60), int(hour % 60)))
+        for k in ("Ua", "Cm", "Ca", "Hm"):
+            cfg["default_house_prop"][k] *= p[k + "_ratio"]
+        tgt = cfg["default_house_prop"]["target_temp"]
+        cfg["default_house_prop"]["init_air_temp"] = tgt + p["air_temp"]
+        cfg["default_house_prop"]["init_mass_temp"] = tgt + p["mass_temp"]
+        cfg["default_env_prop"]["cluster_prop"]["temp_mode"] = "constant"
+        cfg["default_env_prop"]["cluster_prop"]["temp_parameters"]["constant"]["day_temp"] = tgt + p["OD_temp"]
+        cfg["default_env_prop"]["cluster_prop"]["temp_parameters"]["constant"]["night_temp"] = tgt + p["OD_temp"]
+        cfg["default_env_prop"]["power_grid_prop"]["base_power_mode"] = "constant"
+        ref_harness.set_perlin_gradient(None)
+        env = ref["MADemandResponseEnv"](cfg)
+        actor = {0: ref["BangBangController"]({"id": 0}, cfg)}
+        obs = env.reset()
+        actions = ref["utils"].get_actions(actor, obs)
+        total, avg = 0.0, 0.0
+        for i in range(NB_STEPS):
+            obs, _, _, info = env.step(actions)
+            total += info["cluster_hvac_power"]
+            if i >= NB_STEPS - NB_AVG:
+                avg += total / ((i + 1) * NB_AVG)
+            actions = ref["utils"].get_actions(actor, obs)
+        points.append(idx)
+        results.append(avg)
+    np.savez_compressed(os.path.join(OUT, "montecarlo_points.npz"), index=np.array(points, dtype=np.int32),
+                        hvac_average_power=np.array(results, dtype=np.float64))
+    print("montecarlo_points: %d grid points, mean %.1f W" % (len(points), float(np.mean(results))))
+
+
 CL = "default_env_prop.cluster_prop."
 PG = "default_env_prop.power_grid_prop."
 RW = "default_env_prop.reward_prop."
@@ -207,6 +263,7 @@ def main():
     with open(os.path.join(OUT, "reference_env_config.json"), "w") as f:
         json.dump(jsonable({k: ref["config_dict"][k] for k in ENV_KEYS}), f, indent=1, sort_keys=True)
 
+    montecarlo_points()
     # S1: BASELINE config 1 - 1 env x 10 houses, default noise, random start, bang-bang
     a = run_scenario("s1_c1_sinusoidals", {CL + "nb_agents": 10, PG + "signal_mode": "sinusoidals"}, 1, 1000, "bangbang")
     # anchor digits recorded in SURVEY.md section 8c

@@ -351,4 +351,4 @@ def test_interpolation_mode_needs_a_grid():
     from mdr_amd.config import InterpolationGridMissing
     cfg = _cfg(8, **{"default_env_prop.power_grid_prop.base_power_mode": "interpolation"})
     with pytest.raises(InterpolationGridMissing):      # the reference does not ship mergedGridSearchResultFinal.npy
-        mdr.BatchedDemandResponseEnv(cfg, device="cuda:0")
+        mdr.BatchedDemandResponseEnv(cfg, device="cuda:0", regenerate_missing_grid=False)
