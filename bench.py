@@ -106,14 +106,22 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one process per GPU; MDR_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the multi-rank code path
+    # on a one-GPU box (RCCL refuses two ranks on one device) - never used for reported numbers
+    backend = os.environ.get("MDR_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     cfg = c3_config(mdr_amd)
-    env = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E_PER_GPU, device=device, seed=2024,
-                                           env_offset=rank * E_PER_GPU, table_steps=64, stagger_bytes=args.stagger)
+    e_per_gpu = int(os.environ.get("MDR_BENCH_ENVS", E_PER_GPU))   # rehearsal knob only; the reported config is 4096
+    env = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=e_per_gpu, device=device, seed=2024,
+                                           env_offset=rank * e_per_gpu, table_steps=64, stagger_bytes=args.stagger)
     env.reset(episode=0)
     env.rollout(args.warmup)
 
@@ -136,7 +144,7 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    houses = E_PER_GPU * N_HOUSES * world
+    houses = e_per_gpu * N_HOUSES * world
     value = houses * args.steps / elapsed
 
     # sanity: the rollout really advanced and the state is finite (cheap, outside the timed region)
@@ -144,7 +152,7 @@ def main():
     assert bool(torch.isfinite(env.t["Ta"]).all()) and bool(torch.isfinite(env.t["reward"]).all())
 
     if rank == 0:
-        achieved = B_ALG * E_PER_GPU * N_HOUSES / (kernel_ms * 1e-3) / 1e9
+        achieved = B_ALG * e_per_gpu * N_HOUSES / (kernel_ms * 1e-3) / 1e9
         line = {
             "metric": "house-steps/sec at 4096 envs x 1024 houses; achieved HBM GB/s vs roofline",
             "value": value, "unit": "house-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -152,8 +160,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C3: %d envs x %d houses per GPU, house_big_noise + big_noise HVAC, "
                                    "noisy_sinusoidal_heatwave OD temp, solar gain, perlin signal, random start, "
-                                   "in-kernel bang-bang closed loop" % (E_PER_GPU, N_HOUSES),
-                       "envs_per_gpu": E_PER_GPU, "houses_per_env": N_HOUSES, "sharding": "independent env replicas, no collective",
+                                   "in-kernel bang-bang closed loop" % (e_per_gpu, N_HOUSES),
+                       "envs_per_gpu": e_per_gpu, "houses_per_env": N_HOUSES, "sharding": "independent env replicas, no collective",
                        "seed": 2024, "table_steps": 64},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profiles(),
