@@ -1120,7 +1120,7 @@ __global__ __launch_bounds__(256) void k_obs_planes4(ObsArgs a) {
   int f = 0;
   obs_features<4>(a, e, h, base + h,
                   [&](const float* v) {
-                    *reinterpret_cast<float4*>(a.out + (int64_t)f * a.out_plane + base + h) = make_float4(v[0], v[1], v[2], v[3]);
+                    store_out<4>(a.out + (int64_t)f * a.out_plane, base + h, v);
                     ++f;
                   },
                   [&](int m, int q) {
@@ -1227,6 +1227,21 @@ __global__ __launch_bounds__(TILE) void k_obs_rows(ObsArgs a) {
   float* msg = ownbuf + TILE * ownp;                     // [span][mf]
   float* inv_lock = msg + span * mf;                     // [TILE]
   uint32_t* dead = reinterpret_cast<uint32_t*>(inv_lock + TILE);   // [TILE] bit m: message slot m is defective
+  uint32_t* desc = dead + TILE;                          // [F] where element f of a row comes from
+  const int msg_base = TILE * ownp;                      // index of msg[] inside lds[]
+  constexpr uint32_t D_MSG = 1u << 31, D_SSO = 1u << 30;
+  // feature descriptor: own feature f -> offset f in the house's own row; message feature -> offset of (sender slot,
+  // field) relative to the house's first sender in msg[], flagged when it is the sender's seconds_since_off
+  for (int f = tid; f < a.F; f += TILE) {
+    uint32_t d;
+    if (f < own) {
+      d = (uint32_t)f;
+    } else {
+      const int g = f - own, m = g / mf, k = g - m * mf;
+      d = D_MSG | (k == 1 ? D_SSO : 0u) | ((uint32_t)m << 16) | (uint32_t)((m + (m >= before ? 1 : 0)) * mf + k);
+    }
+    desc[f] = d;
+  }
   for (int idx = tid; idx < span; idx += TILE) {
     int j = (h0 - before + idx) % a.N;
     if (j < 0) j += a.N;
@@ -1267,7 +1282,7 @@ __global__ __launch_bounds__(TILE) void k_obs_rows(ObsArgs a) {
   float* dst = a.out + (base + h0) * a.F;          // nh * F contiguous floats
   const int total = nh * a.F;
   const bool vec = (((uintptr_t)dst) & 15u) == 0;
-  const uint32_t magic = (65536u + (uint32_t)mf - 1u) / (uint32_t)mf;   // g / mf == (g * magic) >> 16 for g < 4096
+  const bool defects = a.defect_prob > 0.0f;
   int r = (tid * 4) / a.F, f = tid * 4 - r * a.F;
   const int dr = (TILE * 4) / a.F, df = TILE * 4 - dr * a.F;
   for (int o = tid * 4; o < total; o += TILE * 4) {
@@ -1276,17 +1291,11 @@ __global__ __launch_bounds__(TILE) void k_obs_rows(ObsArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int rc = min(rr, nh - 1);
-      float val;
-      if (ff < own) {
-        val = ownbuf[rc * ownp + ff];
-      } else {
-        const int g = ff - own;
-        const int m = (int)(((uint32_t)g * magic) >> 16);
-        const int k = g - m * mf;
-        val = msg[(rc + m + (m >= before ? 1 : 0)) * mf + k];
-        if (k == 1) val *= inv_lock[rc];                 // sender's seconds_since_off over the RECEIVER's lockout (utils.py:849-851)
-        if ((dead[rc] >> m) & 1u) val = 0.0f;
-      }
+      const uint32_t d = desc[ff];
+      const bool is_msg = (d & D_MSG) != 0u;
+      float val = lds[(is_msg ? msg_base + rc * mf : rc * ownp) + (int)(d & 0xFFFFu)];
+      if (d & D_SSO) val *= inv_lock[rc];               // sender's seconds_since_off over the RECEIVER's lockout (utils.py:849-851)
+      if (defects && is_msg && ((dead[rc] >> ((d >> 16) & 63u)) & 1u)) val = 0.0f;
       v[q] = val;
       if (++ff == a.F) {
         ff = 0;
@@ -1333,10 +1342,10 @@ hipError_t launch_obs_vector(const ObsArgs& a, int layout, hipStream_t s) {
       if (lds_bytes <= lds_cap)
         return launch_with_lds(k_obs_planes4, dim3((unsigned)((a.N + OBS_PTILE - 1) / OBS_PTILE), (unsigned)a.E), dim3(256), lds_bytes, s, a);
     }
-    if (layout == MDR_OBS_ROWS && a.links == nullptr && a.c <= 32 && a.F < 4096) {
+    if (layout == MDR_OBS_ROWS && a.links == nullptr && a.c <= 32 && (a.c + 1) * (int)nf < 65536) {
       constexpr int RT = 256;
       const size_t own = (size_t)(a.F - a.c * (int)nf) | 1;
-      const size_t lds_bytes = (RT * own + (RT + a.c) * nf + 2 * RT) * sizeof(float);
+      const size_t lds_bytes = (RT * own + (RT + a.c) * nf + 2 * RT + a.F) * sizeof(float);
       if (lds_bytes <= lds_cap)
         return launch_with_lds(k_obs_rows<RT>, dim3((unsigned)((a.N + RT - 1) / RT), (unsigned)a.E), dim3(RT), lds_bytes, s, a);
     }
