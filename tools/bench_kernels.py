@@ -93,6 +93,14 @@ def main():
             us = timeit(lambda: env.rollout_fused(steps, accumulate=True), 3, warm=1) / steps
             report("fused multi-step rollout %dx%d, table_steps=%d (per step)" % (E, N, K), us, E * N, 0)
             del env
+    if "shapes" in what:
+        for (E, N) in ((4194304, 1), (419430, 10), (83886, 50), (65536, 64), (41943, 100), (16384, 256), (8192, 512), (4194, 1000),
+                       (4190, 1001), (2048, 2048), (1024, 4096), (512, 8192), (64, 65536), (4, 1048576)):
+            env = mdr_amd.BatchedDemandResponseEnv(cfg_for(N), nb_envs=E, seed=1)
+            env.reset()
+            report("step %d x %d" % (E, N), timeit(lambda: env.rollout(20), 5, warm=2) / 20, E * N, 99)
+            del env
+            torch.cuda.empty_cache()
     if "reset" in what:
         env = mdr_amd.BatchedDemandResponseEnv(cfg_for(1024), nb_envs=4096, seed=1)
         report("C3 reset (sample + derive + tables)", timeit(lambda: env.reset(), 5, warm=1), 4096 * 1024, 114)
