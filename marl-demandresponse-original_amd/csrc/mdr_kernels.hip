@@ -3,6 +3,8 @@
 // Bound: HBM bandwidth (element-wise fp32, ~0.4 flop/B) - no MFMA.  One fused launch per env step:
 // every per-house array is read/written once with 16-byte accesses, the per-env reductions stay in
 // registers + LDS, per-env scalars (weather, solar, signal) come from small pre-built time tables.
+#include <cstdlib>
+
 #include "mdr_device.h"
 #include "mdr_kernels.h"
 
@@ -297,21 +299,6 @@ __device__ __forceinline__ float signal_term(const StepArgs& a, double P, double
 }
 
 // ---- (1) one workgroup per env, VEC houses per thread per tile ---------------------------------
-template <int VEC>
-struct Vec;
-template <>
-struct Vec<4> {
-  using F = float4;
-  using I = int4;
-  using B = uchar4;
-};
-template <>
-struct Vec<1> {
-  using F = float;
-  using I = int;
-  using B = unsigned char;
-};
-
 template <typename T, typename V>
 __device__ __forceinline__ void unpack(const V& v, T* out);
 template <>
@@ -1435,6 +1422,10 @@ StepPlan plan_step(int N) {
     p.kind = STEP_FUSED;
     p.vec = 4;
     p.threads = N <= 256 ? 64 : (N <= 512 ? 128 : 256);
+    if (const char* t = getenv("MDR_PLAN_THREADS")) {   // experiment knob: workgroup size of the fused kernel (64/128/256)
+      const int v = atoi(t);
+      if ((v == 64 || v == 128 || v == 256) && (N + v * 4 - 1) / (v * 4) <= 4) p.threads = v;
+    }
     p.tiles = (N + p.threads * 4 - 1) / (p.threads * 4);
   } else if (N <= 64) {
     p.kind = STEP_GROUP;
