@@ -227,13 +227,51 @@ struct Red3 {
   float max_pen;
 };
 
+// Cross-lane data movement by DPP (data-parallel primitives: a VALU modifier, no LDS crossbar, ~VALU latency).
+// Control words: quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror (i <-> 7-i), row_mirror (i <-> 15-i) swap a lane
+// with its partner at distance 1, 2, 4, 8 (as seen by a symmetric reduction); row_bcast15 / row_bcast31 (gfx9 family)
+// feed the last lane of the previous 16-lane row(s) into the next.  Lanes whose row is masked out receive 0.
+constexpr int DPP_QUAD_SWAP1 = 0xB1, DPP_QUAD_SWAP2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140,
+              DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ void red3_dpp(Red3& v) {
+  v.sum_p += dpp_f64<CTRL, ROW_MASK>(v.sum_p);
+  v.sum_pen += dpp_f64<CTRL, ROW_MASK>(v.sum_pen);
+  v.max_pen = fmaxf(v.max_pen, dpp_f32<CTRL, ROW_MASK>(v.max_pen));   // penalties are >= 0: 0 is the identity
+}
+
+// Reduction over groups of WIDTH consecutive lanes (WIDTH a power of two <= 64); every lane of a group ends with the
+// group's totals.  Distances 1..8 by DPP; 16 by one bpermute butterfly (WIDTH == 32) or, for the full wavefront, the
+// row broadcasts + a scalar read of lane 63.
 template <int WIDTH>
 __device__ __forceinline__ Red3 lanes_reduce(Red3 v) {
-#pragma unroll
-  for (int off = WIDTH / 2; off > 0; off >>= 1) {
-    v.sum_p += __shfl_xor(v.sum_p, off, 64);
-    v.sum_pen += __shfl_xor(v.sum_pen, off, 64);
-    v.max_pen = fmaxf(v.max_pen, __shfl_xor(v.max_pen, off, 64));
+  if constexpr (WIDTH >= 2) red3_dpp<DPP_QUAD_SWAP1>(v);
+  if constexpr (WIDTH >= 4) red3_dpp<DPP_QUAD_SWAP2>(v);
+  if constexpr (WIDTH >= 8) red3_dpp<DPP_ROW_HALF_MIRROR>(v);
+  if constexpr (WIDTH >= 16) red3_dpp<DPP_ROW_MIRROR>(v);
+  if constexpr (WIDTH == 32) {
+    v.sum_p += __shfl_xor(v.sum_p, 16, 64);
+    v.sum_pen += __shfl_xor(v.sum_pen, 16, 64);
+    v.max_pen = fmaxf(v.max_pen, __shfl_xor(v.max_pen, 16, 64));
+  }
+  if constexpr (WIDTH == 64) {
+    red3_dpp<DPP_ROW_BCAST15, 0xA>(v);   // rows 1 and 3 += row 0 / row 2 totals
+    red3_dpp<DPP_ROW_BCAST31, 0xC>(v);   // rows 2 and 3 += the total of rows 0-1: lane 63 holds everything
+    v.sum_p = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v.sum_p), 63), __builtin_amdgcn_readlane(__double2loint(v.sum_p), 63));
+    v.sum_pen = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v.sum_pen), 63), __builtin_amdgcn_readlane(__double2loint(v.sum_pen), 63));
+    v.max_pen = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.max_pen), 63));
   }
   return v;
 }
