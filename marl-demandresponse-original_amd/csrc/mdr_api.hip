@@ -23,6 +23,7 @@ struct mdr_env {
   const double* od_ext = nullptr;
   int64_t od_ext_rows = 0;
   mdr::StepPlan plan;
+  mdr::StepPlan rollout_plan;
   int64_t nblk = 1;
   mdr_interp_grid_t interp{};   // base_power_mode == 1
   bool has_interp = false;
@@ -236,6 +237,8 @@ int step_args(mdr_env* env, uint8_t* actions, int action_source, hipStream_t s, 
   if (action_source == MDR_ACTIONS_EXTERNAL && !actions) return fail(env, MDR_ERR_INVALID, "actions is NULL");
   if (actions && c.nb_houses % 4 == 0 && ((uintptr_t)actions & 3u) != 0)  // uchar4 accesses when N % 4 == 0
     return fail(env, MDR_ERR_INVALID, "actions must be 4-byte aligned when nb_houses is a multiple of 4");
+  if (actions && c.nb_houses % 2 == 0 && ((uintptr_t)actions & 1u) != 0)  // uchar2 accesses when N is even
+    return fail(env, MDR_ERR_INVALID, "actions must be 2-byte aligned when nb_houses is even");
   if (env->k + 1 - env->j0 > c.table_steps) {
     int rc = fill_tables(env, env->k, s);
     if (rc != MDR_OK) return rc;
@@ -318,7 +321,8 @@ int mdr_env_create(const mdr_config_t* config, mdr_env_t** out) {
   env->err = msg;
   *out = env;  // returned even on failure so that mdr_last_error() can explain; caller destroys it
   if (!msg.empty()) return MDR_ERR_INVALID;
-  env->plan = mdr::plan_step(config->nb_houses);
+  env->plan = mdr::plan_step(config->nb_houses, config->nb_envs);
+  env->rollout_plan = mdr::plan_rollout(config->nb_houses, config->nb_envs);
   env->nblk = mdr::split_blocks(config->nb_houses);
   return MDR_OK;
 }
@@ -445,7 +449,7 @@ int mdr_env_rollout_fused(mdr_env_t* env, uint8_t* actions, int32_t nb_steps, co
   if (!env) return MDR_ERR_INVALID;
   if (nb_steps < 0) return fail(env, MDR_ERR_INVALID, "nb_steps must be >= 0");
   if (out && out->struct_size != sizeof(mdr_rollout_out_t)) return fail(env, MDR_ERR_INVALID, "mdr_rollout_out_t size mismatch (ABI)");
-  if (env->cfg.nb_houses_total != env->cfg.nb_houses || !mdr::rollout_fused_supported(env->plan))
+  if (env->cfg.nb_houses_total != env->cfg.nb_houses || !mdr::rollout_fused_supported(env->rollout_plan))
     return fail(env, MDR_ERR_UNSUPPORTED, "fused rollout needs an env per workgroup or sub-wave group (N <= 2048 with N % 4 == 0, else N <= 512) and unsharded houses");
   if (env->split_pending) return fail(env, MDR_ERR_INVALID, "step_begin without step_end");
   const int E = env->cfg.nb_envs;
@@ -465,7 +469,7 @@ int mdr_env_rollout_fused(mdr_env_t* env, uint8_t* actions, int32_t nb_steps, co
       r.sq_temp_error_sum = out->sq_temp_error_sum;
       r.sq_signal_error_sum = out->sq_signal_error_sum;
     }
-    hipError_t e = mdr::launch_rollout_fused(a, r, env->plan, (hipStream_t)stream);
+    hipError_t e = mdr::launch_rollout_fused(a, r, env->rollout_plan, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(env, e, "rollout_fused");
     env->k += r.nsteps;
     done += r.nsteps;

@@ -131,7 +131,8 @@ struct StepPlan {
   int kind, vec, threads, tiles;
 };
 
-StepPlan plan_step(int N);
+StepPlan plan_step(int N, int64_t E);
+StepPlan plan_rollout(int N, int64_t E);
 int64_t split_blocks(int N);
 
 hipError_t launch_sample(const EpisodeArgs& a, hipStream_t s);

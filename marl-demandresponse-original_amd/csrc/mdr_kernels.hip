@@ -314,6 +314,16 @@ __device__ __forceinline__ void unpack<int, int>(const int& v, int* o) { o[0] = 
 template <>
 __device__ __forceinline__ void unpack<unsigned, unsigned char>(const unsigned char& v, unsigned* o) { o[0] = v; }
 
+template <>
+__device__ __forceinline__ void unpack<float, float2>(const float2& v, float* o) { o[0] = v.x; o[1] = v.y; }
+template <>
+__device__ __forceinline__ void unpack<int, int2>(const int2& v, int* o) { o[0] = v.x; o[1] = v.y; }
+template <>
+__device__ __forceinline__ void unpack<unsigned, uchar2>(const uchar2& v, unsigned* o) { o[0] = v.x; o[1] = v.y; }
+__device__ __forceinline__ float2 pack2(const float* v) { return make_float2(v[0], v[1]); }
+__device__ __forceinline__ int2 pack2(const int* v) { return make_int2(v[0], v[1]); }
+__device__ __forceinline__ uchar2 pack2(const unsigned* v) { return make_uchar2((unsigned char)v[0], (unsigned char)v[1]); }
+
 __device__ __forceinline__ float4 pack4(const float* v) { return make_float4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ int4 pack4(const int* v) { return make_int4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ uchar4 pack4(const unsigned* v) {
@@ -325,6 +335,9 @@ __device__ __forceinline__ void load_vec(const T* __restrict__ p, int64_t i, T* 
   if constexpr (VEC == 4) {
     using V = typename std::conditional<std::is_same<T, float>::value, float4, int4>::type;
     unpack<T, V>(*reinterpret_cast<const V*>(p + i), out);
+  } else if constexpr (VEC == 2) {
+    using V = typename std::conditional<std::is_same<T, float>::value, float2, int2>::type;
+    unpack<T, V>(*reinterpret_cast<const V*>(p + i), out);
   } else {
     out[0] = p[i];
   }
@@ -333,6 +346,8 @@ template <int VEC>
 __device__ __forceinline__ void load_bytes(const uint8_t* __restrict__ p, int64_t i, unsigned* out) {
   if constexpr (VEC == 4) {
     unpack<unsigned, uchar4>(*reinterpret_cast<const uchar4*>(p + i), out);
+  } else if constexpr (VEC == 2) {
+    unpack<unsigned, uchar2>(*reinterpret_cast<const uchar2*>(p + i), out);
   } else {
     out[0] = p[i];
   }
@@ -341,6 +356,8 @@ template <int VEC, typename T>
 __device__ __forceinline__ void store_vec(T* __restrict__ p, int64_t i, const T* v) {
   if constexpr (VEC == 4) {
     *reinterpret_cast<decltype(pack4(v))*>(p + i) = pack4(v);
+  } else if constexpr (VEC == 2) {
+    *reinterpret_cast<decltype(pack2(v))*>(p + i) = pack2(v);
   } else {
     p[i] = v[0];
   }
@@ -353,12 +370,16 @@ __device__ __forceinline__ void store_vec(T* __restrict__ p, int64_t i, const T*
 #define MDR_NT_STORES 1
 #endif
 typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef float v2f_t __attribute__((ext_vector_type(2)));
 template <int VEC>
 __device__ __forceinline__ void store_out(float* __restrict__ p, int64_t i, const float* v) {
 #if defined(MDR_NT_STORES) && MDR_NT_STORES
   if constexpr (VEC == 4) {
     v4f_t x = {v[0], v[1], v[2], v[3]};
     __builtin_nontemporal_store(x, reinterpret_cast<v4f_t*>(p + i));
+  } else if constexpr (VEC == 2) {
+    v2f_t x = {v[0], v[1]};
+    __builtin_nontemporal_store(x, reinterpret_cast<v2f_t*>(p + i));
   } else {
     __builtin_nontemporal_store(v[0], p + i);
   }
@@ -372,6 +393,9 @@ __device__ __forceinline__ void load_param(const float* __restrict__ p, int64_t 
   if constexpr (VEC == 4) {
     const v4f_t x = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(p + i));
     out[0] = x.x; out[1] = x.y; out[2] = x.z; out[3] = x.w;
+  } else if constexpr (VEC == 2) {
+    const v2f_t x = __builtin_nontemporal_load(reinterpret_cast<const v2f_t*>(p + i));
+    out[0] = x.x; out[1] = x.y;
   } else {
     out[0] = __builtin_nontemporal_load(p + i);
   }
@@ -383,6 +407,8 @@ template <int VEC>
 __device__ __forceinline__ void store_bytes(uint8_t* __restrict__ p, int64_t i, const unsigned* v) {
   if constexpr (VEC == 4) {
     *reinterpret_cast<uchar4*>(p + i) = pack4(v);
+  } else if constexpr (VEC == 2) {
+    *reinterpret_cast<uchar2*>(p + i) = pack2(v);
   } else {
     p[i] = (uint8_t)v[0];
   }
@@ -681,54 +707,92 @@ __global__ __launch_bounds__(THREADS) void k_rollout_fused(StepArgs a, RolloutAr
   }
 }
 
-// ---- (2) small envs: GROUP lanes per env (N <= GROUP <= 64), several envs per wavefront --------
-template <int GROUP>
+// ---- (2) small envs: GROUP lanes per env, VEC consecutive houses per lane (N <= GROUP * VEC, N % VEC == 0), several
+// envs per wavefront; reductions by sub-wave DPP exchanges only (no LDS, no barrier).  VEC = 4 / 2 keeps the accesses
+// 16 / 8 bytes wide for the agent counts the reference actually trains with (cli.py: 20 and 50 houses).
+template <int GROUP, int VEC>
 __global__ __launch_bounds__(256) void k_step_group(StepArgs a) {
   const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / GROUP;
   const int lane = threadIdx.x % GROUP;
   const bool env_ok = gid < a.E;
   const int e = env_ok ? (int)gid : a.E - 1;
-  const bool active = env_ok && lane < a.N;
-  const int64_t i = (int64_t)e * a.N + lane;
-  HouseOut o[1];
-  int lockout[1];
+  const bool active = env_ok && lane * VEC < a.N;
+  const int64_t i = (int64_t)e * a.N + lane * VEC;
+  HouseOut o[VEC];
+  int lockout[VEC];
+  float pen[VEC];
   Red3 acc{0.0, 0.0, 0.0f};
   if (active) {
-    step_vec<1>(a, i, a.od_old[e], a.solar_new[e], o, lockout);
-    acc.sum_p = (double)o[0].power;
-    acc.sum_pen = (double)o[0].pen;
-    acc.max_pen = o[0].pen;
-    store_obs_local<1>(a, i, o, lockout);
+    step_vec<VEC>(a, i, a.od_old[e], a.solar_new[e], o, lockout);
+    float p = 0.0f, ps = 0.0f;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      p += o[v].power;
+      ps += o[v].pen;
+      pen[v] = o[v].pen;
+      acc.max_pen = fmaxf(acc.max_pen, o[v].pen);
+    }
+    acc.sum_p = (double)p;
+    acc.sum_pen = (double)ps;
+    store_obs_local<VEC>(a, i, o, lockout);
   }
   const Red3 tot = lanes_reduce<GROUP>(acc);
   if (active) {
     const float sig_term = signal_term(a, tot.sum_p, a.sig_old[e]);
     if (lane == 0) a.P[e] = tot.sum_p;
-    store_reward_power<1>(a, i, &o[0].pen, tot.sum_pen, tot.max_pen, sig_term, (float)(a.sig_new[e] * a.inv_obs_norm),
-                          (float)(tot.sum_p * a.inv_obs_norm));
+    store_reward_power<VEC>(a, i, pen, tot.sum_pen, tot.max_pen, sig_term, (float)(a.sig_new[e] * a.inv_obs_norm),
+                            (float)(tot.sum_p * a.inv_obs_norm));
   }
 }
 
-// ---- (2b) multi-step closed loop for small envs: GROUP lanes per env, one house per lane, no LDS, no barrier
-template <int GROUP, bool WINDOW>
+// ---- (2b) multi-step closed loop for small envs: GROUP lanes per env, VEC houses per lane (the same mapping and the
+// same reduction tree as k_step_group, so both end bit for bit in the same state), no LDS, no barrier
+template <int GROUP, int VEC, bool WINDOW>
 __global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs ro) {
   const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / GROUP;
   const int lane = threadIdx.x % GROUP;
   const bool env_ok = gid < a.E;
   const int e = env_ok ? (int)gid : a.E - 1;
-  const bool active = env_ok && lane < a.N;
-  const int64_t i = (int64_t)e * a.N + lane;
-  HouseIn hs{};
-  HouseOut o{};
-  int lockout[1] = {1};
-  if (active) {
-    hs = HouseIn{a.Ta[i], a.Tm[i], a.sso[i], a.flags[i], a.k01[i], a.s0[i], a.k10[i], a.s1[i], a.inv_Ua[i],
-                 a.Q_hvac[i], a.P_max[i], a.target[i], a.deadband[i], a.lockout[i]};
-    lockout[0] = hs.lockout;
+  const bool active = env_ok && lane * VEC < a.N;
+  const int64_t i = (int64_t)e * a.N + lane * VEC;
+  HouseIn hs[VEC];
+  HouseOut o[VEC];
+  int lockout[VEC];
+  float rsum[VEC], pen[VEC];
+  unsigned act[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    hs[v] = HouseIn{};
+    o[v] = HouseOut{};
+    lockout[v] = 1;
+    rsum[v] = 0.0f;
+    act[v] = 0;
   }
-  float rsum = (active && ro.reward_sum) ? ro.reward_sum[i] : 0.0f, sig_term = 0.0f;
+  if (active) {
+    float Ta[VEC], Tm[VEC], k01[VEC], s0[VEC], k10[VEC], s1[VEC], iu[VEC], q[VEC], pm[VEC], tg[VEC], db[VEC];
+    int sso[VEC];
+    unsigned fl[VEC];
+    load_vec<VEC>(a.Ta, i, Ta);
+    load_vec<VEC>(a.Tm, i, Tm);
+    load_vec<VEC>(a.sso, i, sso);
+    load_bytes<VEC>(a.flags, i, fl);
+    load_vec<VEC>(a.k01, i, k01);
+    load_vec<VEC>(a.s0, i, s0);
+    load_vec<VEC>(a.k10, i, k10);
+    load_vec<VEC>(a.s1, i, s1);
+    load_vec<VEC>(a.inv_Ua, i, iu);
+    load_vec<VEC>(a.Q_hvac, i, q);
+    load_vec<VEC>(a.P_max, i, pm);
+    load_vec<VEC>(a.target, i, tg);
+    load_vec<VEC>(a.deadband, i, db);
+    load_vec<VEC>(a.lockout, i, lockout);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+      hs[v] = HouseIn{Ta[v], Tm[v], sso[v], fl[v], k01[v], s0[v], k10[v], s1[v], iu[v], q[v], pm[v], tg[v], db[v], lockout[v]};
+    if (ro.reward_sum) load_vec<VEC>(ro.reward_sum, i, rsum);   // continue the caller's running sum in step order
+  }
+  float sig_term = 0.0f;
   double terr = 0.0, serr = 0.0;
-  unsigned act = 0;
   Red3 tot{0.0, 0.0, 0.0f};
   const int gbase = (threadIdx.x & 63) & ~(GROUP - 1);   // first lane of this env's group inside the wavefront
   EnvRow cur{}, nxt{}, er{};
@@ -749,23 +813,31 @@ __global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs r
     }
     Red3 acc{0.0, 0.0, 0.0f};
     if (active) {
-      const bool cmd = hs.Ta > hs.target;
-      act = cmd ? 1u : 0u;
-      o = house_step(hs, cmd, er.od, er.solar, a.dt);
-      hs.Ta = o.Ta;
-      hs.Tm = o.Tm;
-      hs.sso = o.sso;
-      hs.flags = o.flags;
-      acc.sum_p = (double)o.power;
-      acc.sum_pen = (double)o.pen;
-      acc.max_pen = o.pen;
-      const float d = o.Ta - hs.target;
-      terr += (double)(d * d);
+      float p = 0.0f, ps = 0.0f, te = 0.0f;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const bool cmd = hs[v].Ta > hs[v].target;
+        act[v] = cmd ? 1u : 0u;
+        o[v] = house_step(hs[v], cmd, er.od, er.solar, a.dt);
+        hs[v].Ta = o[v].Ta;
+        hs[v].Tm = o[v].Tm;
+        hs[v].sso = o[v].sso;
+        hs[v].flags = o[v].flags;
+        p += o[v].power;
+        ps += o[v].pen;
+        acc.max_pen = fmaxf(acc.max_pen, o[v].pen);
+        const float d = o[v].Ta - hs[v].target;
+        te = fmaf(d, d, te);
+      }
+      acc.sum_p = (double)p;
+      acc.sum_pen = (double)ps;
+      terr += (double)te;
     }
     tot = lanes_reduce<GROUP>(acc);
     sig_term = signal_term(a, tot.sum_p, er.sig_old);
     if (active) {
-      rsum = __fadd_rn(rsum, reward_value(a, o.pen, tot.sum_pen, tot.max_pen, sig_term));
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) rsum[v] = __fadd_rn(rsum[v], reward_value(a, o[v].pen, tot.sum_pen, tot.max_pen, sig_term));
       if (lane == 0) {
         if (ro.power_trace) ro.power_trace[row] = tot.sum_p;
         const double d = er.sig_new - tot.sum_p;
@@ -777,15 +849,26 @@ __global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs r
   Red3 tr{terr, 0.0, 0.0f};
   tr = lanes_reduce<GROUP>(tr);
   if (!active) return;
-  a.Ta[i] = hs.Ta;
-  a.Tm[i] = hs.Tm;
-  a.sso[i] = hs.sso;
-  a.flags[i] = (uint8_t)hs.flags;
-  if (a.actions != nullptr) a.actions[i] = (uint8_t)act;
-  store_obs_local<1>(a, i, &o, lockout);
-  store_reward_power<1>(a, i, &o.pen, tot.sum_pen, tot.max_pen, sig_term, (float)(er.sig_new * a.inv_obs_norm),
-                        (float)(tot.sum_p * a.inv_obs_norm));
-  if (ro.reward_sum) ro.reward_sum[i] = rsum;
+  float nTa[VEC], nTm[VEC];
+  int nsso[VEC];
+  unsigned nfl[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    nTa[v] = hs[v].Ta;
+    nTm[v] = hs[v].Tm;
+    nsso[v] = hs[v].sso;
+    nfl[v] = hs[v].flags;
+    pen[v] = o[v].pen;
+  }
+  store_vec<VEC>(a.Ta, i, nTa);
+  store_vec<VEC>(a.Tm, i, nTm);
+  store_vec<VEC>(a.sso, i, nsso);
+  store_bytes<VEC>(a.flags, i, nfl);
+  if (a.actions != nullptr) store_bytes<VEC>(a.actions, i, act);
+  store_obs_local<VEC>(a, i, o, lockout);
+  store_reward_power<VEC>(a, i, pen, tot.sum_pen, tot.max_pen, sig_term, (float)(er.sig_new * a.inv_obs_norm),
+                          (float)(tot.sum_p * a.inv_obs_norm));
+  if (ro.reward_sum) store_vec<VEC>(ro.reward_sum, i, rsum);
   if (lane == 0) {
     a.P[e] = tot.sum_p;
     if (ro.sq_temp_error_sum) ro.sq_temp_error_sum[e] += tr.sum_p;
@@ -1480,9 +1563,25 @@ static void launch_fused_tiles(const StepArgs& a, int tiles, hipStream_t s) {
   }
 }
 
-StepPlan plan_step(int N) {
+static int pow2_at_least(int n) {
+  int g = 1;
+  while (g < n) g <<= 1;
+  return g;
+}
+
+StepPlan plan_step(int N, int64_t E) {
   StepPlan p{};
-  if (N % 4 == 0 && N >= 64 && N <= 4096) {
+  int vec = (N % 4 == 0) ? 4 : ((N % 2 == 0) ? 2 : 1);
+  // Small batches (less than ~16 wavefronts per CU even at one house per lane) are latency-bound: one house per lane
+  // exposes the most parallelism; wide accesses only pay once the device is full.
+  if (N <= 64 && E * N < 262144) vec = 1;
+  const int lanes = (N + vec - 1) / vec;
+  if (lanes <= 32 || (vec < 4 && lanes <= 64)) {   // at least two envs per wavefront, or no wider form exists
+    p.kind = STEP_GROUP;
+    p.vec = vec;
+    p.threads = pow2_at_least(lanes);   // lanes per env
+    p.tiles = 1;
+  } else if (N % 4 == 0 && N <= 4096) {
     p.kind = STEP_FUSED;
     p.vec = 4;
     p.threads = N <= 256 ? 64 : (N <= 512 ? 128 : 256);
@@ -1491,13 +1590,6 @@ StepPlan plan_step(int N) {
       if ((v == 64 || v == 128 || v == 256) && (N + v * 4 - 1) / (v * 4) <= 4) p.threads = v;
     }
     p.tiles = (N + p.threads * 4 - 1) / (p.threads * 4);
-  } else if (N <= 64) {
-    p.kind = STEP_GROUP;
-    p.vec = 1;
-    int g = 1;
-    while (g < N) g <<= 1;
-    p.threads = g;  // lanes per env
-    p.tiles = 1;
   } else if (N <= 1024) {
     p.kind = STEP_FUSED;
     p.vec = 1;
@@ -1508,6 +1600,27 @@ StepPlan plan_step(int N) {
     p.vec = (N % 4 == 0) ? 4 : 1;
     p.threads = 256;
     p.tiles = 1;
+  }
+  return p;
+}
+
+// The multi-step kernels keep one house per lane (sub-wave groups) or VEC x TILES houses per thread (workgroup per env)
+StepPlan plan_rollout(int N, int64_t E) {
+  StepPlan p = plan_step(N, E);
+  if (p.kind == STEP_GROUP) return p;   // same lane mapping as the single-step kernel
+  p = StepPlan{};
+  if (N % 4 == 0 && N <= 2048) {
+    p.kind = STEP_FUSED;
+    p.vec = 4;
+    p.threads = N <= 256 ? 64 : (N <= 512 ? 128 : 256);
+    p.tiles = (N + p.threads * 4 - 1) / (p.threads * 4);
+  } else if (N <= 512) {
+    p.kind = STEP_FUSED;
+    p.vec = 1;
+    p.threads = 256;
+    p.tiles = (N + 255) / 256;
+  } else {
+    p.kind = STEP_SPLIT;
   }
   return p;
 }
@@ -1536,7 +1649,7 @@ hipError_t launch_step_end_split(const StepArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-bool rollout_fused_supported(const StepPlan& p) { return p.kind == STEP_GROUP || (p.kind == STEP_FUSED && p.tiles <= 2); }
+bool rollout_fused_supported(const StepPlan& p) { return p.kind == STEP_GROUP || p.kind == STEP_FUSED; }
 
 hipError_t launch_rollout_fused(const StepArgs& a, const RolloutArgs& r, const StepPlan& p, hipStream_t s) {
   if (!rollout_fused_supported(p)) return hipErrorInvalidValue;
@@ -1544,9 +1657,13 @@ hipError_t launch_rollout_fused(const StepArgs& a, const RolloutArgs& r, const S
     const int64_t lanes = (int64_t)a.E * p.threads;
     const dim3 gg((unsigned)((lanes + 255) / 256)), b(256);
     const bool win = lanes < (int64_t)64 * 8 * 256;   // fewer than ~8 wavefronts per CU: latency-bound
-#define MDR_ROLLG(G)                                                          \
-  if (win) hipLaunchKernelGGL((k_rollout_group<G, true>), gg, b, 0, s, a, r); \
-  else hipLaunchKernelGGL((k_rollout_group<G, false>), gg, b, 0, s, a, r);    \
+#define MDR_ROLLGV(G, V)                                                          \
+  if (win) hipLaunchKernelGGL((k_rollout_group<G, V, true>), gg, b, 0, s, a, r); \
+  else hipLaunchKernelGGL((k_rollout_group<G, V, false>), gg, b, 0, s, a, r);
+#define MDR_ROLLG(G)                      \
+  if (p.vec == 4) { MDR_ROLLGV(G, 4) }    \
+  else if (p.vec == 2) { MDR_ROLLGV(G, 2) } \
+  else { MDR_ROLLGV(G, 1) }               \
   break;
     switch (p.threads) {
       case 1: MDR_ROLLG(1)
@@ -1558,6 +1675,7 @@ hipError_t launch_rollout_fused(const StepArgs& a, const RolloutArgs& r, const S
       default: MDR_ROLLG(64)
     }
 #undef MDR_ROLLG
+#undef MDR_ROLLGV
     return hipGetLastError();
   }
   const dim3 g((unsigned)a.E);
@@ -1592,15 +1710,21 @@ hipError_t launch_step(const StepArgs& a, const StepPlan& p, hipStream_t s) {
   if (p.kind == STEP_GROUP) {
     const int64_t lanes = (int64_t)a.E * p.threads;
     const dim3 g((unsigned)((lanes + 255) / 256)), b(256);
+#define MDR_GROUP(G)                                                                   \
+  if (p.vec == 4) hipLaunchKernelGGL((k_step_group<G, 4>), g, b, 0, s, a);             \
+  else if (p.vec == 2) hipLaunchKernelGGL((k_step_group<G, 2>), g, b, 0, s, a);        \
+  else hipLaunchKernelGGL((k_step_group<G, 1>), g, b, 0, s, a);                        \
+  break;
     switch (p.threads) {
-      case 1: hipLaunchKernelGGL(k_step_group<1>, g, b, 0, s, a); break;
-      case 2: hipLaunchKernelGGL(k_step_group<2>, g, b, 0, s, a); break;
-      case 4: hipLaunchKernelGGL(k_step_group<4>, g, b, 0, s, a); break;
-      case 8: hipLaunchKernelGGL(k_step_group<8>, g, b, 0, s, a); break;
-      case 16: hipLaunchKernelGGL(k_step_group<16>, g, b, 0, s, a); break;
-      case 32: hipLaunchKernelGGL(k_step_group<32>, g, b, 0, s, a); break;
-      default: hipLaunchKernelGGL(k_step_group<64>, g, b, 0, s, a); break;
+      case 1: MDR_GROUP(1)
+      case 2: MDR_GROUP(2)
+      case 4: MDR_GROUP(4)
+      case 8: MDR_GROUP(8)
+      case 16: MDR_GROUP(16)
+      case 32: MDR_GROUP(32)
+      default: MDR_GROUP(64)
     }
+#undef MDR_GROUP
     return hipGetLastError();
   }
   hipError_t err = launch_step_begin_split(a, s);
