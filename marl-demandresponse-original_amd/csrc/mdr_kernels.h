@@ -126,7 +126,7 @@ struct RolloutArgs {
   int defer_last_signal_error;   // the last step's reg_signal is not final yet (interpolation update due): the host adds it
 };
 
-enum StepKind { STEP_FUSED = 0, STEP_GROUP = 1, STEP_SPLIT = 2 };
+enum StepKind { STEP_FUSED = 0, STEP_GROUP = 1, STEP_SPLIT = 2, STEP_SINGLE = 3 };
 struct StepPlan {
   int kind, vec, threads, tiles;
 };

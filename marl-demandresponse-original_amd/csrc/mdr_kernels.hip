@@ -238,9 +238,11 @@ __global__ __launch_bounds__(256) void k_fill_tables(TableArgs a) {
   } else {
     const double amp = 0.5 * (a.day_temp - a.night_temp), bias = 0.5 * (a.day_temp + a.night_temp);
     const double tday = (double)c.hour + (double)c.minute / 60.0;
-    od = amp * sin(6.283185307179586476925286766559 * (tday + (-6.0 + a.phase[e])) / 24.0) + bias;
-    const u32x4 g = philox4x32_10(eg, (uint32_t)j, a.episode, TAG_OD_NOISE, a.k0, a.k1);
-    od += a.temp_std * gauss01(g.x, g.y);
+    od = amp * sin(6.283185307179586476925286766559 * (tday + (-6.0 + a.phase[e])) / 24.0) + bias;   // amp == 0: exactly bias
+    if (a.temp_std != 0.0) {   // random.gauss(0, 0) adds exactly 0 in the reference; skipping the draw changes nothing
+      const u32x4 g = philox4x32_10(eg, (uint32_t)j, a.episode, TAG_OD_NOISE, a.k0, a.k1);
+      od += a.temp_std * gauss01(g.x, g.y);
+    }
   }
   a.tab_od[i] = (float)(od - a.temp_ref);
 
@@ -743,6 +745,64 @@ __global__ __launch_bounds__(256) void k_step_group(StepArgs a) {
     store_reward_power<VEC>(a, i, pen, tot.sum_pen, tot.max_pen, sig_term, (float)(a.sig_new[e] * a.inv_obs_norm),
                             (float)(tot.sum_p * a.inv_obs_norm));
   }
+}
+
+// ---- (2a) single-house envs (config.py's literal default nb_agents = 1; the Monte-Carlo grid): the "env" axis is the
+// vector axis - 4 consecutive envs per thread, every per-house array AND the per-env table rows read 16 bytes wide.
+// No reduction: the cluster is the house.
+__global__ __launch_bounds__(256) void k_step_single_house(StepArgs a) {
+  const int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e0 >= a.E) return;   // E % 4 == 0
+  float Ta[4], Tm[4], k01[4], s0[4], k10[4], s1[4], iu[4], q[4], pm[4], tg[4], db[4], od[4], solar[4];
+  int sso[4], lk[4];
+  unsigned fl[4], act[4];
+  load_vec<4>(a.Ta, e0, Ta);
+  load_vec<4>(a.Tm, e0, Tm);
+  load_vec<4>(a.sso, e0, sso);
+  load_bytes<4>(a.flags, e0, fl);
+  if (a.action_source == MDR_ACTIONS_EXTERNAL) load_bytes<4>(a.actions, e0, act);
+  load_param<4>(a.k01, e0, k01);
+  load_param<4>(a.s0, e0, s0);
+  load_param<4>(a.k10, e0, k10);
+  load_param<4>(a.s1, e0, s1);
+  load_param<4>(a.inv_Ua, e0, iu);
+  load_param<4>(a.Q_hvac, e0, q);
+  load_param<4>(a.P_max, e0, pm);
+  load_param<4>(a.target, e0, tg);
+  load_param<4>(a.deadband, e0, db);
+  load_vec<4>(a.lockout, e0, lk);
+  load_vec<4>(a.od_old, e0, od);
+  load_vec<4>(a.solar_new, e0, solar);
+  HouseOut o[4];
+  float nTa[4], nTm[4], rew[4], c5[4], c6[4];
+  int nsso[4];
+  unsigned nfl[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    HouseIn h{Ta[v], Tm[v], sso[v], fl[v], k01[v], s0[v], k10[v], s1[v], iu[v], q[v], pm[v], tg[v], db[v], lk[v]};
+    const bool cmd = (a.action_source == MDR_ACTIONS_BANGBANG) ? (Ta[v] > tg[v]) : (act[v] != 0u);
+    if (a.action_source == MDR_ACTIONS_BANGBANG) act[v] = cmd ? 1u : 0u;
+    o[v] = house_step(h, cmd, od[v], solar[v], a.dt);
+    nTa[v] = o[v].Ta;
+    nTm[v] = o[v].Tm;
+    nsso[v] = o[v].sso;
+    nfl[v] = o[v].flags;
+    const double P = (double)o[v].power;
+    const float sig_term = signal_term(a, P, a.sig_old[e0 + v]);
+    rew[v] = reward_value(a, o[v].pen, (double)o[v].pen, o[v].pen, sig_term);   // one house: common == individual
+    c5[v] = (float)(a.sig_new[e0 + v] * a.inv_obs_norm);
+    c6[v] = (float)(P * a.inv_obs_norm);
+    a.P[e0 + v] = P;
+  }
+  store_vec<4>(a.Ta, e0, nTa);
+  store_vec<4>(a.Tm, e0, nTm);
+  store_vec<4>(a.sso, e0, nsso);
+  store_bytes<4>(a.flags, e0, nfl);
+  if (a.action_source == MDR_ACTIONS_BANGBANG && a.actions != nullptr) store_bytes<4>(a.actions, e0, act);
+  store_obs_local<4>(a, e0, o, lk);
+  store_out<4>(a.reward, e0, rew);
+  store_out<4>(a.obs + 5 * a.plane, e0, c5);
+  store_out<4>(a.obs + 6 * a.plane, e0, c6);
 }
 
 // ---- (2b) multi-step closed loop for small envs: GROUP lanes per env, VEC houses per lane (the same mapping and the
@@ -1576,7 +1636,12 @@ StepPlan plan_step(int N, int64_t E) {
   // exposes the most parallelism; wide accesses only pay once the device is full.
   if (N <= 64 && E * N < 262144) vec = 1;
   const int lanes = (N + vec - 1) / vec;
-  if (lanes <= 32 || (vec < 4 && lanes <= 64)) {   // at least two envs per wavefront, or no wider form exists
+  if (N == 1 && E % 4 == 0 && E >= 262144) {   // single-house envs in bulk: vectorise over the env axis
+    p.kind = STEP_SINGLE;
+    p.vec = 4;
+    p.threads = 256;
+    p.tiles = 1;
+  } else if (lanes <= 32 || (vec < 4 && lanes <= 64)) {   // at least two envs per wavefront, or no wider form exists
     p.kind = STEP_GROUP;
     p.vec = vec;
     p.threads = pow2_at_least(lanes);   // lanes per env
@@ -1608,6 +1673,12 @@ StepPlan plan_step(int N, int64_t E) {
 StepPlan plan_rollout(int N, int64_t E) {
   StepPlan p = plan_step(N, E);
   if (p.kind == STEP_GROUP) return p;   // same lane mapping as the single-step kernel
+  if (p.kind == STEP_SINGLE) {          // one lane per env; nothing to reduce, so any mapping gives the same bits
+    p.kind = STEP_GROUP;
+    p.vec = 1;
+    p.threads = 1;
+    return p;
+  }
   p = StepPlan{};
   if (N % 4 == 0 && N <= 2048) {
     p.kind = STEP_FUSED;
@@ -1697,6 +1768,10 @@ hipError_t launch_rollout_fused(const StepArgs& a, const RolloutArgs& r, const S
 }
 
 hipError_t launch_step(const StepArgs& a, const StepPlan& p, hipStream_t s) {
+  if (p.kind == STEP_SINGLE) {
+    hipLaunchKernelGGL(k_step_single_house, dim3((unsigned)((a.E / 4 + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+  }
   if (p.kind == STEP_FUSED) {
     if (p.vec == 4) {
       if (p.threads == 64) launch_fused_tiles<4, 64>(a, p.tiles, s);

@@ -352,3 +352,33 @@ def test_interpolation_mode_needs_a_grid():
     cfg = _cfg(8, **{"default_env_prop.power_grid_prop.base_power_mode": "interpolation"})
     with pytest.raises(InterpolationGridMissing):      # the reference does not ship mergedGridSearchResultFinal.npy
         mdr.BatchedDemandResponseEnv(cfg, device="cuda:0", regenerate_missing_grid=False)
+
+
+def test_single_house_envs_in_bulk_match_the_group_kernel_and_the_oracle():
+    """N = 1 (config.py's literal default) at large E takes the env-vectorised kernel; it must equal the generic
+    one-lane-per-env kernel bit for bit, and the oracle on a sample."""
+    from oracle import mdr_oracle as mo
+    mdr = _mdr()
+    cfg = _cfg(1, **{"noise_house_prop.noise_mode": "big_noise", "noise_hvac_prop.noise_mode": "big_noise",
+                     "default_env_prop.reward_prop.temp_penalty_mode": "mixture"})
+    E = 262144
+    big = mdr.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=9)
+    small = mdr.BatchedDemandResponseEnv(cfg, nb_envs=4096, device="cuda:0", seed=9, env_offset=E - 4096)   # generic kernel
+    ora = mo.OracleEnv(cfg, nb_envs=64, env_offset=E - 64).reset(seed=9, episode=0)
+    big.reset(episode=0)
+    small.reset(episode=0)
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    for t in range(30):
+        act = (torch.rand((E, 1), device="cuda", generator=gen) < 0.5).to(torch.uint8)
+        _, r_big, _, _ = big.step(act)
+        _, r_small, _, _ = small.step(act[E - 4096:].contiguous())
+        r_ref = ora.step(act[E - 64:].cpu().numpy())
+    for k in ("Ta", "Tm", "sso", "flags", "reward", "P"):
+        assert torch.equal(big.t[k][E - 4096:], small.t[k]), k
+    assert torch.equal(big.t["obs"][:, E - 4096:], small.t["obs"])
+    np.testing.assert_allclose(big.house_temp()[E - 64:].cpu().numpy(), ora.Ta, rtol=T_RTOL)
+    np.testing.assert_allclose(r_big[E - 64:].cpu().numpy(), r_ref, rtol=R_RTOL, atol=R_ATOL)
+    np.testing.assert_array_equal(big.t["P"][E - 64:].cpu().numpy(), ora.P)
+    big.step_bangbang()
+    small.step_bangbang()
+    assert torch.equal(big.t["Ta"][E - 4096:], small.t["Ta"]) and torch.equal(big.t["actions"][E - 4096:], small.t["actions"])
