@@ -260,6 +260,10 @@ int mdr_env_rollout_fused(mdr_env_t *env, uint8_t *actions, int32_t nb_steps, co
  * two power observation columns from the reduced values. */
 int mdr_env_step_begin(mdr_env_t *env, uint8_t *actions, int action_source, void *stream);
 int mdr_env_step_end(mdr_env_t *env, void *stream);
+/* One collective per step instead of two: every rank lays its aggregates out as one [3][E] block (tot_max placed
+ * right behind tot_sum), the caller ALL-GATHERS the blocks into `gathered` [world][3][E] and this call reduces them on
+ * the fly (sum, sum, max over ranks, in rank order) while writing rewards - the all-reduced values are never stored. */
+int mdr_env_step_end_gathered(mdr_env_t *env, const double *gathered, int32_t world, void *stream);
 
 /* utils.normStateDict (utils.py:740-880) for every house at once, including the neighbour messages
  * (SingleHouse.message env 624-662, gathered through `links`): writes the flat state vector of length

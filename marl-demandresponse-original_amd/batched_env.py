@@ -122,8 +122,8 @@ class BatchedDemandResponseEnv:
         items += [(n, torch.int32, (E, N)) for n in _HOUSE_I32]
         items += [(n, torch.uint8, (E, N)) for n in _HOUSE_U8]
         items += [("obs", torch.float32, (nat.MDR_OBS_COLUMNS, E, N))]
-        items += [("t0", torch.int64, (E,))] + [(n, torch.float64, (E,)) for n in ("phase", "ratio", "max_power", "P", "tot_max", "base_power")]
-        items += [("tot_sum", torch.float64, (2, E))]
+        items += [("t0", torch.int64, (E,))] + [(n, torch.float64, (E,)) for n in ("phase", "ratio", "max_power", "P", "base_power")]
+        items += [("tot", torch.float64, (3, E))]     # local aggregates as ONE block: tot_sum = tot[0:2], tot_max = tot[2]
         items += [("tab_od", torch.float32, (K1, E)), ("tab_solar", torch.float32, (K1, E)), ("tab_signal", torch.float64, (K1, E))]
         items += [("partials", torch.float64, (E, nblk, 3))]
         return items
@@ -143,6 +143,7 @@ class BatchedDemandResponseEnv:
         self.t: Dict[str, torch.Tensor] = {}
         for name, (o, nbytes, dtype, shape) in offsets.items():
             self.t[name] = self._slab[o:o + nbytes].view(dtype).view(*shape)
+        self.t["tot_sum"], self.t["tot_max"] = self.t["tot"][0:2], self.t["tot"][2]
 
     def _bind(self):
         b = nat.MdrBuffers()
@@ -299,10 +300,16 @@ class BatchedDemandResponseEnv:
                 import torch.distributed as dist
                 rc = self._lib.mdr_env_step_begin(self._handle, C.c_void_p(ptr), source, self._stream())
                 nat.check(self._lib, self._handle, rc, "mdr_env_step_begin")
-                self._allreduce(self.t["tot_sum"], dist.ReduceOp.SUM)   # cluster power, penalty sum
-                self._allreduce(self.t["tot_max"], dist.ReduceOp.MAX)   # penalty max
-                rc = self._lib.mdr_env_step_end(self._handle, self._stream())
-                nat.check(self._lib, self._handle, rc, "mdr_env_step_end")
+                # ONE collective per step: all-gather every rank's [3][E] block (cluster power, penalty sum, penalty max);
+                # mdr_env_step_end_gathered reduces the blocks while it writes the rewards (payload 24 B per env and rank:
+                # the exchange is latency-bound, so the number of collectives is what counts)
+                world = dist.get_world_size(self.process_group)
+                if getattr(self, "_gathered", None) is None or self._gathered.shape[0] != world:
+                    self._gathered = torch.empty((world, 3, self.nb_envs), dtype=torch.float64, device=self.device)
+                # concatenation form [world * 3, E] (same memory as [world][3][E]): accepted by RCCL and by gloo alike
+                dist.all_gather_into_tensor(self._gathered.view(world * 3, self.nb_envs), self.t["tot"], group=self.process_group)
+                rc = self._lib.mdr_env_step_end_gathered(self._handle, C.c_void_p(self._gathered.data_ptr()), world, self._stream())
+                nat.check(self._lib, self._handle, rc, "mdr_env_step_end_gathered")
 
     def step(self, actions: torch.Tensor):
         """MADemandResponseEnv.step (env 174-210).  Returns (obs [7,E,N], reward [E,N], done [E,N], info)."""

@@ -492,12 +492,15 @@ int mdr_env_step_begin(mdr_env_t* env, uint8_t* actions, int action_source, void
   return MDR_OK;
 }
 
-int mdr_env_step_end(mdr_env_t* env, void* stream) {
+static int step_end_impl(mdr_env_t* env, const double* gathered, int32_t world, void* stream) {
   if (!env) return MDR_ERR_INVALID;
   if (!env->split_pending) return fail(env, MDR_ERR_INVALID, "step_end without step_begin");
+  if (gathered && world < 1) return fail(env, MDR_ERR_INVALID, "world must be >= 1");
   mdr::StepArgs a;
   int rc = step_args(env, nullptr, MDR_ACTIONS_BANGBANG, (hipStream_t)stream, &a);  // actions unused here
   if (rc != MDR_OK) return rc;
+  a.gathered = gathered;
+  a.world = world;
   hipError_t e = mdr::launch_step_end_split(a, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "step_end");
   env->split_pending = false;
@@ -557,6 +560,13 @@ int mdr_env_obs_vector(mdr_env_t* env, const mdr_obs_spec_t* spec, float* out, v
   hipError_t e = mdr::launch_obs_vector(a, spec->layout, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "obs_vector");
   return MDR_OK;
+}
+
+int mdr_env_step_end(mdr_env_t* env, void* stream) { return step_end_impl(env, nullptr, 0, stream); }
+
+int mdr_env_step_end_gathered(mdr_env_t* env, const double* gathered, int32_t world, void* stream) {
+  if (!gathered) return env ? fail(env, MDR_ERR_INVALID, "gathered is NULL") : MDR_ERR_INVALID;
+  return step_end_impl(env, gathered, world, stream);
 }
 
 int mdr_env_cursor(const mdr_env_t* env, int64_t* k, int64_t* j0) {

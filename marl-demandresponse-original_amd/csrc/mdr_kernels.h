@@ -80,6 +80,8 @@ struct StepArgs {
   float* reward;
   float* obs;
   double *P, *tot_sum, *tot_max, *partials;
+  const double* gathered;              // [world][3][E] all-gathered local aggregates (sharded houses), or nullptr
+  int world;
   const float *od_old, *solar_new;     // table rows for this step: OD temp at time index k-1, solar at k
   const double *sig_old, *sig_new;     // regulation signal at k-1 (reward) and k (observation)
   int64_t plane;                       // E * N: stride between observation planes

@@ -993,7 +993,23 @@ template <int VEC>
 __global__ __launch_bounds__(256) void k_step_finish(StepArgs a) {
   const int e = blockIdx.y;
   const int h = ((int)blockIdx.x * 256 + (int)threadIdx.x) * VEC;
-  const double P = a.tot_sum[e];
+  double P, sum_pen;
+  float max_pen;
+  if (a.gathered != nullptr) {   // [world][3][E] local aggregates of every rank: reduce here, in rank order
+    P = 0.0;
+    sum_pen = 0.0;
+    max_pen = 0.0f;
+    for (int r = 0; r < a.world; ++r) {
+      const double* g = a.gathered + (int64_t)r * 3 * a.E;
+      P += g[e];
+      sum_pen += g[a.E + e];
+      max_pen = fmaxf(max_pen, (float)g[2 * a.E + e]);
+    }
+  } else {
+    P = a.tot_sum[e];
+    sum_pen = a.tot_sum[a.E + e];
+    max_pen = (float)a.tot_max[e];
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) a.P[e] = P;
   if (h >= a.N) return;
   const int64_t i = (int64_t)e * a.N + h;
@@ -1007,7 +1023,7 @@ __global__ __launch_bounds__(256) void k_step_finish(StepArgs a) {
     const float above = Ta[v] - hi, below = lo - Ta[v];
     pen[v] = above > 0.0f ? above * above : (below > 0.0f ? below * below : 0.0f);
   }
-  store_reward_power<VEC>(a, i, pen, a.tot_sum[a.E + e], (float)a.tot_max[e], signal_term(a, P, a.sig_old[e]),
+  store_reward_power<VEC>(a, i, pen, sum_pen, max_pen, signal_term(a, P, a.sig_old[e]),
                           (float)(a.sig_new[e] * a.inv_obs_norm), (float)(P * a.inv_obs_norm));
 }
 
