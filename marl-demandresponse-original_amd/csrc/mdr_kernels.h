@@ -113,6 +113,8 @@ struct ObsArgs {
   int64_t env_offset, house_offset;
   uint32_t k0, k1, episode;
   float defect_prob;
+  int lds_entries;          // sender entries staged per workgroup by k_obs_planes4 (set by the launcher)
+  uint32_t magic_n;         // ((1 << 20) + N - 1) / N: r / N == (r * magic_n) >> 20 for r < 1024 (set by the launcher)
   float obs_tshift;
   double inv_obs_norm;
   float inv_norm_reg, inv_cap, inv_Ua, inv_Cm, inv_Ca, inv_Hm, inv_COP, inv_latent;

@@ -1243,35 +1243,102 @@ __global__ __launch_bounds__(256) void k_obs_vector(ObsArgs a) {
                   [&](int m, int) { return sender_from_global(a, base + sender_id(a, h, m)); });
 }
 
-// ---- planes layout, N % 4 == 0: one workgroup per 1024 houses of one env, 4 houses per thread.  The senders'
-// message fields (tile + c halo houses, circular) are staged once in LDS, so HBM sees each state array once and
-// the 10x message fan-out happens in LDS; every feature plane is written with 16-byte stores.
-constexpr int OBS_PTILE = 1024;
+// A workgroup's share of the houses ("tile"): a TILE-house slice of one env when N >= TILE, or floor(TILE / N) WHOLE envs
+// when N < TILE (the agent counts the reference trains with are 20 and 50) so that small envs still fill the workgroup.
+// Senders are staged per env segment of (houses + c) entries - the segment's houses preceded / followed by their circular
+// neighbours - hence message slot m of tile row r always sits at  r + env_l * c + m + (m >= c/2)  with env_l = r / N.
+struct ObsTile {
+  int e0, nenv, h0, nh, rows;   // first env, envs in the tile, first house / houses per env segment, total rows
+};
 
-__global__ __launch_bounds__(256) void k_obs_planes4(ObsArgs a) {
+template <int TILE>
+__device__ __forceinline__ ObsTile obs_tile(const ObsArgs& a, int64_t id) {
+  ObsTile t;
+  if (a.N < TILE) {
+    const int epb = TILE / a.N;
+    t.e0 = (int)(id * epb);
+    t.nenv = min(epb, a.E - t.e0);
+    t.h0 = 0;
+    t.nh = a.N;
+    t.rows = t.nenv * a.N;
+  } else {
+    const int tpe = (a.N + TILE - 1) / TILE;
+    t.e0 = (int)(id / tpe);
+    t.h0 = (int)(id - (int64_t)t.e0 * tpe) * TILE;
+    t.nenv = 1;
+    t.nh = min(TILE, a.N - t.h0);
+    t.rows = t.nh;
+  }
+  return t;
+}
+
+template <int TILE>
+static int64_t obs_tile_count(int64_t E, int N) {
+  if (N < TILE) {
+    const int epb = TILE / N;
+    return (E + epb - 1) / epb;
+  }
+  return E * ((N + TILE - 1) / TILE);
+}
+
+// message fields of every env segment of the tile -> LDS.  FIELD_MAJOR: msg[field][entry] (planes kernel) or
+// entry-major msg[entry][field] (rows kernels).
+template <bool FIELD_MAJOR>
+__device__ __forceinline__ void stage_tile_senders(const ObsArgs& a, const ObsTile& t, float* msg, int entries, int mf, int tid,
+                                                   int nthreads) {
+  const int seg = t.nh + a.c;
+  const int before = a.c / 2;
+  for (int idx = tid; idx < t.nenv * seg; idx += nthreads) {
+    const int el = idx / seg;
+    const int p = idx - el * seg;
+    int j = (t.h0 - before + p) % a.N;
+    if (j < 0) j += a.N;
+    const MsgFields m = sender_from_global(a, (int64_t)(t.e0 + el) * a.N + j);
+    float v[11] = {m.diff, m.sso, m.curr, m.pmax, 0, 0, 0, 0, 0, 0, 0};
+    int q = 4;
+    if (a.m_thermal) {
+      v[q] = m.Ua; v[q + 1] = m.Cm; v[q + 2] = m.Ca; v[q + 3] = m.Hm;
+      q += 4;
+    }
+    if (a.m_hvac) {
+      v[q] = m.COP; v[q + 1] = m.latent; v[q + 2] = m.cap;
+    }
+    for (int k = 0; k < mf; ++k) msg[FIELD_MAJOR ? k * entries + idx : idx * mf + k] = v[k];
+  }
+}
+
+// ---- planes layout: VEC houses per thread (N % VEC == 0), up to 256 * VEC houses per workgroup.  The senders' message
+// fields are staged once in LDS, so HBM sees each state array once and the 10x message fan-out happens in LDS; every
+// feature plane is written with 4 * VEC-byte non-temporal stores.
+template <int VEC>
+__global__ __launch_bounds__(256) void k_obs_planes(ObsArgs a) {
+  constexpr int OBS_PTILE = 256 * VEC;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
-  const int e = blockIdx.y;
-  const int h0 = blockIdx.x * OBS_PTILE;
-  const int h = h0 + tid * 4;
-  const int64_t base = (int64_t)e * a.N;
-  const int span = OBS_PTILE + a.c;
+  const ObsTile t = obs_tile<OBS_PTILE>(a, blockIdx.x);
   const int before = a.c / 2;
+  const int mf = 4 + (a.m_thermal ? 4 : 0) + (a.m_hvac ? 3 : 0);
+  const int entries = a.lds_entries;   // nenv * (nh + c), computed by the launcher
   const bool staged = (a.links == nullptr);
   if (staged) {
-    stage_senders(a, base, h0 - before, min(span, a.N - h0 + a.c), span, lds, tid, 256);
+    stage_tile_senders<true>(a, t, lds, entries, mf, tid, 256);
     __syncthreads();
   }
-  if (h >= a.N) return;
+  const int r = tid * VEC;   // first of this thread's VEC tile rows (same env: N % VEC == 0)
+  if (r >= t.rows) return;
+  const int el = (t.nenv > 1) ? (int)(((uint32_t)r * a.magic_n) >> 20) : 0;
+  const int e = t.e0 + el;
+  const int h = t.h0 + r - el * a.N;
+  const int64_t i = (int64_t)e * a.N + h;
   int f = 0;
-  obs_features<4>(a, e, h, base + h,
+  obs_features<VEC>(a, e, h, i,
                   [&](const float* v) {
-                    store_out<4>(a.out + (int64_t)f * a.out_plane, base + h, v);
+                    store_out<VEC>(a.out + (int64_t)f * a.out_plane, i, v);
                     ++f;
                   },
                   [&](int m, int q) {
-                    if (!staged) return sender_from_global(a, base + sender_id(a, h + q, m));
-                    return sender_from_lds(a, lds, span, tid * 4 + q + m + (m >= before ? 1 : 0));
+                    if (!staged) return sender_from_global(a, (int64_t)e * a.N + sender_id(a, h + q, m));
+                    return sender_from_lds(a, lds, entries, r + q + el * a.c + m + (m >= before ? 1 : 0));
                   });
 }
 
@@ -1465,58 +1532,67 @@ __global__ __launch_bounds__(TILE) void k_obs_rows(ObsArgs a) {
 // ---- rows layout, the reference's DEFAULT observation (state_properties / message_properties all False, 10 circular
 // neighbours, no link defects): F = 11 + 10 * 4 = 51 is a compile-time constant, so element o of a tile maps to its LDS
 // source with a handful of integer ops: row r = o / 51, f = o % 51; own feature -> own[r][f]; message feature
-// g = f - 11 -> msg[4 (r + slot) + k] = msg[4 r + g + (g >= 20 ? 4 : 0)] (the sender list skips the house itself after
-// slot 4).  Same staging as k_obs_rows; ~1/3 fewer vector instructions per element.
+// g = f - 11 -> msg[4 (r + 10 env_l + slot) + k] = msg[4 (r + 10 env_l) + g + (g >= 20 ? 4 : 0)] (the sender list skips
+// the house itself after slot 4).  Only compact data is staged in LDS (own features, sender fields, 1 / lockout), the
+// output rows are generated directly in output order and streamed with 16-byte non-temporal stores.
 template <int TILE>
 __global__ __launch_bounds__(TILE) void k_obs_rows_default(ObsArgs a) {
   constexpr int OWN = 11, MF = 4, C = 10, F = OWN + C * MF, OWNP = 12;   // own row padded with 1 / lockout
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
-  const int e = blockIdx.y;
-  const int h0 = blockIdx.x * TILE;
-  const int h = h0 + tid;
-  const int nh = min(TILE, a.N - h0);
-  const int64_t base = (int64_t)e * a.N;
-  constexpr int span = TILE + C;
+  const ObsTile t = obs_tile<TILE>(a, blockIdx.x);
   float* ownbuf = lds;                 // [TILE][OWNP]
-  float* msg = lds + TILE * OWNP;      // [span][MF]
-  for (int idx = tid; idx < span; idx += TILE) {
-    int j = (h0 - C / 2 + idx) % a.N;
-    if (j < 0) j += a.N;
-    const MsgFields m = sender_from_global(a, base + j);
-    *reinterpret_cast<float4*>(msg + idx * MF) = make_float4(m.diff, m.sso, m.curr, m.pmax);
-  }
-  if (h < a.N) {
+  float* msg = lds + TILE * OWNP;      // [nenv * (nh + C)][MF]
+  stage_tile_senders<false>(a, t, msg, 0, MF, tid, TILE);
+  if (tid < t.rows) {
+    const int el = (t.nenv > 1) ? (int)(((uint32_t)tid * a.magic_n) >> 20) : 0;
+    const int e = t.e0 + el;
+    const int h = t.h0 + tid - el * a.N;
+    const int64_t i = (int64_t)e * a.N + h;
     int f = 0;
-    obs_features<1, false>(a, e, h, base + h, [&](const float* v) { ownbuf[tid * OWNP + f] = v[0]; ++f; },
+    obs_features<1, false>(a, e, h, i, [&](const float* v) { ownbuf[tid * OWNP + f] = v[0]; ++f; },
                            [&](int, int) { return MsgFields{}; });
-    ownbuf[tid * OWNP + OWN] = 1.0f / (float)a.lockout[base + h];
+    ownbuf[tid * OWNP + OWN] = 1.0f / (float)a.lockout[i];
   }
   __syncthreads();
-  float* dst = a.out + (base + h0) * F;
-  const int total = nh * F;
-  const bool vec = (((uintptr_t)dst) & 15u) == 0;
-  for (int o = tid * 4; o < total; o += TILE * 4) {
-    float v[4];
+  float* dst = a.out + ((int64_t)t.e0 * a.N + t.h0) * F;   // rows * F contiguous floats
+  const int total = t.rows * F;
+  // the tile's first byte is only 4-byte aligned in general (F is odd): start the 16-byte store grid at the next
+  // boundary; the up-to-3 leading floats are covered by the group at o = lead - 4 through the scalar branch below
+  const int lead = (int)(((16u - ((uint32_t)(uintptr_t)dst & 15u)) & 15u) >> 2);
+  const bool multi = t.nenv > 1;
+  auto element = [&](int oo) {
+    const int r = (int)(((uint32_t)oo * 20561u) >> 20);   // == oo / 51 for every oo < 13107 (checked exhaustively)
+    const int f = oo - r * F;
+    if (f < OWN) return ownbuf[r * OWNP + f];
+    const int g = f - OWN;
+    const int el = multi ? (int)(((uint32_t)r * a.magic_n) >> 20) : 0;
+    float val = msg[4 * (r + C * el) + g + (g >= 20 ? 4 : 0)];
+    if ((g & 3) == 1) val *= ownbuf[r * OWNP + OWN];   // sender's seconds_since_off over the RECEIVER's lockout
+    return val;
+  };
+  if (lead == 0) {   // aligned tile (always the case when N * F % 4 == 0): no edge handling inside the loop
+    for (int o = tid * 4; o < total; o += TILE * 4) {
+      float v[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int oo = min(o + q, total - 1);
-      const int r = (int)(((uint32_t)oo * 20561u) >> 20);   // == oo / 51 for every oo < 13107 (checked exhaustively)
-      const int f = oo - r * F;
-      float val;
-      if (f < OWN) {
-        val = ownbuf[r * OWNP + f];
+      for (int q = 0; q < 4; ++q) v[q] = element(min(o + q, total - 1));
+      if (o + 3 < total) {
+        store_out<4>(dst, o, v);
       } else {
-        const int g = f - OWN;
-        val = msg[4 * r + g + (g >= 20 ? 4 : 0)];
-        if ((g & 3) == 1) val *= ownbuf[r * OWNP + OWN];   // sender's seconds_since_off over the RECEIVER's lockout
+        for (int q = 0; q < 4 && o + q < total; ++q) dst[o + q] = v[q];
       }
-      v[q] = val;
     }
-    if (vec && o + 3 < total) {
-      store_out<4>(dst, o, v);
-    } else {
-      for (int q = 0; q < 4 && o + q < total; ++q) dst[o + q] = v[q];
+  } else {
+    for (int o = lead - 4 + tid * 4; o < total; o += TILE * 4) {
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = element(min(max(o + q, 0), total - 1));
+      if (o >= 0 && o + 3 < total) {
+        store_out<4>(dst, o, v);
+      } else {
+        for (int q = 0; q < 4; ++q)
+          if (o + q >= 0 && o + q < total) dst[o + q] = v[q];
+      }
     }
   }
 }
@@ -1538,20 +1614,32 @@ static hipError_t launch_with_lds(K kernel, dim3 g, dim3 b, size_t lds_bytes, hi
   return hipGetLastError();
 }
 
-hipError_t launch_obs_vector(const ObsArgs& a, int layout, hipStream_t s) {
+hipError_t launch_obs_vector(const ObsArgs& a_in, int layout, hipStream_t s) {
+  ObsArgs a = a_in;
+  a.magic_n = (uint32_t)(((1u << 20) + (uint32_t)a.N - 1u) / (uint32_t)a.N);   // r / N == (r * magic) >> 20 for r < 1024, N <= 1024
   const size_t nf = 4 + (a.m_thermal ? 4 : 0) + (a.m_hvac ? 3 : 0);
   const size_t lds_cap = 160 * 1024;
+  const bool circular = a.links == nullptr && a.N > a.c;   // every sender is a distinct circular neighbour
+  if (layout == MDR_OBS_PLANES && (((uintptr_t)a.out) & 15u) == 0 && a.out_plane % 4 == 0) {
+    const int vec = a.N % 4 == 0 ? 4 : (a.N % 2 == 0 ? 2 : 1);
+    const int ptile = 256 * vec;
+    a.lds_entries = a.N < ptile ? (ptile / a.N) * (a.N + a.c) : ptile + a.c;
+    const size_t lds_bytes = a.links == nullptr ? nf * (size_t)a.lds_entries * sizeof(float) : 16;
+    const int64_t tiles = vec == 4 ? obs_tile_count<1024>(a.E, a.N) : (vec == 2 ? obs_tile_count<512>(a.E, a.N) : obs_tile_count<256>(a.E, a.N));
+    if (lds_bytes <= lds_cap && tiles < (int64_t)1 << 31) {
+      if (vec == 4) return launch_with_lds(k_obs_planes<4>, dim3((unsigned)tiles), dim3(256), lds_bytes, s, a);
+      if (vec == 2) return launch_with_lds(k_obs_planes<2>, dim3((unsigned)tiles), dim3(256), lds_bytes, s, a);
+      return launch_with_lds(k_obs_planes<1>, dim3((unsigned)tiles), dim3(256), lds_bytes, s, a);
+    }
+  }
+  if (layout == MDR_OBS_ROWS && circular && a.c == 10 && a.F == 51 && a.defect_prob <= 0.0f) {
+    constexpr int RT = 256;   // 256 * 51 = 13056 < 13107: the kernel's mul-shift division is exact
+    const size_t lds_bytes = (RT * 12 + (RT + (RT / 11) * 10) * 4) * sizeof(float);   // N >= 11: at most RT / 11 env segments
+    const int64_t tiles = obs_tile_count<RT>(a.E, a.N);
+    if (tiles < (int64_t)1 << 31)
+      return launch_with_lds(k_obs_rows_default<RT>, dim3((unsigned)tiles), dim3(RT), lds_bytes, s, a);
+  }
   if (a.E <= 65535) {
-    if (layout == MDR_OBS_PLANES && a.N % 4 == 0 && (((uintptr_t)a.out) & 15u) == 0 && a.out_plane % 4 == 0) {
-      const size_t lds_bytes = nf * (OBS_PTILE + a.c) * sizeof(float);
-      if (lds_bytes <= lds_cap)
-        return launch_with_lds(k_obs_planes4, dim3((unsigned)((a.N + OBS_PTILE - 1) / OBS_PTILE), (unsigned)a.E), dim3(256), lds_bytes, s, a);
-    }
-    if (layout == MDR_OBS_ROWS && a.links == nullptr && a.c == 10 && a.F == 51 && a.defect_prob <= 0.0f && a.N >= 11) {
-      constexpr int RT = 256;   // 256 * 51 = 13056 < 13107: the kernel's mul-shift division is exact
-      const size_t lds_bytes = (RT * 12 + (RT + 10) * 4) * sizeof(float);
-      return launch_with_lds(k_obs_rows_default<RT>, dim3((unsigned)((a.N + RT - 1) / RT), (unsigned)a.E), dim3(RT), lds_bytes, s, a);
-    }
     if (layout == MDR_OBS_ROWS && a.links == nullptr && a.c <= 32 && (a.c + 1) * (int)nf < 65536) {
       constexpr int RT = 256;
       const size_t own = (size_t)(a.F - a.c * (int)nf) | 1;

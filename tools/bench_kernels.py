@@ -65,6 +65,16 @@ def main():
         report("C3 obs_vector planes F=%d" % F, timeit(lambda: env.obs_vector("planes"), 20), 4096 * 1024, 4 * F + 25)
         report("C3 obs_vector rows F=%d" % F, timeit(lambda: env.obs_vector("rows"), 20), 4096 * 1024, 4 * F + 25)
         del env
+    if "obs_small" in what:
+        for (E, N) in ((209715, 20), (83886, 50), (32768, 128)):
+            env = mdr_amd.BatchedDemandResponseEnv(cfg_for(N), nb_envs=E, seed=1)
+            env.reset()
+            env.rollout(3)
+            F = env.obs_vector_length()
+            report("obs_vector planes %dx%d F=%d" % (E, N, F), timeit(lambda: env.obs_vector("planes"), 10), E * N, 4 * F + 25)
+            report("obs_vector rows %dx%d F=%d" % (E, N, F), timeit(lambda: env.obs_vector("rows"), 10), E * N, 4 * F + 25)
+            del env
+            torch.cuda.empty_cache()
     if "c2" in what:
         env = mdr_amd.BatchedDemandResponseEnv(cfg_for(50), nb_envs=1024, seed=1)
         env.reset()
