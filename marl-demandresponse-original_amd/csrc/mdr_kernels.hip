@@ -1350,8 +1350,9 @@ template <int LAYOUT, int TILE>
 __global__ __launch_bounds__(TILE) void k_obs_tiled(ObsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
-  const int e = blockIdx.y;
-  const int h0 = blockIdx.x * TILE;
+  const int tpe = (a.N + TILE - 1) / TILE;              // 1-D grid: tile id -> (env, first house)
+  const int e = (int)(blockIdx.x / (unsigned)tpe);
+  const int h0 = (int)(blockIdx.x - (unsigned)e * (unsigned)tpe) * TILE;
   const int h = h0 + tid;
   const int nh = min(TILE, a.N - h0);
   const int64_t base = (int64_t)e * a.N;
@@ -1426,8 +1427,9 @@ template <int TILE>
 __global__ __launch_bounds__(TILE) void k_obs_rows(ObsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
-  const int e = blockIdx.y;
-  const int h0 = blockIdx.x * TILE;
+  const int tpe = (a.N + TILE - 1) / TILE;              // 1-D grid: tile id -> (env, first house)
+  const int e = (int)(blockIdx.x / (unsigned)tpe);
+  const int h0 = (int)(blockIdx.x - (unsigned)e * (unsigned)tpe) * TILE;
   const int h = h0 + tid;
   const int nh = min(TILE, a.N - h0);
   const int64_t base = (int64_t)e * a.N;
@@ -1639,19 +1641,21 @@ hipError_t launch_obs_vector(const ObsArgs& a_in, int layout, hipStream_t s) {
     if (tiles < (int64_t)1 << 31)
       return launch_with_lds(k_obs_rows_default<RT>, dim3((unsigned)tiles), dim3(RT), lds_bytes, s, a);
   }
-  if (a.E <= 65535) {
-    if (layout == MDR_OBS_ROWS && a.links == nullptr && a.c <= 32 && (a.c + 1) * (int)nf < 65536) {
-      constexpr int RT = 256;
-      const size_t own = (size_t)(a.F - a.c * (int)nf) | 1;
-      const size_t lds_bytes = (RT * own + (RT + a.c) * nf + 2 * RT + a.F) * sizeof(float);
-      if (lds_bytes <= lds_cap)
-        return launch_with_lds(k_obs_rows<RT>, dim3((unsigned)((a.N + RT - 1) / RT), (unsigned)a.E), dim3(RT), lds_bytes, s, a);
-    }
+  if (layout == MDR_OBS_ROWS && a.links == nullptr && a.c <= 32 && (a.c + 1) * (int)nf < 65536) {
+    constexpr int RT = 256;
+    const size_t own = (size_t)(a.F - a.c * (int)nf) | 1;
+    const size_t lds_bytes = (RT * own + (RT + a.c) * nf + 2 * RT + a.F) * sizeof(float);
+    const int64_t tiles = a.E * (int64_t)((a.N + RT - 1) / RT);
+    if (lds_bytes <= lds_cap && tiles < (int64_t)1 << 31)
+      return launch_with_lds(k_obs_rows<RT>, dim3((unsigned)tiles), dim3(RT), lds_bytes, s, a);
+  }
+  {
     constexpr int TILE = 64;
     const size_t chunk = (layout == MDR_OBS_ROWS) ? (size_t)TILE * (a.F | 1) : (size_t)a.F * TILE;
     const size_t lds_bytes = (chunk + nf * (TILE + a.c)) * sizeof(float);
-    if (lds_bytes <= lds_cap) {
-      const dim3 g((unsigned)((a.N + TILE - 1) / TILE), (unsigned)a.E), b(TILE);
+    const int64_t tiles = a.E * (int64_t)((a.N + TILE - 1) / TILE);
+    if (lds_bytes <= lds_cap && tiles < (int64_t)1 << 31) {
+      const dim3 g((unsigned)tiles), b(TILE);
       if (layout == MDR_OBS_ROWS) return launch_with_lds(k_obs_tiled<MDR_OBS_ROWS, TILE>, g, b, lds_bytes, s, a);
       return launch_with_lds(k_obs_tiled<MDR_OBS_PLANES, TILE>, g, b, lds_bytes, s, a);
     }
