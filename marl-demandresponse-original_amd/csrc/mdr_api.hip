@@ -322,6 +322,10 @@ int mdr_env_create(const mdr_config_t* config, mdr_env_t** out) {
   *out = env;  // returned even on failure so that mdr_last_error() can explain; caller destroys it
   if (!msg.empty()) return MDR_ERR_INVALID;
   env->plan = mdr::plan_step(config->nb_houses, config->nb_envs);
+  if ((env->plan.kind == mdr::STEP_SPLIT || config->nb_houses_total != config->nb_houses) && config->nb_envs > 65535) {
+    env->err = "the split / sharded step path puts the env index on grid.y: nb_envs must be <= 65535 there";
+    return MDR_ERR_UNSUPPORTED;
+  }
   env->rollout_plan = mdr::plan_rollout(config->nb_houses, config->nb_envs);
   env->nblk = mdr::split_blocks(config->nb_houses);
   return MDR_OK;
