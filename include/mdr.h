@@ -197,6 +197,8 @@ int64_t mdr_partials_per_env(int32_t nb_houses);
 /* MADemandResponseEnv.__init__ (env 73-96) minus build_environment: validates and stores the config. */
 int mdr_env_create(const mdr_config_t *config, mdr_env_t **out);
 int mdr_env_destroy(mdr_env_t *env);
+/* Hands the library the caller's device buffers: they stand where the reference keeps its Python object graph
+ * (ClusterHouses.houses[*] / .hvac, env/MA_DemandResponse.py:776-780). */
 int mdr_env_bind(mdr_env_t *env, const mdr_buffers_t *buffers);
 
 /* build_environment, part 1 (env 98-123; utils.applyPropertyNoise 573-709): sample every per-house and
@@ -207,7 +209,7 @@ int mdr_env_reset(mdr_env_t *env, uint64_t seed, uint32_t episode, void *stream)
 /* Same, but from caller-supplied raw parameters instead of sampling. */
 int mdr_env_load_episode(mdr_env_t *env, const mdr_episode_t *episode, uint64_t seed, uint32_t episode_index,
                          void *stream);
-/* Optional: replace the modelled outdoor temperature by a table, double [rows][E] deg C (row = time index);
+/* Optional: replace ClusterHouses.compute_OD_temp (env 1057-1081, incl. its random.gauss draw 1079) by a table, double [rows][E] deg C (row = time index);
  * NULL restores the model.  Takes effect at the next mdr_env_begin_episode / table refill. */
 int mdr_env_set_od_table(mdr_env_t *env, const double *od_table, int64_t rows);
 /* The 10-D bang-bang average-power grid of monteCarlo/ (PowerInterpolator, monteCarlo/interpolation.py:21-47).
@@ -234,7 +236,8 @@ int mdr_env_begin_episode(mdr_env_t *env, void *stream);
 
 /* MADemandResponseEnv.step (env 174-210), whole step on this device. */
 int mdr_env_step(mdr_env_t *env, uint8_t *actions, int action_source, void *stream);
-/* `nb_steps` consecutive steps without returning to the host (device-resident rollout). */
+/* `nb_steps` consecutive steps without returning to the host: the `for i in range(nb_time_steps)` loop of
+ * main-deploy.py:99-104 (one launch per step; see mdr_env_rollout_fused for the in-register form). */
 int mdr_env_rollout(mdr_env_t *env, uint8_t *actions, int action_source, int32_t nb_steps, void *stream);
 
 /* Device-resident closed-loop rollout: `nb_steps` consecutive env steps with the bang-bang rule in ONE launch per
@@ -255,7 +258,8 @@ typedef struct mdr_rollout_out {
  * for sharded houses: use mdr_env_rollout there. */
 int mdr_env_rollout_fused(mdr_env_t *env, uint8_t *actions, int32_t nb_steps, const mdr_rollout_out_t *out, void *stream);
 
-/* Sharded houses (one env spans several devices): step_begin updates the local houses and leaves the local
+/* Sharded houses (one env spans several devices).  Houses interact only through the cluster power sum (env 1042-1050)
+ * and the common penalty sum / max (env 274-321): step_begin updates the local houses and leaves the local
  * reductions in tot_sum/tot_max; the caller all-reduces them (SUM / MAX); step_end writes rewards and the
  * two power observation columns from the reduced values. */
 int mdr_env_step_begin(mdr_env_t *env, uint8_t *actions, int action_source, void *stream);
@@ -272,9 +276,11 @@ int mdr_env_step_end_gathered(mdr_env_t *env, const double *gathered, int32_t wo
 int32_t mdr_obs_vector_length(const mdr_obs_spec_t *spec);
 int mdr_env_obs_vector(mdr_env_t *env, const mdr_obs_spec_t *spec, float *out, void *stream);
 
-/* Cursor: k = number of steps taken this episode; j0 = time index of table row 0. */
+/* Cursor: k = number of steps taken this episode (env.datetime == start_datetime + k * time_step, env 189);
+ * j0 = time index of table row 0. */
 int mdr_env_cursor(const mdr_env_t *env, int64_t *k, int64_t *j0);
-/* Re-create a cursor on a new handle whose buffers were cloned from another env (copy.deepcopy support). */
+/* Re-create a cursor on a new handle whose buffers were cloned from another env: copy.deepcopy(env) as
+ * utils.test_*_agent use it (utils.py:890, 931, 970, 1008). */
 int mdr_env_set_cursor(mdr_env_t *env, uint64_t seed, uint32_t episode, int64_t k, int64_t j0);
 
 #ifdef __cplusplus
