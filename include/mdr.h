@@ -179,6 +179,9 @@ typedef struct mdr_obs_spec {
   int32_t nb_comm;                 /* messages per house: min(nb_agents_comm, nb_agents - 1), env 808-810 */
   const int32_t *links;            /* device int32 [N][nb_comm] sender ids (ClusterHouses.agent_communicators,
                                       env 806-902), shared by all envs; NULL = circular "neighbours" (816-828) */
+  int32_t random_links;            /* agents_comm_mode "random_sample" (env 976-983): every house draws nb_comm distinct
+                                      senders among the others anew at every step (`links` is ignored) */
+  int32_t reserved0;
   double comm_defect_prob;         /* per-link probability of an all-zero message (env 992-1002) */
   int64_t out_plane_stride;        /* MDR_OBS_PLANES: elements between feature planes; 0 = nb_envs * nb_houses.  A stride
                                       that is not a multiple of 2 MiB keeps the F concurrently written planes off one HBM channel */

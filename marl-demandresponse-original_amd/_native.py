@@ -90,6 +90,7 @@ class MdrObsSpec(C.Structure):
         ("message_thermal", C.c_int32), ("message_hvac", C.c_int32),
         ("nb_comm", C.c_int32),
         ("links", _i32p),
+        ("random_links", C.c_int32), ("reserved0", C.c_int32),
         ("comm_defect_prob", C.c_double),
         ("out_plane_stride", C.c_int64),
         ("def_Ua", C.c_double), ("def_Cm", C.c_double), ("def_Ca", C.c_double), ("def_Hm", C.c_double),

@@ -373,16 +373,15 @@ class BatchedDemandResponseEnv:
         spec.message_thermal, spec.message_hvac = int(mp["thermal"]), int(mp["hvac"])
         spec.nb_comm = nb_comm(cluster)
         mode = cluster["agents_comm_mode"]
-        if mode == "random_sample":
-            raise ValueError("agents_comm_mode 'random_sample' re-draws its links every step and has no batched form; "
-                             "use the dict adapter or a fixed topology")
+        if mode == "random_sample":      # senders re-drawn per house and step on the device (env 976-983)
+            spec.random_links = 1
         if mode == "no_message":
             spec.nb_comm = 0
-        if getattr(self, "_links_dev", None) is None and mode not in ("neighbours", "no_message"):
+        if getattr(self, "_links_dev", None) is None and mode not in ("neighbours", "no_message", "random_sample"):
             links = build_comm_links(cluster)
             table = np.array([links[i] for i in range(self.nb_agents)], dtype=np.int32).reshape(self.nb_agents, -1)
             self._links_dev = torch.from_numpy(table).to(self.device)
-        if mode not in ("neighbours", "no_message") or getattr(self, "_links_forced", False):
+        if mode not in ("neighbours", "no_message", "random_sample") or getattr(self, "_links_forced", False):
             spec.nb_comm = int(self._links_dev.shape[1])
             spec.links = self._links_dev.data_ptr() if spec.nb_comm > 0 else None
         spec.comm_defect_prob = float(cluster["comm_defect_prob"])

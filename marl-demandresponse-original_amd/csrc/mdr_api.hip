@@ -527,6 +527,7 @@ int mdr_env_obs_vector(mdr_env_t* env, const mdr_obs_spec_t* spec, float* out, v
   if (spec->layout != MDR_OBS_PLANES && spec->layout != MDR_OBS_ROWS) return fail(env, MDR_ERR_INVALID, "unknown obs layout");
   if (spec->nb_comm < 0 || spec->nb_comm > c.nb_houses - 1 + (c.nb_houses == 1 ? 1 : 0) || (c.nb_houses == 1 && spec->nb_comm != 0))
     return fail(env, MDR_ERR_INVALID, "nb_comm must be in [0, nb_houses - 1]");
+  if (spec->random_links && spec->nb_comm > 16) return fail(env, MDR_ERR_UNSUPPORTED, "random_sample links support nb_comm <= 16");
   if (!(spec->comm_defect_prob >= 0.0 && spec->comm_defect_prob <= 1.0)) return fail(env, MDR_ERR_INVALID, "comm_defect_prob outside [0, 1]");
   if (!(spec->def_Ua > 0 && spec->def_Cm > 0 && spec->def_Ca > 0 && spec->def_Hm > 0 && spec->def_COP > 0 && spec->def_capacity > 0 &&
         spec->def_latent > 0 && spec->norm_reg_sig > 0))
@@ -542,7 +543,8 @@ int mdr_env_obs_vector(mdr_env_t* env, const mdr_obs_spec_t* spec, float* out, v
   a.od_now = b.tab_od + row * c.nb_envs;
   a.solar_now = b.tab_solar + row * c.nb_envs;
   a.t0 = b.t0;
-  a.links = spec->links;
+  a.links = spec->random_links ? nullptr : spec->links;
+  a.random_links = spec->random_links ? 1 : 0;
   a.out = out;
   a.plane = (int64_t)c.nb_envs * c.nb_houses;
   a.out_plane = spec->out_plane_stride > 0 ? spec->out_plane_stride : a.plane;

@@ -21,6 +21,7 @@ enum : uint32_t {
   TAG_OD_NOISE = 5,      // item = time index ; x0,x1 -> gauss
   TAG_PERLIN = 6,        // item = lattice index ; x0 -> gradient
   TAG_COMM = 7,          // item = house ; counter word 2 = time index ; x0..x3 -> link defects (4 links per draw)
+  TAG_LINKS = 9,         // item = house ; counter word 2 = time index ; x0..x3 -> round keys of the sender permutation
   TAG_INTERP = 8,        // item = draw index ; counter word 2 = time index ; tag | episode << 8 ; x0 -> sampled house
   ENV_LEVEL = 0xFFFFFFFFu
 };

@@ -104,6 +104,7 @@ struct ObsArgs {
   const float *od_now, *solar_now;
   const int64_t* t0;
   const int32_t* links;     // [N][c] or nullptr (circular neighbours)
+  int random_links;         // senders re-drawn per house and step (agents_comm_mode random_sample)
   float* out;
   int64_t plane;            // E * N
   int64_t out_plane;        // stride between output feature planes (>= plane)

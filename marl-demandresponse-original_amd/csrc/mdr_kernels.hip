@@ -1060,7 +1060,45 @@ __device__ __forceinline__ MsgFields sender_from_global(const ObsArgs& a, int64_
   return m;
 }
 
-// sender id of message slot m of house h: link table, or circular neighbours (env 816-828)
+// agents_comm_mode "random_sample" (env 976-983): random.sample(others, k = nb_comm) per house and step, i.e. an
+// ordered draw without replacement.  Exactly that, by rejection: slot m takes uniform draws among the N - 1 other
+// houses (TAG_LINKS Philox stream of (env, house, time index), 4 draws per block) until one is not among the m senders
+// already chosen.  The chosen list lives in registers (nb_comm <= 16), all indexing is static.
+constexpr int MAX_RANDOM_LINKS = 16;
+
+struct LinkSampler {
+  int prev[MAX_RANDOM_LINKS];
+  int count = 0, draws = 0;
+  u32x4 buf{0, 0, 0, 0};
+
+  __device__ __forceinline__ int next(const ObsArgs& a, int e, int h) {
+    const uint32_t D = (uint32_t)(a.N - 1);   // >= nb_comm >= 1
+    int pick;
+    bool taken;
+    do {
+      if ((draws & 3) == 0)
+        buf = philox4x32_10((uint32_t)(e + a.env_offset), (uint32_t)(h + a.house_offset), (uint32_t)a.k,
+                            TAG_LINKS | ((uint32_t)(draws >> 2) << 8), a.k0, a.k1 ^ (a.episode * 0x85EBCA6Bu));
+      const uint32_t x = (draws & 3) == 0 ? buf.x : (draws & 3) == 1 ? buf.y : (draws & 3) == 2 ? buf.z : buf.w;
+      ++draws;
+      pick = (int)mulhi_pick(x, D);
+      taken = false;
+#pragma unroll
+      for (int t = 0; t < MAX_RANDOM_LINKS; ++t) taken = taken || (t < count && prev[t] == pick);
+    } while (taken);
+#pragma unroll
+    for (int t = 0; t < MAX_RANDOM_LINKS; ++t)
+      if (t == count) prev[t] = pick;
+    ++count;
+    return pick < h ? pick : pick + 1;   // index among the OTHER houses -> house id
+  }
+};
+
+struct NoSampler {   // stands in for LinkSampler in the instantiations without random links: no registers, never called
+  __device__ __forceinline__ int next(const ObsArgs&, int, int) { return 0; }
+};
+
+// sender id of message slot m of house h: link table, or circular neighbours (env 816-828); random_sample: LinkSampler
 __device__ __forceinline__ int sender_id(const ObsArgs& a, int h, int m) {
   if (a.links != nullptr) return a.links[(int64_t)h * a.c + m];
   const int before = a.c / 2;
@@ -1226,7 +1264,7 @@ __device__ __forceinline__ MsgFields sender_from_lds(const ObsArgs& a, const flo
 }
 
 // ---- simple form: one thread per house, direct (4-byte) stores; fallback for shapes the other kernels cannot hold
-template <int LAYOUT>
+template <int LAYOUT, bool RANDOM>
 __global__ __launch_bounds__(256) void k_obs_vector(ObsArgs a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.plane) return;
@@ -1234,13 +1272,14 @@ __global__ __launch_bounds__(256) void k_obs_vector(ObsArgs a) {
   const int h = (int)(i - (int64_t)e * a.N);
   const int64_t base = (int64_t)e * a.N;
   int f = 0;
+  typename std::conditional<RANDOM, LinkSampler, NoSampler>::type smp;
   obs_features<1>(a, e, h, i,
                   [&](const float* v) {
                     if (LAYOUT == MDR_OBS_PLANES) a.out[(int64_t)f * a.out_plane + i] = v[0];
                     else a.out[i * a.F + f] = v[0];
                     ++f;
                   },
-                  [&](int m, int) { return sender_from_global(a, base + sender_id(a, h, m)); });
+                  [&](int m, int) { return sender_from_global(a, base + (RANDOM ? smp.next(a, e, h) : sender_id(a, h, m))); });
 }
 
 // A workgroup's share of the houses ("tile"): a TILE-house slice of one env when N >= TILE, or floor(TILE / N) WHOLE envs
@@ -1310,7 +1349,7 @@ __device__ __forceinline__ void stage_tile_senders(const ObsArgs& a, const ObsTi
 // ---- planes layout: VEC houses per thread (N % VEC == 0), up to 256 * VEC houses per workgroup.  The senders' message
 // fields are staged once in LDS, so HBM sees each state array once and the 10x message fan-out happens in LDS; every
 // feature plane is written with 4 * VEC-byte non-temporal stores.
-template <int VEC>
+template <int VEC, bool RANDOM>
 __global__ __launch_bounds__(256) void k_obs_planes(ObsArgs a) {
   constexpr int OBS_PTILE = 256 * VEC;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1319,7 +1358,7 @@ __global__ __launch_bounds__(256) void k_obs_planes(ObsArgs a) {
   const int before = a.c / 2;
   const int mf = 4 + (a.m_thermal ? 4 : 0) + (a.m_hvac ? 3 : 0);
   const int entries = a.lds_entries;   // nenv * (nh + c), computed by the launcher
-  const bool staged = (a.links == nullptr);
+  const bool staged = (a.links == nullptr) && !a.random_links;
   if (staged) {
     stage_tile_senders<true>(a, t, lds, entries, mf, tid, 256);
     __syncthreads();
@@ -1331,13 +1370,14 @@ __global__ __launch_bounds__(256) void k_obs_planes(ObsArgs a) {
   const int h = t.h0 + r - el * a.N;
   const int64_t i = (int64_t)e * a.N + h;
   int f = 0;
+  typename std::conditional<RANDOM, LinkSampler, NoSampler>::type smp[VEC];
   obs_features<VEC>(a, e, h, i,
                   [&](const float* v) {
                     store_out<VEC>(a.out + (int64_t)f * a.out_plane, i, v);
                     ++f;
                   },
                   [&](int m, int q) {
-                    if (!staged) return sender_from_global(a, (int64_t)e * a.N + sender_id(a, h + q, m));
+                    if (!staged) return sender_from_global(a, (int64_t)e * a.N + (RANDOM ? smp[q].next(a, e, h + q) : sender_id(a, h + q, m)));
                     return sender_from_lds(a, lds, entries, r + q + el * a.c + m + (m >= before ? 1 : 0));
                   });
 }
@@ -1346,7 +1386,7 @@ __global__ __launch_bounds__(256) void k_obs_planes(ObsArgs a) {
 //  (1) sender fields staged in LDS as above; (2) every thread builds its house's F features into an LDS chunk laid
 //  out like the OUTPUT tile; (3) the chunk is streamed out with 16-byte stores: rows -> one contiguous TILE*F-float
 //  block, planes -> F rows of TILE floats.  TILE = 64 keeps a workgroup at one wavefront (LDS ~13 KB at F = 51).
-template <int LAYOUT, int TILE>
+template <int LAYOUT, int TILE, bool RANDOM>
 __global__ __launch_bounds__(TILE) void k_obs_tiled(ObsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -1361,20 +1401,21 @@ __global__ __launch_bounds__(TILE) void k_obs_tiled(ObsArgs a) {
   float* msg = lds + ((LAYOUT == MDR_OBS_ROWS) ? TILE * Fp : a.F * TILE);
   const int span = TILE + a.c;
   const int before = a.c / 2;
-  const bool staged = (a.links == nullptr);
+  const bool staged = (a.links == nullptr) && !a.random_links;
   if (staged) {
     stage_senders(a, base, h0 - before, span, span, msg, tid, TILE);
     __syncthreads();
   }
   if (h < a.N) {
     int f = 0;
+    typename std::conditional<RANDOM, LinkSampler, NoSampler>::type smp;
     obs_features<1>(a, e, h, base + h,
                     [&](const float* v) {
                       chunk[(LAYOUT == MDR_OBS_ROWS) ? tid * Fp + f : f * TILE + tid] = v[0];
                       ++f;
                     },
                     [&](int m, int) {
-                      if (!staged) return sender_from_global(a, base + sender_id(a, h, m));
+                      if (!staged) return sender_from_global(a, base + (RANDOM ? smp.next(a, e, h) : sender_id(a, h, m)));
                       return sender_from_lds(a, msg, span, tid + m + (m >= before ? 1 : 0));
                     });
   }
@@ -1621,17 +1662,23 @@ hipError_t launch_obs_vector(const ObsArgs& a_in, int layout, hipStream_t s) {
   a.magic_n = (uint32_t)(((1u << 20) + (uint32_t)a.N - 1u) / (uint32_t)a.N);   // r / N == (r * magic) >> 20 for r < 1024, N <= 1024
   const size_t nf = 4 + (a.m_thermal ? 4 : 0) + (a.m_hvac ? 3 : 0);
   const size_t lds_cap = 160 * 1024;
-  const bool circular = a.links == nullptr && a.N > a.c;   // every sender is a distinct circular neighbour
+  const bool circular = a.links == nullptr && !a.random_links && a.N > a.c;   // every sender is a distinct circular neighbour
   if (layout == MDR_OBS_PLANES && (((uintptr_t)a.out) & 15u) == 0 && a.out_plane % 4 == 0) {
     const int vec = a.N % 4 == 0 ? 4 : (a.N % 2 == 0 ? 2 : 1);
     const int ptile = 256 * vec;
     a.lds_entries = a.N < ptile ? (ptile / a.N) * (a.N + a.c) : ptile + a.c;
-    const size_t lds_bytes = a.links == nullptr ? nf * (size_t)a.lds_entries * sizeof(float) : 16;
+    const size_t lds_bytes = (a.links == nullptr && !a.random_links) ? nf * (size_t)a.lds_entries * sizeof(float) : 16;
     const int64_t tiles = vec == 4 ? obs_tile_count<1024>(a.E, a.N) : (vec == 2 ? obs_tile_count<512>(a.E, a.N) : obs_tile_count<256>(a.E, a.N));
     if (lds_bytes <= lds_cap && tiles < (int64_t)1 << 31) {
-      if (vec == 4) return launch_with_lds(k_obs_planes<4>, dim3((unsigned)tiles), dim3(256), lds_bytes, s, a);
-      if (vec == 2) return launch_with_lds(k_obs_planes<2>, dim3((unsigned)tiles), dim3(256), lds_bytes, s, a);
-      return launch_with_lds(k_obs_planes<1>, dim3((unsigned)tiles), dim3(256), lds_bytes, s, a);
+      const dim3 g((unsigned)tiles), b(256);
+      if (a.random_links) {
+        if (vec == 4) return launch_with_lds(k_obs_planes<4, true>, g, b, lds_bytes, s, a);
+        if (vec == 2) return launch_with_lds(k_obs_planes<2, true>, g, b, lds_bytes, s, a);
+        return launch_with_lds(k_obs_planes<1, true>, g, b, lds_bytes, s, a);
+      }
+      if (vec == 4) return launch_with_lds(k_obs_planes<4, false>, g, b, lds_bytes, s, a);
+      if (vec == 2) return launch_with_lds(k_obs_planes<2, false>, g, b, lds_bytes, s, a);
+      return launch_with_lds(k_obs_planes<1, false>, g, b, lds_bytes, s, a);
     }
   }
   if (layout == MDR_OBS_ROWS && circular && a.c == 10 && a.F == 51 && a.defect_prob <= 0.0f) {
@@ -1641,7 +1688,7 @@ hipError_t launch_obs_vector(const ObsArgs& a_in, int layout, hipStream_t s) {
     if (tiles < (int64_t)1 << 31)
       return launch_with_lds(k_obs_rows_default<RT>, dim3((unsigned)tiles), dim3(RT), lds_bytes, s, a);
   }
-  if (layout == MDR_OBS_ROWS && a.links == nullptr && a.c <= 32 && (a.c + 1) * (int)nf < 65536) {
+  if (layout == MDR_OBS_ROWS && circular && a.c <= 32 && (a.c + 1) * (int)nf < 65536) {
     constexpr int RT = 256;
     const size_t own = (size_t)(a.F - a.c * (int)nf) | 1;
     const size_t lds_bytes = (RT * own + (RT + a.c) * nf + 2 * RT + a.F) * sizeof(float);
@@ -1656,15 +1703,22 @@ hipError_t launch_obs_vector(const ObsArgs& a_in, int layout, hipStream_t s) {
     const int64_t tiles = a.E * (int64_t)((a.N + TILE - 1) / TILE);
     if (lds_bytes <= lds_cap && tiles < (int64_t)1 << 31) {
       const dim3 g((unsigned)tiles), b(TILE);
-      if (layout == MDR_OBS_ROWS) return launch_with_lds(k_obs_tiled<MDR_OBS_ROWS, TILE>, g, b, lds_bytes, s, a);
-      return launch_with_lds(k_obs_tiled<MDR_OBS_PLANES, TILE>, g, b, lds_bytes, s, a);
+      if (a.random_links) {
+        if (layout == MDR_OBS_ROWS) return launch_with_lds(k_obs_tiled<MDR_OBS_ROWS, TILE, true>, g, b, lds_bytes, s, a);
+        return launch_with_lds(k_obs_tiled<MDR_OBS_PLANES, TILE, true>, g, b, lds_bytes, s, a);
+      }
+      if (layout == MDR_OBS_ROWS) return launch_with_lds(k_obs_tiled<MDR_OBS_ROWS, TILE, false>, g, b, lds_bytes, s, a);
+      return launch_with_lds(k_obs_tiled<MDR_OBS_PLANES, TILE, false>, g, b, lds_bytes, s, a);
     }
   }
   const dim3 g((unsigned)((a.plane + 255) / 256)), b(256);
-  if (layout == MDR_OBS_PLANES)
-    hipLaunchKernelGGL(k_obs_vector<MDR_OBS_PLANES>, g, b, 0, s, a);
-  else
-    hipLaunchKernelGGL(k_obs_vector<MDR_OBS_ROWS>, g, b, 0, s, a);
+  if (a.random_links) {
+    if (layout == MDR_OBS_PLANES) hipLaunchKernelGGL((k_obs_vector<MDR_OBS_PLANES, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_obs_vector<MDR_OBS_ROWS, true>), g, b, 0, s, a);
+  } else {
+    if (layout == MDR_OBS_PLANES) hipLaunchKernelGGL((k_obs_vector<MDR_OBS_PLANES, false>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_obs_vector<MDR_OBS_ROWS, false>), g, b, 0, s, a);
+  }
   return hipGetLastError();
 }
 

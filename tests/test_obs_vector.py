@@ -113,3 +113,39 @@ def test_comm_defects_zero_whole_messages_at_the_configured_rate():
     env.rollout(1)
     dead2 = env.obs_vector("rows")[..., 11:].reshape(64, 256, 10, 4)[..., 3] == 0
     assert not torch.equal(dead, dead2)
+
+
+@pytest.mark.gpu
+def test_random_sample_links_are_distinct_uniform_and_redrawn():
+    """agents_comm_mode='random_sample' (env 976-983): nb_comm distinct senders among the other houses, uniformly,
+    anew at every step - checked through the sender's hvac_max_consumption column, made unique per house."""
+    import torch
+    import mdr_amd
+    from scipy import stats
+    N, E, c = 40, 512, 10
+    cfg = mdr_amd.default_config()
+    cfg["default_env_prop"]["cluster_prop"].update(nb_agents=N, agents_comm_mode="random_sample")
+    cfg["default_env_prop"]["power_grid_prop"]["base_power_mode"] = "constant"
+    env = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=11)
+    env.reset()
+    env.t["P_max"].copy_((torch.arange(N, device="cuda", dtype=torch.float32) + 1.0)[None, :].expand(E, N) * 7500.0)   # id + 1 after /7500
+    def senders():
+        for layout in ("rows", "planes"):
+            v = env.obs_vector(layout)
+            rows = v if layout == "rows" else v.permute(1, 2, 0)
+            ids = (rows[..., 11:].reshape(E, N, c, 4)[..., 3]).round().long() - 1
+            yield ids
+    a, b = list(senders())
+    assert torch.equal(a, b)                                         # both layouts draw the same links
+    own = torch.arange(N, device="cuda")[None, :, None]
+    assert bool(((a >= 0) & (a < N) & (a != own)).all())
+    srt = a.sort(dim=-1).values
+    assert bool((srt[..., 1:] != srt[..., :-1]).all())               # distinct within a house
+    counts = torch.bincount(((a - (a > own).long())).reshape(-1), minlength=N - 1).cpu().numpy()   # index among the others
+    assert stats.chisquare(counts).pvalue > 1e-4
+    first = torch.bincount((a[..., 0] - (a[..., 0] > own[..., 0]).long()).reshape(-1), minlength=N - 1).cpu().numpy()
+    assert stats.chisquare(first).pvalue > 1e-4                      # every slot is uniform, not only the set
+    env.rollout(1)
+    env.t["P_max"].copy_((torch.arange(N, device="cuda", dtype=torch.float32) + 1.0)[None, :].expand(E, N) * 7500.0)
+    c2 = next(iter(senders()))
+    assert not torch.equal(a, c2)                                    # re-drawn at the next step
