@@ -61,6 +61,14 @@ def cpu_baseline(cfg_full, seconds):
            "sample": "oracle/loop_port.py (object-per-house pure-Python restatement, obs dicts + 10-neighbour "
                      "messages as the reference builds them), 1 env x %d houses x %d bang-bang steps, %.1f s"
                      % (N_HOUSES, steps, el)}
+    try:   # the reference's only parallelism: independent processes side by side
+        procs = max(1, min(16, (os.cpu_count() or 1)))
+        mp_rate, procs = loop_port.time_baseline_parallel(cfg, procs, seconds=min(6.0, seconds))
+        out["multi_process_value"] = mp_rate
+        out["multi_process_cores"] = procs
+    except Exception as exc:
+        out["multi_process_value"] = None
+        out["multi_process_cores"] = "unavailable: %s" % exc
     try:   # the same per-house arithmetic compiled (oracle/mdr_oracle_c.c): what one core does without the interpreter
         from oracle import c_port
         crate, csteps, cel = c_port.time_baseline(cfg, nb_envs=4, seconds=min(4.0, seconds))

@@ -214,3 +214,18 @@ def time_baseline(config, seconds=12.0, min_steps=5):
         if steps >= min_steps and el >= seconds:
             break
     return env.n * steps / el, steps, el
+
+
+def _worker(args):
+    config, seconds = args
+    return time_baseline(config, seconds=seconds)[0]
+
+
+def time_baseline_parallel(config, processes, seconds=6.0):
+    """Aggregate house-steps/s of `processes` independent copies of the port (the reference is single-threaded; its only
+    parallelism is running several processes side by side, monteCarlo.py:28-40)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")        # never fork a process that may have initialised the GPU
+    with ctx.Pool(processes) as pool:
+        rates = pool.map(_worker, [(config, seconds)] * processes)
+    return float(sum(rates)), processes
