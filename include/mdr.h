@@ -257,8 +257,8 @@ typedef struct mdr_rollout_out {
   double *sq_temp_error_sum;       /* [E]     += sum over steps and houses of (house_temp - target)^2, main-deploy.py:127,138 */
   double *sq_signal_error_sum;     /* [E]     += sum over steps of (reg_signal - cluster_hvac_power)^2, main-deploy.py:145-152 */
 } mdr_rollout_out_t;
-/* Returns MDR_ERR_UNSUPPORTED for shapes that need the split path (N > 2048, or N > 512 with N % 4 != 0) and
- * for sharded houses: use mdr_env_rollout there. */
+/* Shapes without an env-per-workgroup kernel (N > 2048, or N > 512 with N % 4 != 0) are run as single steps with the
+ * same accumulators (same results, no fusion).  Returns MDR_ERR_UNSUPPORTED for sharded houses: use mdr_env_rollout. */
 int mdr_env_rollout_fused(mdr_env_t *env, uint8_t *actions, int32_t nb_steps, const mdr_rollout_out_t *out, void *stream);
 
 /* Sharded houses (one env spans several devices).  Houses interact only through the cluster power sum (env 1042-1050)

@@ -336,7 +336,9 @@ class BatchedDemandResponseEnv:
         """`nb_steps` bang-bang steps with the houses held in registers between steps (one launch per time-table
         chunk).  Ends in the same state as ``rollout(nb_steps)`` bit for bit.  Returns a dict with the accumulators
         of main-deploy.py:124-152: ``reward_sum`` [E,N], ``sq_temp_error_sum`` [E], ``sq_signal_error_sum`` [E] and,
-        if asked, ``power_trace`` [nb_steps, E].  Falls back to ``rollout`` (no accumulators) for unsupported shapes."""
+        if asked, ``power_trace`` [nb_steps, E].  Shapes without a fused kernel (N > 2048, or N > 512 with N % 4 != 0) are
+        stepped one launch at a time inside the library with the same accumulators; sharded houses fall back to
+        ``rollout`` and return None."""
         E, N = self.nb_envs, self.nb_houses
         out = nat.MdrRolloutOut()
         out.struct_size = C.sizeof(nat.MdrRolloutOut)

@@ -30,7 +30,10 @@ def is_stale() -> bool:
 def build_native(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return OUTPUT
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # -ffp-contract=on: a*b+c fuses only inside one source expression (decided by the front end), never across statements,
+    # so that every kernel inlining the same house update / reward expression rounds it identically (hipcc's default
+    # "fast" lets the back end fuse depending on the surrounding code)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=on", "-std=c++17", "-fPIC", "-shared",
            "-o", OUTPUT] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))

@@ -453,10 +453,30 @@ int mdr_env_rollout_fused(mdr_env_t* env, uint8_t* actions, int32_t nb_steps, co
   if (!env) return MDR_ERR_INVALID;
   if (nb_steps < 0) return fail(env, MDR_ERR_INVALID, "nb_steps must be >= 0");
   if (out && out->struct_size != sizeof(mdr_rollout_out_t)) return fail(env, MDR_ERR_INVALID, "mdr_rollout_out_t size mismatch (ABI)");
-  if (env->cfg.nb_houses_total != env->cfg.nb_houses || !mdr::rollout_fused_supported(env->rollout_plan))
-    return fail(env, MDR_ERR_UNSUPPORTED, "fused rollout needs an env per workgroup or sub-wave group (N <= 2048 with N % 4 == 0, else N <= 512) and unsharded houses");
+  if (env->cfg.nb_houses_total != env->cfg.nb_houses)
+    return fail(env, MDR_ERR_UNSUPPORTED, "fused rollout needs unsharded houses");
   if (env->split_pending) return fail(env, MDR_ERR_INVALID, "step_begin without step_end");
   const int E = env->cfg.nb_envs;
+  if (!mdr::rollout_fused_supported(env->rollout_plan)) {
+    // no env-per-workgroup kernel for this shape (N > 2048, or N > 512 with N % 4 != 0): single steps, same accumulators
+    for (int32_t i = 0; i < nb_steps; ++i) {
+      int rc = mdr_env_step(env, actions, MDR_ACTIONS_BANGBANG, stream);
+      if (rc != MDR_OK) return rc;
+      if (!out) continue;
+      mdr::StepArgs a;
+      rc = step_args(env, actions, MDR_ACTIONS_BANGBANG, (hipStream_t)stream, &a);   // rows of the new time index
+      if (rc != MDR_OK) return rc;
+      mdr::RolloutArgs r{};
+      r.nsteps = 1;
+      r.power_trace = out->power_trace ? out->power_trace + (int64_t)i * E : nullptr;
+      r.reward_sum = out->reward_sum;
+      r.sq_temp_error_sum = out->sq_temp_error_sum;
+      r.sq_signal_error_sum = out->sq_signal_error_sum;
+      hipError_t e = mdr::launch_rollout_accumulate(a, r, (hipStream_t)stream);
+      if (e != hipSuccess) return hip_fail(env, e, "rollout_accumulate");
+    }
+    return MDR_OK;
+  }
   int32_t done = 0;
   while (done < nb_steps) {
     mdr::StepArgs a;

@@ -149,6 +149,7 @@ hipError_t launch_signal_error(const StepArgs& a, double* sq_signal_error_sum, h
 hipError_t launch_reset_obs(const StepArgs& a, hipStream_t s);  // uses sig_old = table row 0
 hipError_t launch_step(const StepArgs& a, const StepPlan& p, hipStream_t s);
 bool rollout_fused_supported(const StepPlan& p);
+hipError_t launch_rollout_accumulate(const StepArgs& a, const RolloutArgs& ro, hipStream_t s);   // after ONE single step
 hipError_t launch_rollout_fused(const StepArgs& a, const RolloutArgs& r, const StepPlan& p, hipStream_t s);
 hipError_t launch_obs_vector(const ObsArgs& a, int layout, hipStream_t s);
 int obs_vector_length(const mdr_obs_spec_t& spec);

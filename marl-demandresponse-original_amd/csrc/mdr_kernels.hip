@@ -262,7 +262,14 @@ __global__ __launch_bounds__(256) void k_fill_tables(TableArgs a) {
   } else if (a.signal_mode == MDR_SIGNAL_REGULAR_STEPS) {
     const double ampl = a.steps_amp * (double)a.n_total;
     const double duty = base / ampl;
-    sig = (fmod(sod, a.steps_period) - (1.0 - duty) * a.steps_period) >= 0.0 ? ampl : 0.0;
+    // np.heaviside(x, 1) is discontinuous at x == 0: the product must be rounded on its own, as NumPy does.  (HIP's
+    // __dmul_rn is a plain `*` that the compiler may still contract into an FMA, hence the pragma.)
+    {
+#pragma clang fp contract(off)
+      const double edge = (1.0 - duty) * a.steps_period;
+      const double x = fmod(sod, a.steps_period) - edge;
+      sig = x >= 0.0 ? ampl : 0.0;
+    }
   } else {  // Perlin family; mktime(t) % 86400 == seconds of day for naive/UTC time (env 1297)
     const double x = sod / a.perlin_period;
     double n = 0.0;
@@ -285,7 +292,7 @@ __device__ __forceinline__ float temp_penalty(const StepArgs& a, float pen, doub
   const float common = (float)(sum_pen * a.inv_n_total);
   if (a.penalty_mode == MDR_PENALTY_COMMON_L2) return common;
   if (a.penalty_mode == MDR_PENALTY_COMMON_MAX) return max_pen;
-  return a.mix_i * pen + a.mix_c * common + a.mix_m * max_pen;
+  return __fmaf_rn(a.mix_i, pen, __fmaf_rn(a.mix_c, common, a.mix_m * max_pen));   // explicit: no context-dependent contraction
 }
 
 // r_i = -(alpha_temp * pen_i / norm_T + alpha_sig * sig / norm_S)  (env 364-372); one explicit fma so that every
@@ -1755,6 +1762,34 @@ __global__ __launch_bounds__(256) void k_signal_error(StepArgs a, double* acc) {
 
 hipError_t launch_signal_error(const StepArgs& a, double* acc, hipStream_t s) {
   hipLaunchKernelGGL(k_signal_error, dim3((unsigned)((a.E + 255) / 256)), dim3(256), 0, s, a, acc);
+  return hipGetLastError();
+}
+
+// Stepwise stand-in for the accumulators of the fused rollout kernels (shapes they do not cover: N > 2048, or N > 512
+// with N % 4 != 0): run after each single step; a.sig_old is the row of the NEW time index, i.e. the step's new signal.
+__global__ __launch_bounds__(256) void k_rollout_accumulate(StepArgs a, RolloutArgs ro) {
+  __shared__ double lds[3 * 4];
+  const int e = blockIdx.x;
+  const int64_t base = (int64_t)e * a.N;
+  double terr = 0.0;
+  for (int h = threadIdx.x; h < a.N; h += 256) {
+    const int64_t i = base + h;
+    if (ro.reward_sum) ro.reward_sum[i] = ro.reward_sum[i] + a.reward[i];
+    const float d = a.Ta[i] - a.target[i];
+    terr += (double)(d * d);
+  }
+  Red3 r{terr, 0.0, 0.0f};
+  r = block_reduce<256>(r, lds);
+  if (threadIdx.x == 0) {
+    if (ro.sq_temp_error_sum) ro.sq_temp_error_sum[e] += r.sum_p;
+    const double d = a.sig_old[e] - a.P[e];
+    if (ro.sq_signal_error_sum) ro.sq_signal_error_sum[e] += d * d;
+    if (ro.power_trace) ro.power_trace[e] = a.P[e];
+  }
+}
+
+hipError_t launch_rollout_accumulate(const StepArgs& a, const RolloutArgs& ro, hipStream_t s) {
+  hipLaunchKernelGGL(k_rollout_accumulate, dim3((unsigned)a.E), dim3(256), 0, s, a, ro);
   return hipGetLastError();
 }
 

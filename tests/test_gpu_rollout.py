@@ -58,15 +58,29 @@ def test_fused_rollout_equals_single_steps(E, N, mode):
     assert torch.equal(a.t["Ta"], b.t["Ta"]) and torch.equal(a.t["reward"], b.t["reward"])
 
 
-def test_fused_rollout_unsupported_shapes_fall_back():
+@pytest.mark.parametrize("N", [5000, 2052, 513, 1023])
+def test_fused_rollout_shapes_without_a_fused_kernel_step_inside_the_library(N):
+    """N > 2048, or N > 512 with N % 4 != 0: single steps + k_rollout_accumulate, same accumulators as the fused kernels."""
     import mdr_amd
-    env = mdr_amd.BatchedDemandResponseEnv(_cfg(5000), nb_envs=2, device="cuda:0", seed=1)
-    twin = mdr_amd.BatchedDemandResponseEnv(_cfg(5000), nb_envs=2, device="cuda:0", seed=1)
+    env = mdr_amd.BatchedDemandResponseEnv(_cfg(N), nb_envs=3, device="cuda:0", seed=1, table_steps=8)
+    twin = mdr_amd.BatchedDemandResponseEnv(_cfg(N), nb_envs=3, device="cuda:0", seed=1, table_steps=8)
     env.reset(episode=0)
     twin.reset(episode=0)
-    assert env.rollout_fused(20) is None       # split-path shape: plain rollout ran instead
-    twin.rollout(20)
+    res = env.rollout_fused(20, power_trace=True)
+    rsum = torch.zeros_like(res["reward_sum"])
+    terr = torch.zeros(3, dtype=torch.float64, device="cuda:0")
+    serr = torch.zeros(3, dtype=torch.float64, device="cuda:0")
+    for t in range(20):
+        _, r, _, _ = twin.step_bangbang()
+        rsum += r
+        d = (twin.t["Ta"] - twin.t["target"]).double()
+        terr += (d * d).sum(dim=1)
+        serr += (twin.reg_signal() - twin.t["P"]) ** 2
+        assert torch.equal(res["power_trace"][t], twin.t["P"])
     assert torch.equal(env.t["Ta"], twin.t["Ta"]) and env.steps_taken == 20
+    assert torch.equal(res["reward_sum"], rsum)
+    torch.testing.assert_close(res["sq_signal_error_sum"], serr, rtol=1e-12, atol=0)
+    torch.testing.assert_close(res["sq_temp_error_sum"], terr, rtol=1e-6, atol=0)
 
 
 def test_fused_rollout_in_interpolation_mode():
