@@ -110,7 +110,7 @@ def make_small_grid(seed):
     return patches, dict(interp_grid_file=np.array("interp_grid_small.npz"))
 
 
-def run_scenario(name, patches, seed, T, policy, perlin=False, norm_steps=(0, 1, -1), extra=None):
+def run_scenario(name, patches, seed, T, policy, perlin=False, norm_steps=(0, 1, -1), extra=None, save=True):
     ref = ref_harness.load_reference()
     cfg = copy.deepcopy({k: ref["config_dict"][k] for k in ENV_KEYS})
     patch(cfg, "default_env_prop.power_grid_prop.base_power_mode", "constant")  # the interpolation grid is a missing blob
@@ -189,6 +189,8 @@ def run_scenario(name, patches, seed, T, policy, perlin=False, norm_steps=(0, 1,
         arrays.update(extra)
         arrays["base_power"] = np.array(base_power, dtype=np.float64)
     arrays["meta"] = np.array(json.dumps(meta))
+    if not save:          # tests/test_oracle_vs_reference_live.py: compare on the spot, write nothing
+        return arrays
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **arrays)
     print("%-28s N=%-3d T=%-5d  sum(reward)=%.9f  %6.1f KB" % (
