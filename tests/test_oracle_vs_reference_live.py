@@ -113,3 +113,67 @@ def test_oracle_tracks_the_live_reference(idx):
             k += 1
             np.testing.assert_allclose(env.norm_state(cfg, links)[0], a["norm_state"][k], rtol=1e-10, atol=1e-11)
     assert N == env.N
+
+
+@pytest.mark.parametrize("idx", range(40))
+def test_oracle_tracks_the_live_reference_in_interpolation_mode(idx, tmp_path):
+    """base_power_mode='interpolation' (the reference's default): a random grid written in the reference's own file formats is
+    read by ITS PowerInterpolator; the oracle's restatement of interpolatePower / interpolateGridFast must give the same base
+    power and signal at every update (N <= interp_nb_agents: above it the reference samples houses with `random`)."""
+    import csv
+    mg = _make_golden()
+    rng = np.random.default_rng(47000 + idx)
+
+    def axis(lo, hi, n, must=None):
+        v = np.unique(np.round(np.sort(rng.uniform(lo, hi, n)), 3))
+        if must is not None:
+            v = np.unique(np.concatenate([v, np.asarray(must, dtype=np.float64)]))
+        return [float(x) for x in v]
+    axes = {"Ua_ratio": axis(0.8, 1.2, int(rng.integers(1, 4)), [1.0]), "Cm_ratio": axis(0.8, 1.2, int(rng.integers(1, 4)), [1.0]),
+            "Ca_ratio": axis(0.8, 1.2, int(rng.integers(1, 3)), [1.0]), "Hm_ratio": axis(0.8, 1.2, int(rng.integers(1, 3)), [1.0]),
+            "air_temp": axis(-5, 5, int(rng.integers(2, 5))), "mass_temp": axis(-5, 5, int(rng.integers(2, 4))),
+            "OD_temp": axis(0, 20, int(rng.integers(2, 5))),
+            "HVAC_power": [float(x) for x in sorted(set(rng.choice([10000, 12500, 15000, 17500, 20000], int(rng.integers(1, 4)))))],
+            "hour": axis(0, 86399, int(rng.integers(2, 5))), "date": axis(0, 364, int(rng.integers(2, 4)))}
+    dims = [len(v) for v in axes.values()]
+    values = np.round(rng.uniform(0, 6000, int(np.prod(dims))))
+    np.save(tmp_path / "grid.npy", values)
+    (tmp_path / "params.json").write_text(json.dumps(axes))
+    with open(tmp_path / "keys.csv", "w") as f:
+        csv.writer(f).writerow(list(axes.keys()))
+    ip = PG + "base_power_parameters.interpolation."
+    N = int(rng.choice([1, 5, 12, 30]))
+    patches = {
+        PG + "base_power_mode": "interpolation", ip + "path_datafile": str(tmp_path / "grid.npy"),
+        ip + "path_parameter_dict": str(tmp_path / "params.json"), ip + "path_dict_keys": str(tmp_path / "keys.csv"),
+        ENV + "cluster_prop.nb_agents": N,
+        ENV + "time_step": int(rng.choice([4, 7, 30, 60, 150, 300, 400])),
+        ENV + "start_datetime_mode": str(rng.choice(["random", "fixed"])),
+        ENV + "start_datetime": str(rng.choice(["2021-01-01 00:00:00", "2021-12-31 23:58:00", "2024-02-29 23:50:00", "2024-12-31 12:00:00",
+                                                "2021-06-21 07:29:00"])),
+        ENV + "cluster_prop.temp_mode": str(rng.choice(["noisy_sinusoidal", "noisy_sinusoidal_hot", "noisy_sinusoidal_heatwave", "constant"])),
+        PG + "signal_mode": str(rng.choice(["flat", "sinusoidals", "regular_steps", "perlin"])),
+        "noise_house_prop.noise_mode": str(rng.choice(["no_noise", "small_noise", "big_noise"])),
+        "noise_hvac_prop.noise_mode": str(rng.choice(["no_noise", "small_noise", "big_noise"])),
+    }
+    seed = int(rng.integers(1, 10 ** 6))
+    T = 90
+    a = mg.run_scenario("live_interp_%d" % idx, patches, seed, T, "mixed", perlin="perlin" in patches[PG + "signal_mode"],
+                        norm_steps=(0,), extra={"live": np.array(1)}, save=False)
+    meta = json.loads(str(a["meta"]))
+    cfg = gu._intkeys(meta["config"])
+    env = mo.OracleEnv(cfg, nb_envs=1)
+    env.seed, env.episode = seed, 0
+    env.interp_grid = mo.InterpGrid(values, axes)
+    params = {k: a["p_" + k][None, :] for k in ("Ta", "Tm", "target", "deadband", "Ua", "Cm", "Ca", "Hm", "capacity", "COP", "latent", "lockout")}
+    params.update(t0=np.array([a["p_t0"]], dtype=np.int64), phase=np.array([a["p_phase"]]), ratio=np.array([a["p_ratio"]]))
+    env.load_episode(params, od_table=a["od"][:, None])
+    np.testing.assert_allclose(env.base_power[0], a["base_power"][0], rtol=1e-11)
+    np.testing.assert_allclose(env.S[0], a["S"][0], rtol=1e-11, atol=1e-8)
+    for t in range(T):
+        r = env.step(a["actions"][t][None, :])
+        np.testing.assert_allclose(env.base_power[0], a["base_power"][t + 1], rtol=1e-11, err_msg="base power @%d" % t)
+        np.testing.assert_allclose(env.S[0], a["S"][t + 1], rtol=1e-11, atol=1e-8)
+        np.testing.assert_allclose(env.Ta[0], a["Ta"][t], rtol=1e-10)
+        np.testing.assert_allclose(r[0], a["reward"][t], rtol=1e-9, atol=1e-12)
+    assert len(np.unique(a["base_power"])) > 1 or values.std() == 0
