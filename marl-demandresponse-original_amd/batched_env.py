@@ -204,18 +204,25 @@ class BatchedDemandResponseEnv:
             pass
 
     # ------------------------------------------------------------------ episode start
-    def _allreduce(self, tensor, op):
-        import torch.distributed as dist
-        dist.all_reduce(tensor, op=op, group=self.process_group)
+    def _exchange(self):
+        """The object that carries the sharded-houses exchanges (sharding.TorchDistExchange unless a
+        sharding.LocalShardGroup installed its own)."""
+        ex = getattr(self, "_exchange_impl", None)
+        if ex is None:
+            from .sharding import TorchDistExchange
+            ex = self._exchange_impl = TorchDistExchange(self.process_group)
+        return ex
 
     def _begin_episode(self):
         if self.sharded:  # ClusterHouses.max_power spans the whole env (env 798-802, 125)
-            import torch.distributed as dist
-            self._allreduce(self.t["max_power"], dist.ReduceOp.SUM)
-        nat.check(self._lib, self._handle, self._lib.mdr_env_begin_episode(self._handle, self._stream()), "begin_episode")
+            self._exchange().sum_max_power(self)
+        self._begin_episode_local()
 
-    def reset(self, seed: Optional[int] = None, episode: Optional[int] = None) -> torch.Tensor:
-        """MADemandResponseEnv.reset (env 135-172): re-samples every house and the start date, on the device."""
+    def _begin_episode_local(self):
+        with torch.cuda.device(self.device):
+            nat.check(self._lib, self._handle, self._lib.mdr_env_begin_episode(self._handle, self._stream()), "begin_episode")
+
+    def _reset_local(self, seed: Optional[int] = None, episode: Optional[int] = None) -> None:
         if seed is not None:
             self.seed = int(seed)
         self.episode = self.episode + 1 if episode is None else int(episode)
@@ -223,8 +230,12 @@ class BatchedDemandResponseEnv:
             rc = self._lib.mdr_env_reset(self._handle, C.c_uint64(self.seed & 0xFFFFFFFFFFFFFFFF),
                                          C.c_uint32(self.episode & 0xFFFFFFFF), self._stream())
             nat.check(self._lib, self._handle, rc, "mdr_env_reset")
-            self._begin_episode()
-            return self._reset_obs()
+
+    def reset(self, seed: Optional[int] = None, episode: Optional[int] = None) -> torch.Tensor:
+        """MADemandResponseEnv.reset (env 135-172): re-samples every house and the start date, on the device."""
+        self._reset_local(seed, episode)
+        self._begin_episode()
+        return self._reset_obs()
 
     def load_episode(self, params: Dict[str, np.ndarray], od_table=None, seed: Optional[int] = None,
                      episode: int = 0) -> torch.Tensor:
@@ -292,24 +303,28 @@ class BatchedDemandResponseEnv:
         return actions.data_ptr()
 
     def _step(self, ptr, source):
-        with torch.cuda.device(self.device):
-            if not self.sharded:
+        if not self.sharded:
+            with torch.cuda.device(self.device):
                 rc = self._lib.mdr_env_step(self._handle, C.c_void_p(ptr), source, self._stream())
                 nat.check(self._lib, self._handle, rc, "mdr_env_step")
-            else:
-                import torch.distributed as dist
-                rc = self._lib.mdr_env_step_begin(self._handle, C.c_void_p(ptr), source, self._stream())
-                nat.check(self._lib, self._handle, rc, "mdr_env_step_begin")
-                # ONE collective per step: all-gather every rank's [3][E] block (cluster power, penalty sum, penalty max);
-                # mdr_env_step_end_gathered reduces the blocks while it writes the rewards (payload 24 B per env and rank:
-                # the exchange is latency-bound, so the number of collectives is what counts)
-                world = dist.get_world_size(self.process_group)
-                if getattr(self, "_gathered", None) is None or self._gathered.shape[0] != world:
-                    self._gathered = torch.empty((world, 3, self.nb_envs), dtype=torch.float64, device=self.device)
-                # concatenation form [world * 3, E] (same memory as [world][3][E]): accepted by RCCL and by gloo alike
-                dist.all_gather_into_tensor(self._gathered.view(world * 3, self.nb_envs), self.t["tot"], group=self.process_group)
-                rc = self._lib.mdr_env_step_end_gathered(self._handle, C.c_void_p(self._gathered.data_ptr()), world, self._stream())
-                nat.check(self._lib, self._handle, rc, "mdr_env_step_end_gathered")
+            return
+        self._step_begin(ptr, source)
+        # ONE collective per step: all-gather every rank's [3][E] block (cluster power, penalty sum, penalty max);
+        # mdr_env_step_end_gathered reduces the blocks while it writes the rewards (payload 24 B per env and rank:
+        # the exchange is latency-bound, so the number of collectives is what counts)
+        gathered, world = self._exchange().gather_totals(self)
+        self._step_end(gathered, world)
+
+    def _step_begin(self, ptr, source):
+        with torch.cuda.device(self.device):
+            rc = self._lib.mdr_env_step_begin(self._handle, C.c_void_p(ptr), source, self._stream())
+            nat.check(self._lib, self._handle, rc, "mdr_env_step_begin")
+
+    def _step_end(self, gathered: torch.Tensor, world: int):
+        """`gathered`: float64 [world][3][E] on this device - every shard's `t['tot']` block."""
+        with torch.cuda.device(self.device):
+            rc = self._lib.mdr_env_step_end_gathered(self._handle, C.c_void_p(gathered.data_ptr()), int(world), self._stream())
+            nat.check(self._lib, self._handle, rc, "mdr_env_step_end_gathered")
 
     def step(self, actions: torch.Tensor):
         """MADemandResponseEnv.step (env 174-210).  Returns (obs [7,E,N], reward [E,N], done [E,N], info)."""

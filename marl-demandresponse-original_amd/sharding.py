@@ -7,7 +7,7 @@
 """
 from __future__ import annotations
 
-from typing import Tuple
+from typing import List, Optional, Sequence, Tuple
 
 
 def env_shard(nb_envs_total: int, world_size: int, rank: int) -> Tuple[int, int]:
@@ -34,3 +34,110 @@ def house_shard(nb_houses_total: int, world_size: int, rank: int, granule: int =
     if rank == world_size - 1:
         count = nb_houses_total - start
     return start, count
+
+
+class TorchDistExchange:
+    """The two exchanges of the sharded-houses layout over torch.distributed (RCCL on the GPU box, gloo in CPU tests):
+    one SUM all-reduce of `max_power` per episode and ONE all-gather of the [3][E] aggregate block per step."""
+
+    def __init__(self, process_group=None):
+        self.process_group = process_group
+        self._gathered = None
+
+    def sum_max_power(self, env) -> None:
+        import torch.distributed as dist
+        dist.all_reduce(env.t["max_power"], op=dist.ReduceOp.SUM, group=self.process_group)
+
+    def gather_totals(self, env):
+        import torch
+        import torch.distributed as dist
+        world = dist.get_world_size(self.process_group)
+        if self._gathered is None or self._gathered.shape[0] != world:
+            self._gathered = torch.empty((world, 3, env.nb_envs), dtype=torch.float64, device=env.device)
+        # concatenation form [world * 3, E] (same memory as [world][3][E]): accepted by RCCL and by gloo alike
+        dist.all_gather_into_tensor(self._gathered.view(world * 3, env.nb_envs), env.t["tot"], group=self.process_group)
+        return self._gathered, world
+
+
+class LocalShardGroup:
+    """All house shards of the same envs driven from ONE process: `nb_shards` BatchedDemandResponseEnv objects, spread
+    round-robin over `devices` (a single device rehearses BASELINE config 5's eight 125,000-house shards on one GPU).
+    The per-step exchange is a stack of the shards' [3][E] blocks copied to each shard's device - the peer-copy
+    alternative to the RCCL all-gather that one-process-per-GPU runs use - and every shard's
+    kernels are issued before the exchange so that the shards overlap.  Results are identical to the
+    torch.distributed path: both feed mdr_env_step_end_gathered the same [world][3][E] tensor."""
+
+    def __init__(self, config: dict, nb_envs: int, nb_shards: int, devices: Sequence = ("cuda:0",), seed: int = 0, **kw):
+        from .batched_env import BatchedDemandResponseEnv
+        total = int(config["default_env_prop"]["cluster_prop"]["nb_agents"])
+        self.nb_shards, self.nb_envs, self.nb_agents = int(nb_shards), int(nb_envs), total
+        self.shards: List = []
+        for r in range(self.nb_shards):
+            env = BatchedDemandResponseEnv(config, nb_envs=nb_envs, device=devices[r % len(devices)], seed=seed,
+                                           house_shard=house_shard(total, self.nb_shards, r), **kw)
+            env._exchange_impl = self            # a lone shard.step() would wait for peers that never come: refuse it
+            self.shards.append(env)
+
+    # the shards must move in lockstep, which only the group can guarantee
+    def sum_max_power(self, env):
+        raise RuntimeError("shards of a LocalShardGroup are stepped through the group, not one by one")
+
+    gather_totals = sum_max_power
+
+    def _sync_devices(self):
+        import torch
+        if len({e.device for e in self.shards}) > 1:    # cross-device reads must see the producers' results
+            for env in self.shards:
+                torch.cuda.current_stream(env.device).synchronize()
+
+    def reset(self, seed: Optional[int] = None, episode: Optional[int] = None):
+        for env in self.shards:
+            env._reset_local(seed, episode)
+        if self.nb_shards > 1:                           # ClusterHouses.max_power spans the whole env (env 798-802)
+            self._sync_devices()
+            total = sum(env.t["max_power"].to(self.shards[0].device) for env in self.shards)
+            for env in self.shards:
+                env.t["max_power"].copy_(total)
+        for env in self.shards:
+            env._begin_episode_local()
+        return [env._reset_obs() for env in self.shards]
+
+    def _finish(self):
+        import torch
+        first = self.shards[0]
+        self._sync_devices()
+        block = torch.stack([env.t["tot"].to(first.device) for env in self.shards])     # [world][3][E]
+        for env in self.shards:
+            env._gathered_local = block if env.device == first.device else block.to(env.device)
+            env._step_end(env._gathered_local, self.nb_shards)
+
+    def _begin(self, env, ptr, source):
+        if env.sharded:
+            env._step_begin(ptr, source)
+        else:                                            # nb_shards == 1: the plain fused step
+            env._step(ptr, source)
+
+    def step(self, actions: Sequence):
+        """`actions[r]`: uint8/bool [E, shard r's houses] on shard r's device."""
+        from . import _native as nat
+        for env, act in zip(self.shards, actions):
+            self._begin(env, env._actions_ptr(act), nat.ACTIONS_EXTERNAL)
+        if self.nb_shards > 1:
+            self._finish()
+        return [(e.t["obs"], e.t["reward"]) for e in self.shards]
+
+    def step_bangbang(self):
+        from . import _native as nat
+        for env in self.shards:
+            self._begin(env, env.t["actions"].data_ptr(), nat.ACTIONS_BANGBANG)
+        if self.nb_shards > 1:
+            self._finish()
+        return [(e.t["obs"], e.t["reward"]) for e in self.shards]
+
+    def cluster_hvac_power(self):
+        return self.shards[0].t["P"]
+
+    def gather(self, name: str):
+        """One [E, N_total] tensor of a per-house array (on the first shard's device)."""
+        import torch
+        return torch.cat([env.t[name].to(self.shards[0].device) for env in self.shards], dim=1)
