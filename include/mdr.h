@@ -272,6 +272,20 @@ int mdr_env_step_end(mdr_env_t *env, void *stream);
  * the fly (sum, sum, max over ranks, in rank order) while writing rewards - the all-reduced values are never stored. */
 int mdr_env_step_end_gathered(mdr_env_t *env, const double *gathered, int32_t world, void *stream);
 
+/* Sharded houses with base_power_mode "interpolation": PowerGrid.interpolatePower (env 1195-1234) averages up to
+ * interp_nb_agents houses drawn from the WHOLE env (env 1209-1215), so the update at episode start and every
+ * ceil(interp_update_period / time_step) steps (env 1250-1255) needs one more exchange.  After mdr_env_begin_episode /
+ * mdr_env_step_end*, while mdr_env_interp_due() is 1:
+ *   mdr_env_interp_local  - this shard's part of the new base power -> base_power[E] (every shard walks the same
+ *                           draws, which are functions of global indices, and adds the houses it holds);
+ *   caller                - SUM all-reduce of base_power over the shards;
+ *   mdr_env_interp_apply  - rebuilds the signal rows from the summed base power and re-writes the reg_signal
+ *                           observation plane of the step just taken.
+ * mdr_env_step_begin refuses to run while an update is due.  Unsharded handles never report 1. */
+int mdr_env_interp_due(const mdr_env_t *env);
+int mdr_env_interp_local(mdr_env_t *env, void *stream);
+int mdr_env_interp_apply(mdr_env_t *env, void *stream);
+
 /* utils.normStateDict (utils.py:740-880) for every house at once, including the neighbour messages
  * (SingleHouse.message env 624-662, gathered through `links`): writes the flat state vector of length
  * mdr_obs_vector_length(spec) per house into `out` in the requested layout.  Reads the post-step (or post-reset)

@@ -217,6 +217,25 @@ class BatchedDemandResponseEnv:
         if self.sharded:  # ClusterHouses.max_power spans the whole env (env 798-802, 125)
             self._exchange().sum_max_power(self)
         self._begin_episode_local()
+        self._interp_exchange()
+
+    # sharded houses + interpolated base power: interpolatePower draws its houses from the whole env (env 1209-1215)
+    def _interp_due(self) -> bool:
+        return self.sharded and self.spec.base_power_mode == 1 and bool(self._lib.mdr_env_interp_due(self._handle))
+
+    def _interp_local(self):
+        with torch.cuda.device(self.device):
+            nat.check(self._lib, self._handle, self._lib.mdr_env_interp_local(self._handle, self._stream()), "mdr_env_interp_local")
+
+    def _interp_apply(self):
+        with torch.cuda.device(self.device):
+            nat.check(self._lib, self._handle, self._lib.mdr_env_interp_apply(self._handle, self._stream()), "mdr_env_interp_apply")
+
+    def _interp_exchange(self):
+        if self._interp_due():
+            self._interp_local()
+            self._exchange().sum_base_power(self)
+            self._interp_apply()
 
     def _begin_episode_local(self):
         with torch.cuda.device(self.device):
@@ -314,6 +333,7 @@ class BatchedDemandResponseEnv:
         # the exchange is latency-bound, so the number of collectives is what counts)
         gathered, world = self._exchange().gather_totals(self)
         self._step_end(gathered, world)
+        self._interp_exchange()       # every ceil(interp_update_period / time_step) steps: one more SUM all-reduce of [E]
 
     def _step_begin(self, ptr, source):
         with torch.cuda.device(self.device):

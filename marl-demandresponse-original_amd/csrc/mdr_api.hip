@@ -16,6 +16,7 @@ struct mdr_env {
   bool has_episode = false;   // per-house parameters present
   bool has_tables = false;    // begin_episode done
   bool split_pending = false; // step_begin issued, step_end outstanding
+  bool interp_due = false;    // sharded houses, interpolation mode: the base power of the current time index awaits its exchange
   uint64_t seed = 0;
   uint32_t episode = 0;
   int64_t k = 0;              // steps taken this episode
@@ -80,8 +81,6 @@ std::string validate(const mdr_config_t& c) {
   if (c.penalty_mode == MDR_PENALTY_MIXTURE && !(c.mix_ind_L2 + c.mix_common_L2 + c.mix_common_max != 0.0))
     return "mixture weights sum to zero";
   if (c.base_power_mode != 0 && c.base_power_mode != 1) return "base_power_mode can only be 0 (constant) or 1 (interpolation)";
-  if (c.base_power_mode == 1 && c.nb_houses_total != c.nb_houses)
-    return "base_power_mode interpolation is not available for sharded houses";
   if (!(c.norm_temp_penalty > 0.0) || !(c.norm_sig_penalty > 0.0) || !(c.obs_power_norm > 0.0))
     return "normalisation constants must be positive";
   if ((int64_t)c.nb_envs * (int64_t)c.nb_houses > (int64_t)1 << 40) return "E * N too large";
@@ -196,7 +195,7 @@ int fill_tables(mdr_env* env, int64_t j0, hipStream_t s) {
 
 // PowerGrid.step in interpolation mode (env 1250-1255) at time index j: the outdoor temperature row has to exist
 // before interpolatePower can read it, and the signal rows need the new base power, hence fill - interpolate - fill.
-int refresh_interp(mdr_env* env, int64_t j, hipStream_t s) {
+int interp_local(mdr_env* env, int64_t j, hipStream_t s) {
   const mdr_config_t& c = env->cfg;
   int rc = fill_tables(env, j, s);
   if (rc != MDR_OK) return rc;
@@ -212,16 +211,24 @@ int refresh_interp(mdr_env* env, int64_t j, hipStream_t s) {
   a.t0 = b.t0;
   a.base_power = b.base_power;
   a.E = c.nb_envs; a.N = c.nb_houses; a.dt = c.time_step; a.nb_agents = env->interp.nb_agents; a.solar_on = c.solar_gain;
+  a.N_total = c.nb_houses_total; a.house_offset = c.house_offset;
   a.j = j;
   a.env_offset = c.env_offset;
   a.k0 = (uint32_t)(env->seed & 0xFFFFFFFFull); a.k1 = (uint32_t)(env->seed >> 32); a.episode = env->episode;
   a.def_Ua = c.Ua; a.def_Cm = c.Cm; a.def_Ca = c.Ca; a.def_Hm = c.Hm;
   hipError_t e = mdr::launch_interp_base(a, s);
   if (e != hipSuccess) return hip_fail(env, e, "interp_base");
+  return MDR_OK;
+}
+
+int refresh_interp(mdr_env* env, int64_t j, hipStream_t s) {
+  int rc = interp_local(env, j, s);
+  if (rc != MDR_OK) return rc;
   return fill_tables(env, j, s);
 }
 
 bool interp_mode(const mdr_env* env) { return env->cfg.base_power_mode == 1; }
+bool sharded(const mdr_env* env) { return env->cfg.nb_houses_total != env->cfg.nb_houses; }
 
 // Called after a step that brought the cursor onto an interpolation update: new base power, new tables from the
 // current time index, and the reg_signal observation plane of the step just taken re-written with the final signal.
@@ -354,6 +361,7 @@ int mdr_env_reset(mdr_env_t* env, uint64_t seed, uint32_t episode, void* stream)
   env->episode = episode;
   env->has_tables = false;
   env->split_pending = false;
+  env->interp_due = false;
   hipError_t e = mdr::launch_sample(episode_args(*env), (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "reset");
   env->has_episode = true;
@@ -372,6 +380,7 @@ int mdr_env_load_episode(mdr_env_t* env, const mdr_episode_t* ep, uint64_t seed,
   env->episode = episode_index;
   env->has_tables = false;
   env->split_pending = false;
+  env->interp_due = false;
   hipError_t e = mdr::launch_load(episode_args(*env), *ep, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "load_episode");
   env->has_episode = true;
@@ -414,7 +423,14 @@ int mdr_env_begin_episode(mdr_env_t* env, void* stream) {
     if (!env->buf.base_power) return fail(env, MDR_ERR_UNBOUND, "buffer 'base_power' is NULL");
   }
   env->k = 0;
-  int rc = interp_mode(env) ? refresh_interp(env, 0, (hipStream_t)stream) : fill_tables(env, 0, (hipStream_t)stream);
+  env->interp_due = false;
+  int rc;
+  if (interp_mode(env) && sharded(env)) {   // the signal rows stay provisional until mdr_env_interp_apply
+    rc = fill_tables(env, 0, (hipStream_t)stream);
+    env->interp_due = true;
+  } else {
+    rc = interp_mode(env) ? refresh_interp(env, 0, (hipStream_t)stream) : fill_tables(env, 0, (hipStream_t)stream);
+  }
   if (rc != MDR_OK) return rc;
   env->has_tables = true;
   mdr::StepArgs a;
@@ -506,6 +522,8 @@ int mdr_env_rollout_fused(mdr_env_t* env, uint8_t* actions, int32_t nb_steps, co
 int mdr_env_step_begin(mdr_env_t* env, uint8_t* actions, int action_source, void* stream) {
   if (!env) return MDR_ERR_INVALID;
   if (env->split_pending) return fail(env, MDR_ERR_INVALID, "step_begin called twice");
+  if (env->interp_due)
+    return fail(env, MDR_ERR_INVALID, "base power update pending: mdr_env_interp_local, SUM all-reduce of base_power, mdr_env_interp_apply");
   if (env->bound && !env->buf.partials) return fail(env, MDR_ERR_UNBOUND, "buffer 'partials' is NULL");
   mdr::StepArgs a;
   int rc = step_args(env, actions, action_source, (hipStream_t)stream, &a);
@@ -529,6 +547,34 @@ static int step_end_impl(mdr_env_t* env, const double* gathered, int32_t world, 
   if (e != hipSuccess) return hip_fail(env, e, "step_end");
   env->split_pending = false;
   env->k += 1;
+  if (interp_mode(env) && env->k % env->interp_steps == 0) {
+    if (!sharded(env)) return interp_boundary(env, (hipStream_t)stream, nullptr);
+    env->interp_due = true;   // the caller runs the exchange: interp_local - all-reduce - interp_apply
+  }
+  return MDR_OK;
+}
+
+int mdr_env_interp_due(const mdr_env_t* env) { return (env && env->interp_due) ? 1 : 0; }
+
+int mdr_env_interp_local(mdr_env_t* env, void* stream) {
+  if (!env) return MDR_ERR_INVALID;
+  if (!env->bound || !env->has_tables) return fail(env, MDR_ERR_UNBOUND, "no episode: call reset/load_episode and begin_episode first");
+  if (!env->interp_due) return fail(env, MDR_ERR_INVALID, "no base power update is due");
+  return interp_local(env, env->k, (hipStream_t)stream);
+}
+
+int mdr_env_interp_apply(mdr_env_t* env, void* stream) {
+  if (!env) return MDR_ERR_INVALID;
+  if (!env->bound || !env->has_tables) return fail(env, MDR_ERR_UNBOUND, "no episode: call reset/load_episode and begin_episode first");
+  if (!env->interp_due) return fail(env, MDR_ERR_INVALID, "no base power update is due");
+  int rc = fill_tables(env, env->k, (hipStream_t)stream);   // signal rows from the summed base power
+  if (rc != MDR_OK) return rc;
+  mdr::StepArgs a;
+  rc = step_args(env, nullptr, MDR_ACTIONS_BANGBANG, (hipStream_t)stream, &a);
+  if (rc != MDR_OK) return rc;
+  hipError_t e = mdr::launch_patch_signal_plane(a, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(env, e, "patch_signal_plane");
+  env->interp_due = false;
   return MDR_OK;
 }
 
@@ -613,6 +659,7 @@ int mdr_env_set_cursor(mdr_env_t* env, uint64_t seed, uint32_t episode, int64_t 
   env->has_episode = true;
   env->has_tables = true;
   env->split_pending = false;
+  env->interp_due = false;
   return MDR_OK;
 }
 

@@ -63,6 +63,7 @@ struct InterpArgs {
   const int64_t* t0;
   double* base_power;       // [E] out
   int E, N, dt, nb_agents, solar_on;
+  int N_total, house_offset;   // sharded houses: this device holds houses [house_offset, house_offset + N) of N_total
   int64_t j;                // time index of the update
   int64_t env_offset;
   uint32_t k0, k1, episode;

@@ -141,8 +141,10 @@ __global__ __launch_bounds__(128) void k_interp_base(InterpArgs a) {
   __shared__ double lds[3 * 2];
   const int e = blockIdx.x;
   const int64_t base = (int64_t)e * a.N;
-  const bool all = a.N <= a.nb_agents;
-  const int count = all ? a.N : a.nb_agents;
+  // sharded houses: every shard walks the same sample slots (the draws are functions of global indices) and adds the
+  // houses it holds; the caller sums base_power over the shards
+  const bool all = a.N_total <= a.nb_agents;
+  const int count = all ? a.N_total : a.nb_agents;
   const Civil c = civil_from_epoch(a.t0[e] + a.j * (int64_t)a.dt);
   // env 1198-1207: tm_yday and seconds since midnight, or (0, 0) when the solar gain is not modelled
   const double date = a.solar_on ? (double)c.yday : 0.0;
@@ -156,8 +158,10 @@ __global__ __launch_bounds__(128) void k_interp_base(InterpArgs a) {
     int h = q;
     if (!all) {   // random.choices(all_ids, k = interp_nb_agents), env 1214
       const u32x4 r = philox4x32_10((uint32_t)(e + a.env_offset), (uint32_t)q, (uint32_t)a.j, TAG_INTERP | (a.episode << 8), a.k0, a.k1);
-      h = (int)mulhi_pick(r.x, (uint32_t)a.N);
+      h = (int)mulhi_pick(r.x, (uint32_t)a.N_total);
     }
+    h -= a.house_offset;
+    if (h < 0 || h >= a.N) continue;
     const int64_t i = base + h;
     const double tgt = (double)a.target[i];   // all temperatures here are relative to temp_ref: differences are unaffected
     double p[MDR_INTERP_AXES];
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(128) void k_interp_base(InterpArgs a) {
   }
   Red3 r{sum, 0.0, 0.0f};
   r = block_reduce<128>(r, lds);
-  if (threadIdx.x == 0) a.base_power[e] = r.sum_p * (all ? 1.0 : (double)a.N / (double)a.nb_agents);
+  if (threadIdx.x == 0) a.base_power[e] = r.sum_p * (all ? 1.0 : (double)a.N_total / (double)a.nb_agents);
 }
 
 // obs plane 5 (reg_signal / norm) <- the freshly computed signal of the current time index (sig_old row)

@@ -48,6 +48,10 @@ class TorchDistExchange:
         import torch.distributed as dist
         dist.all_reduce(env.t["max_power"], op=dist.ReduceOp.SUM, group=self.process_group)
 
+    def sum_base_power(self, env) -> None:
+        import torch.distributed as dist
+        dist.all_reduce(env.t["base_power"], op=dist.ReduceOp.SUM, group=self.process_group)
+
     def gather_totals(self, env):
         import torch
         import torch.distributed as dist
@@ -82,7 +86,20 @@ class LocalShardGroup:
     def sum_max_power(self, env):
         raise RuntimeError("shards of a LocalShardGroup are stepped through the group, not one by one")
 
-    gather_totals = sum_max_power
+    gather_totals = sum_base_power = sum_max_power
+
+    def _interp_exchange(self):
+        due = [env._interp_due() for env in self.shards]
+        if not any(due):
+            return
+        assert all(due), "shards out of lockstep"
+        for env in self.shards:
+            env._interp_local()
+        self._sync_devices()
+        total = sum(env.t["base_power"].to(self.shards[0].device) for env in self.shards)
+        for env in self.shards:
+            env.t["base_power"].copy_(total)
+            env._interp_apply()
 
     def _sync_devices(self):
         import torch
@@ -100,6 +117,7 @@ class LocalShardGroup:
                 env.t["max_power"].copy_(total)
         for env in self.shards:
             env._begin_episode_local()
+        self._interp_exchange()
         return [env._reset_obs() for env in self.shards]
 
     def _finish(self):
@@ -110,6 +128,7 @@ class LocalShardGroup:
         for env in self.shards:
             env._gathered_local = block if env.device == first.device else block.to(env.device)
             env._step_end(env._gathered_local, self.nb_shards)
+        self._interp_exchange()
 
     def _begin(self, env, ptr, source):
         if env.sharded:

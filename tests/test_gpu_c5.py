@@ -78,3 +78,71 @@ def test_c5_eight_shards_in_one_process_match_unsharded(mode, shards):
         torch.testing.assert_close(group.gather("reward"), whole.t["reward"], rtol=1e-6, atol=1e-6)
     with pytest.raises(RuntimeError):
         group.shards[0].step_bangbang()                                     # a lone shard cannot step
+
+
+@pytest.mark.parametrize("N,shards,dt", [(40, 2, 60), (300, 3, 60), (5000, 4, 150), (100000, 8, 300)])
+def test_sharded_interpolated_base_power_matches_unsharded_and_oracle(N, shards, dt):
+    """base_power_mode='interpolation' with sharded houses: interpolatePower's <= 100 houses are drawn from the whole env;
+    every shard adds the drawn houses it holds and the parts are summed (mdr_env_interp_local / apply)."""
+    import mdr_amd
+    from mdr_amd.sharding import LocalShardGroup
+    from oracle import mdr_oracle as mo
+    from tests import golden_util as gu
+    values, axes = gu.Golden("s12_interp_default_like").interp_grid()
+    cfg = _cfg()
+    env = cfg["default_env_prop"]
+    env["cluster_prop"]["nb_agents"] = N
+    env["time_step"] = dt
+    env["power_grid_prop"]["base_power_mode"] = "interpolation"
+    cfg["noise_house_prop"]["noise_mode"] = "small_noise"
+    E = 3
+    whole = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=12, interp_grid=(values, axes))
+    group = LocalShardGroup(cfg, nb_envs=E, nb_shards=shards, devices=("cuda:0",), seed=12, interp_grid=(values, axes))
+    ora = mo.OracleEnv(cfg, nb_envs=E)
+    ora.interp_grid = mo.InterpGrid(values, axes)
+    whole.reset(episode=2)
+    group.reset(episode=2)
+    ora.reset(seed=12, episode=2)
+    bounds = np.cumsum([0] + [e.nb_houses for e in group.shards])
+    rng = np.random.default_rng(3)
+    moved = set()
+    for t in range(13):
+        for e in group.shards:
+            torch.testing.assert_close(e.t["base_power"], whole.t["base_power"], rtol=1e-13, atol=0)
+            torch.testing.assert_close(e.reg_signal(), whole.reg_signal(), rtol=1e-13, atol=0)
+        np.testing.assert_allclose(whole.t["base_power"].cpu().numpy(), ora.base_power, rtol=3e-6)
+        moved.add(float(whole.t["base_power"][0]))
+        act = (rng.random((E, N)) < 0.5).astype(np.uint8)
+        dev = torch.from_numpy(act).cuda()
+        whole.step(dev)
+        group.step([dev[:, bounds[r]:bounds[r + 1]].contiguous() for r in range(shards)])
+        ora.step(act)
+        assert torch.equal(group.cluster_hvac_power(), whole.t["P"])
+        for name in ("Ta", "Tm", "sso", "flags"):
+            assert torch.equal(group.gather(name), whole.t[name]), name
+        torch.testing.assert_close(group.gather("reward"), whole.t["reward"], rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(torch.cat([e.t["obs"] for e in group.shards], dim=2), whole.t["obs"], rtol=1e-6, atol=1e-7)
+    assert len(moved) >= 3
+
+
+def test_sharded_interp_update_must_be_exchanged_before_the_next_step():
+    import mdr_amd
+    from mdr_amd import _native as nat
+    from mdr_amd.sharding import LocalShardGroup
+    from tests import golden_util as gu
+    grid = gu.Golden("s12_interp_default_like").interp_grid()
+    cfg = _cfg()
+    cfg["default_env_prop"]["cluster_prop"]["nb_agents"] = 64
+    cfg["default_env_prop"]["power_grid_prop"]["base_power_mode"] = "interpolation"
+    group = LocalShardGroup(cfg, nb_envs=2, nb_shards=2, devices=("cuda:0",), seed=1, interp_grid=grid)
+    for env in group.shards:
+        env._reset_local(None, 0)
+        env._begin_episode_local()
+        assert env._interp_due()
+    shard = group.shards[0]
+    with pytest.raises(ValueError, match="base power update pending"):
+        shard._step_begin(shard.t["actions"].data_ptr(), nat.ACTIONS_BANGBANG)
+    group._interp_exchange()
+    assert not shard._interp_due()
+    with pytest.raises(ValueError, match="no base power update is due"):
+        shard._interp_local()

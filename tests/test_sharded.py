@@ -176,3 +176,44 @@ def _hip_sharded_worker(rank, world, port, mode, N):
 @pytest.mark.parametrize("mode,N", [("individual_L2", 2048), ("mixture", 1001), ("common_max", 60000)])
 def test_hip_sharded_houses_two_ranks_one_gpu(mode, N):
     _spawn(_hip_sharded_worker, 2, mode, N)
+
+
+def _hip_sharded_interp_worker(rank, world, port, N):
+    """Interpolated base power over sharded houses through torch.distributed: one more SUM all-reduce per update."""
+    import mdr_amd
+    from mdr_amd.sharding import house_shard
+    from tests import golden_util as gu
+    _init(rank, world, port)
+    torch.cuda.set_device(0)
+    E, T = 2, 23
+    grid = gu.Golden("s12_interp_default_like").interp_grid()
+    cfg = _cfg(N, **{"noise_house_prop.noise_mode": "small_noise", "noise_hvac_prop.noise_mode": "big_noise",
+                     "default_env_prop.time_step": 60,                           # update every ceil(300 / 60) = 5 steps
+                     "default_env_prop.power_grid_prop.base_power_mode": "interpolation",
+                     "default_env_prop.power_grid_prop.signal_mode": "sinusoidals"})
+    off, cnt = house_shard(N, world, rank)
+    shard = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=33, house_shard=(off, cnt), interp_grid=grid)
+    whole = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=33, interp_grid=grid)
+    shard.reset(episode=0)
+    whole.reset(episode=0)
+    seen = set()
+    for t in range(T):
+        torch.testing.assert_close(shard.t["base_power"], whole.t["base_power"], rtol=1e-13, atol=0)
+        torch.testing.assert_close(shard.reg_signal(), whole.reg_signal(), rtol=1e-13, atol=0)
+        seen.add(float(whole.t["base_power"][0]))
+        shard.step_bangbang()
+        whole.step_bangbang()
+        assert torch.equal(shard.t["P"], whole.t["P"])
+        for k in ("Ta", "Tm", "sso", "flags"):
+            assert torch.equal(shard.t[k], whole.t[k][:, off:off + cnt]), k
+        torch.testing.assert_close(shard.t["obs"], whole.t["obs"][:, :, off:off + cnt], rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(shard.t["reward"], whole.t["reward"][:, off:off + cnt], rtol=1e-6, atol=1e-6)
+    assert len(seen) >= 4            # the base power really moved at the updates
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [40, 1001])      # below / above interp_nb_agents = 100 (all houses / 100 drawn from the whole env)
+def test_hip_sharded_interpolated_base_power_two_ranks_one_gpu(N):
+    _spawn(_hip_sharded_interp_worker, 2, N)
