@@ -293,6 +293,22 @@ int mdr_env_interp_apply(mdr_env_t *env, void *stream);
 int32_t mdr_obs_vector_length(const mdr_obs_spec_t *spec);
 int mdr_env_obs_vector(mdr_env_t *env, const mdr_obs_spec_t *spec, float *out, void *stream);
 
+/* Sharded houses: the neighbour messages cross shard edges ("halo exchange").  Three steps per observation:
+ *   mdr_env_obs_messages    - SingleHouse.message (env 624-662) of every LOCAL house as a record of
+ *                             mdr_obs_message_fields(spec) floats (diff/5, sso, curr/norm, max/norm, [Ua Cm Ca Hm / def],
+ *                             [COP latent capacity / def]) -> messages[e][h][:], h < nb_houses, row stride
+ *                             entries_per_env records;
+ *   caller                  - copies the records of the remote senders its houses listen to behind the local ones
+ *                             (slots nb_houses .. entries_per_env-1): peer copies or an all-gather of the exported records;
+ *   mdr_env_obs_vector_ext  - as mdr_env_obs_vector, but message slot m of house h is the record
+ *                             messages[e][spec->links[h * nb_comm + m]] (links = record slots, not house ids).
+ * Own columns, comm defects (drawn per global house index) and layouts are those of mdr_env_obs_vector; an unsharded
+ * handle may use the pair too (entries_per_env = nb_houses, links = house ids).  random_links is not available here. */
+int32_t mdr_obs_message_fields(const mdr_obs_spec_t *spec);
+int mdr_env_obs_messages(mdr_env_t *env, const mdr_obs_spec_t *spec, float *messages, int64_t entries_per_env, void *stream);
+int mdr_env_obs_vector_ext(mdr_env_t *env, const mdr_obs_spec_t *spec, const float *messages, int64_t entries_per_env,
+                           float *out, void *stream);
+
 /* Cursor: k = number of steps taken this episode (env.datetime == start_datetime + k * time_step, env 189);
  * j0 = time index of table row 0. */
 int mdr_env_cursor(const mdr_env_t *env, int64_t *k, int64_t *j0);

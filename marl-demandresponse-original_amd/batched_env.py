@@ -398,7 +398,7 @@ class BatchedDemandResponseEnv:
         return res
 
     # ------------------------------------------------------------------ full normStateDict vector
-    def _obs_spec(self, layout: str) -> nat.MdrObsSpec:
+    def _obs_spec(self, layout: str, with_links: bool = True) -> nat.MdrObsSpec:
         from .comm import build_comm_links, nb_comm
         env = self.config["default_env_prop"]
         cluster, sp, mp = env["cluster_prop"], env["state_properties"], env["message_properties"]
@@ -414,11 +414,13 @@ class BatchedDemandResponseEnv:
             spec.random_links = 1
         if mode == "no_message":
             spec.nb_comm = 0
-        if getattr(self, "_links_dev", None) is None and mode not in ("neighbours", "no_message", "random_sample"):
+        if not with_links:
+            pass
+        elif getattr(self, "_links_dev", None) is None and mode not in ("neighbours", "no_message", "random_sample"):
             links = build_comm_links(cluster)
             table = np.array([links[i] for i in range(self.nb_agents)], dtype=np.int32).reshape(self.nb_agents, -1)
             self._links_dev = torch.from_numpy(table).to(self.device)
-        if mode not in ("neighbours", "no_message", "random_sample") or getattr(self, "_links_forced", False):
+        if with_links and (mode not in ("neighbours", "no_message", "random_sample") or getattr(self, "_links_forced", False)):
             spec.nb_comm = int(self._links_dev.shape[1])
             spec.links = self._links_dev.data_ptr() if spec.nb_comm > 0 else None
         spec.comm_defect_prob = float(cluster["comm_defect_prob"])
@@ -434,7 +436,10 @@ class BatchedDemandResponseEnv:
         table = np.ascontiguousarray(np.asarray(table, dtype=np.int32)).reshape(self.nb_agents, -1)
         if table.size and (table.min() < 0 or table.max() >= self.nb_agents):
             raise ValueError("sender ids must be in [0, nb_agents)")
-        self._links_dev = torch.from_numpy(table).to(self.device)
+        self._links_global = table
+        self._halo = None
+        if not self.sharded:
+            self._links_dev = torch.from_numpy(table).to(self.device)
         self._links_forced = True
 
     def obs_vector_length(self) -> int:
@@ -445,7 +450,15 @@ class BatchedDemandResponseEnv:
         """utils.normStateDict (utils.py:740-880) of every house, messages included, as one tensor:
         ``planes`` -> float32 [F, E, N] (feature-major), ``rows`` -> float32 [E, N, F] (what Actor(num_state) eats).
         Feature order is normStateDict's; F = 11 (+ optional state columns) + nb_comm * 4 (+ optional message columns)."""
+        if self.sharded:      # the messages cross shard edges: message records, ONE gather of the exported ones, ext kernel
+            if out is not None:
+                raise ValueError("obs_vector over sharded houses allocates its own output")
+            padded = self._obs_messages()
+            return self._obs_from_gathered(layout, self._exchange().gather_messages(self, padded))
         spec = self._obs_spec(layout)
+        return self._obs_launch(layout, spec, out, None)
+
+    def _obs_launch(self, layout, spec, out, messages):
         F = int(self._lib.mdr_obs_vector_length(C.byref(spec)))
         E, N = self.nb_envs, self.nb_houses
         shape = (F, E, N) if layout == "planes" else (E, N, F)
@@ -468,9 +481,60 @@ class BatchedDemandResponseEnv:
         elif not out.is_contiguous():
             raise ValueError("rows output must be contiguous")
         with torch.cuda.device(self.device):
-            rc = self._lib.mdr_env_obs_vector(self._handle, C.byref(spec), C.c_void_p(out.data_ptr()), self._stream())
-            nat.check(self._lib, self._handle, rc, "mdr_env_obs_vector")
+            if messages is None:
+                rc = self._lib.mdr_env_obs_vector(self._handle, C.byref(spec), C.c_void_p(out.data_ptr()), self._stream())
+                nat.check(self._lib, self._handle, rc, "mdr_env_obs_vector")
+            else:
+                rc = self._lib.mdr_env_obs_vector_ext(self._handle, C.byref(spec), C.c_void_p(messages.data_ptr()),
+                                                      int(messages.shape[1]), C.c_void_p(out.data_ptr()), self._stream())
+                nat.check(self._lib, self._handle, rc, "mdr_env_obs_vector_ext")
         return out
+
+    # sharded houses: SURVEY 8e "halo exchange" of the neighbour messages
+    def _halo_plan(self):
+        from .comm import links_array
+        from .sharding import HaloPlan
+        plan = getattr(self, "_halo", None)
+        if plan is None:
+            cluster = self.config["default_env_prop"]["cluster_prop"]
+            if cluster["agents_comm_mode"] == "random_sample" and not getattr(self, "_links_forced", False):
+                raise NotImplementedError("agents_comm_mode 'random_sample' is not available over sharded houses "
+                                          "(every house would need every other house's message each step)")
+            links = self._links_global if getattr(self, "_links_forced", False) else links_array(cluster)
+            ranges, rank = self._exchange().ranges(self)
+            plan = self._halo = HaloPlan(links, ranges, rank).to(self.device)
+        return plan
+
+    def _obs_spec_sharded(self, layout, plan):
+        spec = self._obs_spec(layout, with_links=False)
+        spec.random_links = 0
+        spec.nb_comm = int(plan.slots.shape[1])
+        spec.links = plan.slots_dev.data_ptr() if spec.nb_comm > 0 else None
+        return spec
+
+    def _obs_messages(self) -> torch.Tensor:
+        """Message records of the local houses -> self._msg[:, :n_local]; returns the exported ones padded to the
+        group-wide maximum, [E, export_max, mf], ready for the gather."""
+        plan = self._halo_plan()
+        spec = self._obs_spec_sharded("rows", plan)
+        mf = int(self._lib.mdr_obs_message_fields(C.byref(spec)))
+        E = self.nb_envs
+        msg = getattr(self, "_msg", None)
+        if msg is None or tuple(msg.shape) != (E, plan.entries, mf):
+            msg = self._msg = torch.zeros((E, plan.entries, mf), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self._lib.mdr_env_obs_messages(self._handle, C.byref(spec), C.c_void_p(msg.data_ptr()), plan.entries, self._stream())
+            nat.check(self._lib, self._handle, rc, "mdr_env_obs_messages")
+        padded = torch.zeros((E, plan.export_max, mf), dtype=torch.float32, device=self.device)
+        if len(plan.export_idx):
+            padded[:, :len(plan.export_idx)] = msg[:, plan.export_dev]
+        return padded
+
+    def _obs_from_gathered(self, layout, gathered) -> torch.Tensor:
+        plan = self._halo_plan()
+        if plan.halo:
+            self._msg[:, plan.n_local:] = plan.pick(gathered)
+        return self._obs_launch(layout, self._obs_spec_sharded(layout, plan), None, self._msg)
 
     # ------------------------------------------------------------------ views of the state
     def cursor(self) -> Tuple[int, int]:

@@ -53,3 +53,22 @@ def build_comm_links(cluster_prop: dict) -> Optional[Dict[int, List[int]]]:
     if mode == "no_message":
         return {i: [] for i in ids}
     raise ValueError("Cluster property: unknown agents_comm_mode '{}'.".format(mode))
+
+
+def links_array(cluster_prop: dict):
+    """The static link table as int32 [nb_agents, c] (None for random_sample).  'neighbours' is built with array
+    arithmetic so that a 1,000,000-house env does not go through a Python dict."""
+    import numpy as np
+    n = int(cluster_prop["nb_agents"])
+    c = nb_comm(cluster_prop)
+    mode = cluster_prop["agents_comm_mode"]
+    if mode == "random_sample":
+        return None
+    if mode == "no_message" or c == 0 and mode == "neighbours":
+        return np.zeros((n, 0), dtype=np.int32)
+    if mode == "neighbours":
+        before = c // 2
+        offsets = np.concatenate([np.arange(-before, 0), np.arange(1, c - before + 1)])
+        return ((np.arange(n, dtype=np.int64)[:, None] + offsets[None, :]) % n).astype(np.int32)
+    links = build_comm_links(cluster_prop)
+    return np.array([links[i] for i in range(n)], dtype=np.int32).reshape(n, -1)

@@ -584,14 +584,14 @@ int32_t mdr_obs_vector_length(const mdr_obs_spec_t* spec) {
   return mdr::obs_vector_length(*spec);
 }
 
-int mdr_env_obs_vector(mdr_env_t* env, const mdr_obs_spec_t* spec, float* out, void* stream) {
-  if (!env || !spec || !out) return MDR_ERR_INVALID;
+// Checks shared by the observation entry points and the argument block they all start from.
+static int obs_args(mdr_env_t* env, const mdr_obs_spec_t* spec, bool need_layout, mdr::ObsArgs* out_args) {
   if (spec->struct_size != sizeof(mdr_obs_spec_t)) return fail(env, MDR_ERR_INVALID, "mdr_obs_spec_t size mismatch (ABI)");
   if (!env->bound || !env->has_tables) return fail(env, MDR_ERR_UNBOUND, "no episode: call reset/load_episode and begin_episode first");
   const mdr_config_t& c = env->cfg;
-  if (c.nb_houses_total != c.nb_houses) return fail(env, MDR_ERR_UNSUPPORTED, "obs_vector needs all houses of an env on one device");
-  if (spec->layout != MDR_OBS_PLANES && spec->layout != MDR_OBS_ROWS) return fail(env, MDR_ERR_INVALID, "unknown obs layout");
-  if (spec->nb_comm < 0 || spec->nb_comm > c.nb_houses - 1 + (c.nb_houses == 1 ? 1 : 0) || (c.nb_houses == 1 && spec->nb_comm != 0))
+  if (need_layout && spec->layout != MDR_OBS_PLANES && spec->layout != MDR_OBS_ROWS) return fail(env, MDR_ERR_INVALID, "unknown obs layout");
+  const int n = c.nb_houses_total;
+  if (spec->nb_comm < 0 || spec->nb_comm > n - 1 + (n == 1 ? 1 : 0) || (n == 1 && spec->nb_comm != 0))
     return fail(env, MDR_ERR_INVALID, "nb_comm must be in [0, nb_houses - 1]");
   if (spec->random_links && spec->nb_comm > 16) return fail(env, MDR_ERR_UNSUPPORTED, "random_sample links support nb_comm <= 16");
   if (!(spec->comm_defect_prob >= 0.0 && spec->comm_defect_prob <= 1.0)) return fail(env, MDR_ERR_INVALID, "comm_defect_prob outside [0, 1]");
@@ -611,7 +611,6 @@ int mdr_env_obs_vector(mdr_env_t* env, const mdr_obs_spec_t* spec, float* out, v
   a.t0 = b.t0;
   a.links = spec->random_links ? nullptr : spec->links;
   a.random_links = spec->random_links ? 1 : 0;
-  a.out = out;
   a.plane = (int64_t)c.nb_envs * c.nb_houses;
   a.out_plane = spec->out_plane_stride > 0 ? spec->out_plane_stride : a.plane;
   if (a.out_plane < a.plane) return fail(env, MDR_ERR_INVALID, "out_plane_stride smaller than nb_envs * nb_houses");
@@ -620,6 +619,7 @@ int mdr_env_obs_vector(mdr_env_t* env, const mdr_obs_spec_t* spec, float* out, v
   a.f_hour = spec->state_hour; a.f_day = spec->state_day; a.f_solar = spec->state_solar_gain;
   a.f_thermal = spec->state_thermal; a.f_hvac = spec->state_hvac;
   a.m_thermal = spec->message_thermal; a.m_hvac = spec->message_hvac;
+  a.mf = mdr::obs_message_fields(*spec);
   a.env_offset = c.env_offset; a.house_offset = c.house_offset;
   a.k0 = (uint32_t)(env->seed & 0xFFFFFFFFull); a.k1 = (uint32_t)(env->seed >> 32); a.episode = env->episode;
   a.defect_prob = (float)spec->comm_defect_prob;
@@ -629,8 +629,55 @@ int mdr_env_obs_vector(mdr_env_t* env, const mdr_obs_spec_t* spec, float* out, v
   a.inv_cap = (float)(1.0 / spec->def_capacity); a.inv_Ua = (float)(1.0 / spec->def_Ua); a.inv_Cm = (float)(1.0 / spec->def_Cm);
   a.inv_Ca = (float)(1.0 / spec->def_Ca); a.inv_Hm = (float)(1.0 / spec->def_Hm); a.inv_COP = (float)(1.0 / spec->def_COP);
   a.inv_latent = (float)(1.0 / spec->def_latent);
+  *out_args = a;
+  return MDR_OK;
+}
+
+int mdr_env_obs_vector(mdr_env_t* env, const mdr_obs_spec_t* spec, float* out, void* stream) {
+  if (!env || !spec || !out) return MDR_ERR_INVALID;
+  if (env->cfg.nb_houses_total != env->cfg.nb_houses)
+    return fail(env, MDR_ERR_UNSUPPORTED, "sharded houses: mdr_env_obs_messages, halo exchange, mdr_env_obs_vector_ext");
+  mdr::ObsArgs a;
+  int rc = obs_args(env, spec, true, &a);
+  if (rc != MDR_OK) return rc;
+  a.out = out;
   hipError_t e = mdr::launch_obs_vector(a, spec->layout, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "obs_vector");
+  return MDR_OK;
+}
+
+int32_t mdr_obs_message_fields(const mdr_obs_spec_t* spec) {
+  if (!spec || spec->struct_size != sizeof(mdr_obs_spec_t)) return -1;
+  return mdr::obs_message_fields(*spec);
+}
+
+int mdr_env_obs_messages(mdr_env_t* env, const mdr_obs_spec_t* spec, float* messages, int64_t entries_per_env, void* stream) {
+  if (!env || !spec || !messages) return MDR_ERR_INVALID;
+  mdr::ObsArgs a;
+  int rc = obs_args(env, spec, false, &a);
+  if (rc != MDR_OK) return rc;
+  if (entries_per_env < env->cfg.nb_houses) return fail(env, MDR_ERR_INVALID, "entries_per_env smaller than nb_houses");
+  a.msg_ext_out = messages;
+  a.ext_entries = entries_per_env;
+  hipError_t e = mdr::launch_obs_messages(a, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(env, e, "obs_messages");
+  return MDR_OK;
+}
+
+int mdr_env_obs_vector_ext(mdr_env_t* env, const mdr_obs_spec_t* spec, const float* messages, int64_t entries_per_env, float* out,
+                           void* stream) {
+  if (!env || !spec || !out) return MDR_ERR_INVALID;
+  mdr::ObsArgs a;
+  int rc = obs_args(env, spec, true, &a);
+  if (rc != MDR_OK) return rc;
+  if (spec->random_links) return fail(env, MDR_ERR_UNSUPPORTED, "random_sample links need every house's message: not available through record slots");
+  if (spec->nb_comm > 0 && (!messages || !spec->links)) return fail(env, MDR_ERR_INVALID, "messages and a link table of record slots are required");
+  if (entries_per_env < 0) return fail(env, MDR_ERR_INVALID, "entries_per_env must be >= 0");
+  a.out = out;
+  a.msg_ext_in = messages;
+  a.ext_entries = entries_per_env;
+  hipError_t e = mdr::launch_obs_vector_ext(a, spec->layout, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(env, e, "obs_vector_ext");
   return MDR_OK;
 }
 

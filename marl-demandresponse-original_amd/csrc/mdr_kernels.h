@@ -115,6 +115,12 @@ struct ObsArgs {
   int64_t env_offset, house_offset;
   uint32_t k0, k1, episode;
   float defect_prob;
+  // sharded houses: message records [E][ext_entries][mf] = the local houses' messages followed by the halo the caller
+  // fetched from the other shards; `links` then holds record slots instead of house ids
+  const float* msg_ext_in;
+  float* msg_ext_out;
+  int64_t ext_entries;
+  int mf;                   // floats per message record: 4 + 4 * m_thermal + 3 * m_hvac
   int lds_entries;          // sender entries staged per workgroup by k_obs_planes4 (set by the launcher)
   uint32_t magic_n;         // ((1 << 20) + N - 1) / N: r / N == (r * magic_n) >> 20 for r < 1024 (set by the launcher)
   float obs_tshift;
@@ -153,6 +159,9 @@ bool rollout_fused_supported(const StepPlan& p);
 hipError_t launch_rollout_accumulate(const StepArgs& a, const RolloutArgs& ro, hipStream_t s);   // after ONE single step
 hipError_t launch_rollout_fused(const StepArgs& a, const RolloutArgs& r, const StepPlan& p, hipStream_t s);
 hipError_t launch_obs_vector(const ObsArgs& a, int layout, hipStream_t s);
+hipError_t launch_obs_messages(const ObsArgs& a, hipStream_t s);               // msg_ext_out[e][h][:] for the local houses
+hipError_t launch_obs_vector_ext(const ObsArgs& a, int layout, hipStream_t s);  // senders read from msg_ext_in through links
+int obs_message_fields(const mdr_obs_spec_t& s);
 int obs_vector_length(const mdr_obs_spec_t& spec);
 hipError_t launch_step_begin_split(const StepArgs& a, hipStream_t s);
 hipError_t launch_step_end_split(const StepArgs& a, hipStream_t s);

@@ -1274,8 +1274,50 @@ __device__ __forceinline__ MsgFields sender_from_lds(const ObsArgs& a, const flo
   return s;
 }
 
-// ---- simple form: one thread per house, direct (4-byte) stores; fallback for shapes the other kernels cannot hold
-template <int LAYOUT, bool RANDOM>
+// message record of a sender slot (sharded houses: local messages followed by the halo), fields in MsgFields order
+__device__ __forceinline__ MsgFields sender_from_ext(const ObsArgs& a, int e, int slot) {
+  const float* r = a.msg_ext_in + ((int64_t)e * a.ext_entries + slot) * a.mf;
+  MsgFields s;
+  s.diff = r[0];
+  s.sso = r[1];
+  s.curr = r[2];
+  s.pmax = r[3];
+  int q = 4;
+  if (a.m_thermal) {
+    s.Ua = r[q]; s.Cm = r[q + 1]; s.Ca = r[q + 2]; s.Hm = r[q + 3];
+    q += 4;
+  }
+  if (a.m_hvac) {
+    s.COP = r[q]; s.latent = r[q + 1]; s.cap = r[q + 2];
+  }
+  return s;
+}
+
+// SingleHouse.message (env 624-662) of every local house as one record of mf floats: what a shard exports to its peers
+__global__ __launch_bounds__(256) void k_obs_messages(ObsArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.plane) return;
+  const int e = (int)(i / a.N);
+  const int h = (int)(i - (int64_t)e * a.N);
+  const MsgFields m = sender_from_global(a, i);
+  float* r = a.msg_ext_out + ((int64_t)e * a.ext_entries + h) * a.mf;
+  r[0] = m.diff;
+  r[1] = m.sso;
+  r[2] = m.curr;
+  r[3] = m.pmax;
+  int q = 4;
+  if (a.m_thermal) {
+    r[q] = m.Ua; r[q + 1] = m.Cm; r[q + 2] = m.Ca; r[q + 3] = m.Hm;
+    q += 4;
+  }
+  if (a.m_hvac) {
+    r[q] = m.COP; r[q + 1] = m.latent; r[q + 2] = m.cap;
+  }
+}
+
+// ---- simple form: one thread per house, direct (4-byte) stores; fallback for shapes the other kernels cannot hold.
+// EXT: the senders are message records (sender_from_ext) addressed through the link table - the sharded-houses form.
+template <int LAYOUT, bool RANDOM, bool EXT = false>
 __global__ __launch_bounds__(256) void k_obs_vector(ObsArgs a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.plane) return;
@@ -1290,7 +1332,10 @@ __global__ __launch_bounds__(256) void k_obs_vector(ObsArgs a) {
                     else a.out[i * a.F + f] = v[0];
                     ++f;
                   },
-                  [&](int m, int) { return sender_from_global(a, base + (RANDOM ? smp.next(a, e, h) : sender_id(a, h, m))); });
+                  [&](int m, int) {
+                    if (EXT) return sender_from_ext(a, e, a.links[(int64_t)h * a.c + m]);
+                    return sender_from_global(a, base + (RANDOM ? smp.next(a, e, h) : sender_id(a, h, m)));
+                  });
 }
 
 // A workgroup's share of the houses ("tile"): a TILE-house slice of one env when N >= TILE, or floor(TILE / N) WHOLE envs
@@ -1492,8 +1537,8 @@ __global__ __launch_bounds__(TILE) void k_obs_rows(ObsArgs a) {
   const int before = a.c / 2;
   float* ownbuf = lds;                                   // [TILE][ownp]
   float* msg = ownbuf + TILE * ownp;                     // [span][mf]
-  float* inv_lock = msg + span * mf;                     // [TILE]
-  uint32_t* dead = reinterpret_cast<uint32_t*>(inv_lock + TILE);   // [TILE] bit m: message slot m is defective
+  float* lock_f = msg + span * mf;                     // [TILE]
+  uint32_t* dead = reinterpret_cast<uint32_t*>(lock_f + TILE);   // [TILE] bit m: message slot m is defective
   uint32_t* desc = dead + TILE;                          // [F] where element f of a row comes from
   const int msg_base = TILE * ownp;                      // index of msg[] inside lds[]
   constexpr uint32_t D_MSG = 1u << 31, D_SSO = 1u << 30;
@@ -1531,7 +1576,7 @@ __global__ __launch_bounds__(TILE) void k_obs_rows(ObsArgs a) {
     int f = 0;
     obs_features<1, false>(a, e, h, base + h, [&](const float* v) { ownbuf[tid * ownp + f] = v[0]; ++f; },
                            [&](int, int) { return MsgFields{}; });
-    inv_lock[tid] = 1.0f / (float)a.lockout[base + h];
+    lock_f[tid] = (float)a.lockout[base + h];   // kept as L: sso / L must round as the other kernels' division does
     uint32_t mask = 0;
     if (a.defect_prob > 0.0f) {
       u32x4 rnd{0, 0, 0, 0};
@@ -1561,7 +1606,7 @@ __global__ __launch_bounds__(TILE) void k_obs_rows(ObsArgs a) {
       const uint32_t d = desc[ff];
       const bool is_msg = (d & D_MSG) != 0u;
       float val = lds[(is_msg ? msg_base + rc * mf : rc * ownp) + (int)(d & 0xFFFFu)];
-      if (d & D_SSO) val *= inv_lock[rc];               // sender's seconds_since_off over the RECEIVER's lockout (utils.py:849-851)
+      if (d & D_SSO) val = val / lock_f[rc];          // sender's seconds_since_off over the RECEIVER's lockout (utils.py:849-851)
       if (defects && is_msg && ((dead[rc] >> ((d >> 16) & 63u)) & 1u)) val = 0.0f;
       v[q] = val;
       if (++ff == a.F) {
@@ -1606,7 +1651,7 @@ __global__ __launch_bounds__(TILE) void k_obs_rows_default(ObsArgs a) {
     int f = 0;
     obs_features<1, false>(a, e, h, i, [&](const float* v) { ownbuf[tid * OWNP + f] = v[0]; ++f; },
                            [&](int, int) { return MsgFields{}; });
-    ownbuf[tid * OWNP + OWN] = 1.0f / (float)a.lockout[i];
+    ownbuf[tid * OWNP + OWN] = (float)a.lockout[i];
   }
   __syncthreads();
   float* dst = a.out + ((int64_t)t.e0 * a.N + t.h0) * F;   // rows * F contiguous floats
@@ -1622,7 +1667,7 @@ __global__ __launch_bounds__(TILE) void k_obs_rows_default(ObsArgs a) {
     const int g = f - OWN;
     const int el = multi ? (int)(((uint32_t)r * a.magic_n) >> 20) : 0;
     float val = msg[4 * (r + C * el) + g + (g >= 20 ? 4 : 0)];
-    if ((g & 3) == 1) val *= ownbuf[r * OWNP + OWN];   // sender's seconds_since_off over the RECEIVER's lockout
+    if ((g & 3) == 1) val = val / ownbuf[r * OWNP + OWN];   // sender's seconds_since_off over the RECEIVER's lockout (a true division, as everywhere else)
     return val;
   };
   if (lead == 0) {   // aligned tile (always the case when N * F % 4 == 0): no edge handling inside the loop
@@ -1649,6 +1694,20 @@ __global__ __launch_bounds__(TILE) void k_obs_rows_default(ObsArgs a) {
       }
     }
   }
+}
+
+int obs_message_fields(const mdr_obs_spec_t& s) { return 4 + (s.message_thermal ? 4 : 0) + (s.message_hvac ? 3 : 0); }
+
+hipError_t launch_obs_messages(const ObsArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_obs_messages, dim3((unsigned)((a.plane + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_obs_vector_ext(const ObsArgs& a, int layout, hipStream_t s) {
+  const dim3 g((unsigned)((a.plane + 255) / 256)), b(256);
+  if (layout == MDR_OBS_PLANES) hipLaunchKernelGGL((k_obs_vector<MDR_OBS_PLANES, false, true>), g, b, 0, s, a);
+  else hipLaunchKernelGGL((k_obs_vector<MDR_OBS_ROWS, false, true>), g, b, 0, s, a);
+  return hipGetLastError();
 }
 
 int obs_vector_length(const mdr_obs_spec_t& s) {

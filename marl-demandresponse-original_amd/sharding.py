@@ -36,6 +36,65 @@ def house_shard(nb_houses_total: int, world_size: int, rank: int, granule: int =
     return start, count
 
 
+class HaloPlan:
+    """Who needs whose messages, for one rank of a sharded-houses layout (halo exchange).
+
+    From the GLOBAL link table [N_total, c] (replicated: it is static) and the ranks' house ranges every rank derives,
+    without communication, the same picture:  need[q] = the remote houses rank q's houses listen to;  export[r] = the
+    houses of rank r that anyone else needs (sorted);  per step every rank contributes its export records, padded to
+    `export_max`, to ONE all-gather, and picks its halo out of the gathered block with (src_rank, src_pos).
+
+    slots      int32 [n_local, c]  record slot of every link: local house -> its index, remote -> n_local + halo index
+    export_idx int64 [X_r]         local indices of the houses this rank exports
+    src_rank, src_pos int64 [H]    where each halo record sits in the gathered [world, E, export_max, mf] block"""
+
+    def __init__(self, links, ranges: Sequence[Tuple[int, int]], rank: int):
+        import numpy as np
+        links = np.asarray(links, dtype=np.int64)
+        world = len(ranges)
+        starts = np.array([r[0] for r in ranges], dtype=np.int64)
+        needs = []
+        for (off, cnt) in ranges:
+            mine = links[off:off + cnt]
+            remote = mine[(mine < off) | (mine >= off + cnt)]
+            needs.append(np.unique(remote))
+        wanted = np.unique(np.concatenate(needs)) if world > 1 else np.zeros(0, dtype=np.int64)
+        owner_of = lambda ids: np.searchsorted(starts, ids, side="right") - 1
+        exports = [wanted[owner_of(wanted) == r] for r in range(world)]          # sorted global ids each rank exports
+        self.export_max = int(max((len(x) for x in exports), default=0))
+        off, cnt = ranges[rank]
+        self.n_local = int(cnt)
+        self.export_idx = exports[rank] - off
+        need = needs[rank]
+        self.halo = int(len(need))
+        self.src_rank = owner_of(need)
+        self.src_pos = np.zeros(len(need), dtype=np.int64)
+        for r in range(world):
+            sel = self.src_rank == r
+            self.src_pos[sel] = np.searchsorted(exports[r], need[sel])
+        mine = links[off:off + cnt]
+        local = (mine >= off) & (mine < off + cnt)
+        self.slots = np.where(local, mine - off, cnt + np.searchsorted(need, mine)).astype(np.int32)
+        self.entries = self.n_local + self.halo
+
+    def to(self, device):
+        import torch
+        self.slots_dev = torch.from_numpy(np_contig(self.slots)).to(device)
+        self.export_dev = torch.from_numpy(self.export_idx.astype("int64")).to(device)
+        self.src_rank_dev = torch.from_numpy(self.src_rank.astype("int64")).to(device)
+        self.src_pos_dev = torch.from_numpy(self.src_pos.astype("int64")).to(device)
+        return self
+
+    def pick(self, gathered):
+        """halo records [E, H, mf] out of the gathered block [world, E, export_max, mf]"""
+        return gathered[self.src_rank_dev, :, self.src_pos_dev, :].permute(1, 0, 2)
+
+
+def np_contig(a):
+    import numpy as np
+    return np.ascontiguousarray(a)
+
+
 class TorchDistExchange:
     """The two exchanges of the sharded-houses layout over torch.distributed (RCCL on the GPU box, gloo in CPU tests):
     one SUM all-reduce of `max_power` per episode and ONE all-gather of the [3][E] aggregate block per step."""
@@ -51,6 +110,23 @@ class TorchDistExchange:
     def sum_base_power(self, env) -> None:
         import torch.distributed as dist
         dist.all_reduce(env.t["base_power"], op=dist.ReduceOp.SUM, group=self.process_group)
+
+    def ranges(self, env):
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(self.process_group), dist.get_rank(self.process_group)
+        ranges = [house_shard(env.nb_agents, world, r) for r in range(world)]
+        if ranges[rank] != (env.house_offset, env.nb_houses):
+            raise ValueError("obs_vector over sharded houses needs the sharding.house_shard partition")
+        return ranges, rank
+
+    def gather_messages(self, env, padded):
+        """`padded`: this rank's export records [E, export_max, mf] -> every rank's [world, E, export_max, mf]."""
+        import torch
+        import torch.distributed as dist
+        world = dist.get_world_size(self.process_group)
+        out = torch.empty((world,) + tuple(padded.shape), dtype=padded.dtype, device=padded.device)
+        dist.all_gather_into_tensor(out.view(world * padded.shape[0], padded.shape[1], padded.shape[2]), padded, group=self.process_group)
+        return out
 
     def gather_totals(self, env):
         import torch
@@ -152,6 +228,26 @@ class LocalShardGroup:
         if self.nb_shards > 1:
             self._finish()
         return [(e.t["obs"], e.t["reward"]) for e in self.shards]
+
+    def ranges(self, env):
+        return [(e.house_offset, e.nb_houses) for e in self.shards], self.shards.index(env)
+
+    def gather_messages(self, env, padded):
+        raise RuntimeError("shards of a LocalShardGroup are observed through the group, not one by one")
+
+    def obs_vector(self, layout: str = "rows"):
+        """utils.normStateDict of every house incl. the neighbour messages that cross shard edges: one tensor per shard
+        (`rows` [E, n_r, F] / `planes` [F, E, n_r]).  Same three steps as the torch.distributed path - message records,
+        one gather of the exported records, observation from record slots - with the gather done by device copies."""
+        import torch
+        first = self.shards[0]
+        if self.nb_shards == 1:
+            return [first.obs_vector(layout)]
+        padded = [env._obs_messages() for env in self.shards]
+        self._sync_devices()
+        gathered = torch.stack([p.to(first.device) for p in padded])
+        return [env._obs_from_gathered(layout, gathered if env.device == first.device else gathered.to(env.device))
+                for env in self.shards]
 
     def cluster_hvac_power(self):
         return self.shards[0].t["P"]

@@ -146,3 +146,82 @@ def test_sharded_interp_update_must_be_exchanged_before_the_next_step():
     assert not shard._interp_due()
     with pytest.raises(ValueError, match="no base power update is due"):
         shard._interp_local()
+
+
+def _obs_cfg(N, mode, nb_comm, flags, defect=0.0, row=None):
+    cfg = _cfg()
+    env = cfg["default_env_prop"]
+    cl = env["cluster_prop"]
+    cl["nb_agents"], cl["agents_comm_mode"], cl["nb_agents_comm"], cl["comm_defect_prob"] = N, mode, nb_comm, defect
+    if row:
+        cl["agents_comm_parameters"]["neighbours_2D"] = {"row_size": row, "distance_comm": 2}
+    for k in ("hour", "day", "solar_gain", "thermal", "hvac"):
+        env["state_properties"][k] = flags
+    for k in ("thermal", "hvac"):
+        env["message_properties"][k] = flags
+    return cfg
+
+
+@pytest.mark.parametrize("N,shards,mode,nb_comm,flags,defect", [
+    (1000, 3, "neighbours", 10, False, 0.0), (1000, 8, "neighbours", 7, True, 0.3), (64, 2, "neighbours", 63, False, 0.0),
+    (1001, 4, "closed_groups", 6, False, 0.0), (400, 3, "random_fixed", 5, True, 0.0), (900, 4, "neighbours_2D", 10, False, 0.2),
+    (500, 2, "no_message", 10, True, 0.0), (120000, 8, "neighbours", 10, False, 0.0)])
+def test_sharded_obs_vector_equals_unsharded(N, shards, mode, nb_comm, flags, defect):
+    """The flat normStateDict vector over sharded houses (message records + one gather of the exported records + record
+    slots) is bit for bit the unsharded one, for every static topology, with comm defects and the optional columns."""
+    import random
+    import mdr_amd
+    from mdr_amd.comm import links_array
+    from mdr_amd.sharding import LocalShardGroup
+    cfg = _obs_cfg(N, mode, nb_comm, flags, defect, row=30 if mode == "neighbours_2D" else None)
+    E = 2
+    whole = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=4)
+    group = LocalShardGroup(cfg, nb_envs=E, nb_shards=shards, devices=("cuda:0",), seed=4)
+    if mode == "random_fixed":       # the table is drawn with `random`: draw it once and hand it to both
+        random.seed(1)
+        table = links_array(cfg["default_env_prop"]["cluster_prop"])
+        whole.set_comm_links(table)
+        for e in group.shards:
+            e.set_comm_links(table)
+    whole.reset(episode=0)
+    group.reset(episode=0)
+    for t in range(3):
+        for layout in ("rows", "planes"):
+            ref = whole.obs_vector(layout)
+            parts = group.obs_vector(layout)
+            got = torch.cat(parts, dim=1 if layout == "rows" else 2)
+            assert got.shape == ref.shape
+            assert torch.equal(got, ref), "%s step %d" % (layout, t)
+        whole.step_bangbang()
+        group.step_bangbang()
+    plan = group.shards[0]._halo_plan()
+    if mode == "neighbours" and nb_comm < N // shards:
+        assert plan.halo == nb_comm and plan.export_max == nb_comm      # c/2 houses from each side, nothing more
+    if mode == "no_message":
+        assert plan.halo == 0
+
+
+def test_c5_sharded_obs_vector_at_full_size():
+    import mdr_amd
+    from mdr_amd.sharding import LocalShardGroup
+    cfg = _obs_cfg(N_C5, "neighbours", 10, False)
+    whole = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=1, device="cuda:0", seed=2)
+    group = LocalShardGroup(cfg, nb_envs=1, nb_shards=8, devices=("cuda:0",), seed=2)
+    whole.reset(episode=0)
+    group.reset(episode=0)
+    whole.rollout(3)
+    for _ in range(3):
+        group.step_bangbang()
+    ref = whole.obs_vector("rows")
+    got = torch.cat(group.obs_vector("rows"), dim=1)
+    assert ref.shape == (1, N_C5, 51) and torch.equal(got, ref)
+
+
+def test_sharded_obs_vector_refuses_random_sample():
+    import mdr_amd
+    from mdr_amd.sharding import LocalShardGroup
+    cfg = _obs_cfg(400, "random_sample", 5, False)
+    group = LocalShardGroup(cfg, nb_envs=1, nb_shards=2, devices=("cuda:0",), seed=2)
+    group.reset(episode=0)
+    with pytest.raises(NotImplementedError):
+        group.obs_vector("rows")

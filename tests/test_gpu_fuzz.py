@@ -133,6 +133,7 @@ def test_fuzz_obs_vector_vs_oracle(idx):
     ref = ora.norm_state(cfg, links)
     assert env.obs_vector_length() == ref.shape[-1]
     np.testing.assert_allclose(env.obs_vector("rows").cpu().numpy(), ref, rtol=3e-5, atol=3e-6, err_msg="rows, case %d" % idx)
+    assert torch.equal(env.obs_vector("rows"), env.obs_vector("planes").permute(1, 2, 0)), "layouts differ bitwise, case %d" % idx
     np.testing.assert_allclose(env.obs_vector("planes").cpu().numpy(), np.moveaxis(ref, -1, 0), rtol=3e-5, atol=3e-6, err_msg="planes, case %d" % idx)
 
 

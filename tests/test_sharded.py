@@ -217,3 +217,34 @@ def _hip_sharded_interp_worker(rank, world, port, N):
 @pytest.mark.parametrize("N", [40, 1001])      # below / above interp_nb_agents = 100 (all houses / 100 drawn from the whole env)
 def test_hip_sharded_interpolated_base_power_two_ranks_one_gpu(N):
     _spawn(_hip_sharded_interp_worker, 2, N)
+
+
+def _hip_sharded_obs_worker(rank, world, port, N, mode):
+    """obs_vector over sharded houses through torch.distributed: ONE all-gather of the exported message records."""
+    import mdr_amd
+    from mdr_amd.sharding import house_shard
+    _init(rank, world, port)
+    torch.cuda.set_device(0)
+    E = 2
+    cfg = _cfg(N, **{"noise_house_prop.noise_mode": "big_noise", "noise_hvac_prop.noise_mode": "big_noise",
+                     "default_env_prop.cluster_prop.agents_comm_mode": mode, "default_env_prop.cluster_prop.nb_agents_comm": 6,
+                     "default_env_prop.cluster_prop.comm_defect_prob": 0.25,
+                     "default_env_prop.message_properties.thermal": True})
+    off, cnt = house_shard(N, world, rank)
+    shard = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=3, house_shard=(off, cnt))
+    whole = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=3)
+    shard.reset(episode=0)
+    whole.reset(episode=0)
+    for t in range(3):
+        assert torch.equal(shard.obs_vector("rows"), whole.obs_vector("rows")[:, off:off + cnt])
+        assert torch.equal(shard.obs_vector("planes"), whole.obs_vector("planes")[:, :, off:off + cnt])
+        shard.step_bangbang()
+        whole.step_bangbang()
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,mode", [(1000, "neighbours"), (602, "closed_groups")])
+def test_hip_sharded_obs_vector_two_ranks_one_gpu(N, mode):
+    _spawn(_hip_sharded_obs_worker, 2, N, mode)
