@@ -1274,6 +1274,15 @@ __device__ __forceinline__ MsgFields sender_from_lds(const ObsArgs& a, const flo
   return s;
 }
 
+// a / L for integer-valued a and L (exact in fp32) with y = RN(1 / L): q = RN(a y), r = a - q L (exact in one fma),
+// RN(q + r y) is the correctly rounded quotient (Markstein; L's significand is never all ones below 2^24 - 1; checked
+// exhaustively for a <= 20000, L <= 3000), i.e. the very bits the `/` of the other kernels gives, in 3 ops instead of ~10
+__device__ __forceinline__ float div_by_lockout(float a, float L, float y) {
+  if (L == 0.0f) return a / L;   // inf / nan exactly as the division produces them
+  const float q = a * y;
+  return __fmaf_rn(__fmaf_rn(-q, L, a), y, q);
+}
+
 // message record of a sender slot (sharded houses: local messages followed by the halo), fields in MsgFields order
 __device__ __forceinline__ MsgFields sender_from_ext(const ObsArgs& a, int e, int slot) {
   const float* r = a.msg_ext_in + ((int64_t)e * a.ext_entries + slot) * a.mf;
@@ -1537,8 +1546,9 @@ __global__ __launch_bounds__(TILE) void k_obs_rows(ObsArgs a) {
   const int before = a.c / 2;
   float* ownbuf = lds;                                   // [TILE][ownp]
   float* msg = ownbuf + TILE * ownp;                     // [span][mf]
-  float* lock_f = msg + span * mf;                     // [TILE]
-  uint32_t* dead = reinterpret_cast<uint32_t*>(lock_f + TILE);   // [TILE] bit m: message slot m is defective
+  float* lock_f = msg + span * mf;                       // [TILE] the receiver's lockout L ...
+  float* lock_r = lock_f + TILE;                         // [TILE] ... and RN(1 / L)
+  uint32_t* dead = reinterpret_cast<uint32_t*>(lock_r + TILE);   // [TILE] bit m: message slot m is defective
   uint32_t* desc = dead + TILE;                          // [F] where element f of a row comes from
   const int msg_base = TILE * ownp;                      // index of msg[] inside lds[]
   constexpr uint32_t D_MSG = 1u << 31, D_SSO = 1u << 30;
@@ -1576,7 +1586,8 @@ __global__ __launch_bounds__(TILE) void k_obs_rows(ObsArgs a) {
     int f = 0;
     obs_features<1, false>(a, e, h, base + h, [&](const float* v) { ownbuf[tid * ownp + f] = v[0]; ++f; },
                            [&](int, int) { return MsgFields{}; });
-    lock_f[tid] = (float)a.lockout[base + h];   // kept as L: sso / L must round as the other kernels' division does
+    lock_f[tid] = (float)a.lockout[base + h];
+    lock_r[tid] = 1.0f / lock_f[tid];
     uint32_t mask = 0;
     if (a.defect_prob > 0.0f) {
       u32x4 rnd{0, 0, 0, 0};
@@ -1606,7 +1617,7 @@ __global__ __launch_bounds__(TILE) void k_obs_rows(ObsArgs a) {
       const uint32_t d = desc[ff];
       const bool is_msg = (d & D_MSG) != 0u;
       float val = lds[(is_msg ? msg_base + rc * mf : rc * ownp) + (int)(d & 0xFFFFu)];
-      if (d & D_SSO) val = val / lock_f[rc];          // sender's seconds_since_off over the RECEIVER's lockout (utils.py:849-851)
+      if (d & D_SSO) val = div_by_lockout(val, lock_f[rc], lock_r[rc]);   // sender's seconds_since_off over the RECEIVER's lockout (utils.py:849-851)
       if (defects && is_msg && ((dead[rc] >> ((d >> 16) & 63u)) & 1u)) val = 0.0f;
       v[q] = val;
       if (++ff == a.F) {
@@ -1632,26 +1643,35 @@ __global__ __launch_bounds__(TILE) void k_obs_rows(ObsArgs a) {
 // neighbours, no link defects): F = 11 + 10 * 4 = 51 is a compile-time constant, so element o of a tile maps to its LDS
 // source with a handful of integer ops: row r = o / 51, f = o % 51; own feature -> own[r][f]; message feature
 // g = f - 11 -> msg[4 (r + 10 env_l + slot) + k] = msg[4 (r + 10 env_l) + g + (g >= 20 ? 4 : 0)] (the sender list skips
-// the house itself after slot 4).  Only compact data is staged in LDS (own features, sender fields, 1 / lockout), the
+// the house itself after slot 4).  Only compact data is staged in LDS (own features, sender fields, sso / lockout pairs), the
 // output rows are generated directly in output order and streamed with 16-byte non-temporal stores.
 template <int TILE>
 __global__ __launch_bounds__(TILE) void k_obs_rows_default(ObsArgs a) {
-  constexpr int OWN = 11, MF = 4, C = 10, F = OWN + C * MF, OWNP = 12;   // own row padded with 1 / lockout
+  constexpr int OWN = 11, MF = 4, C = 10, F = OWN + C * MF, OWNP = 11;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const ObsTile t = obs_tile<TILE>(a, blockIdx.x);
   float* ownbuf = lds;                 // [TILE][OWNP]
-  float* msg = lds + TILE * OWNP;      // [nenv * (nh + C)][MF]
+  float* quot = lds + TILE * OWNP;     // [TILE][C]  sender's seconds_since_off over the RECEIVER's lockout (utils.py:849-851)
+  float* msg = quot + TILE * C;        // [nenv * (nh + C)][MF]
   stage_tile_senders<false>(a, t, msg, 0, MF, tid, TILE);
+  const int el_own = (tid < t.rows && t.nenv > 1) ? (int)(((uint32_t)tid * a.magic_n) >> 20) : 0;
+  float L = 1.0f;
   if (tid < t.rows) {
-    const int el = (t.nenv > 1) ? (int)(((uint32_t)tid * a.magic_n) >> 20) : 0;
-    const int e = t.e0 + el;
-    const int h = t.h0 + tid - el * a.N;
+    const int e = t.e0 + el_own;
+    const int h = t.h0 + tid - el_own * a.N;
     const int64_t i = (int64_t)e * a.N + h;
     int f = 0;
     obs_features<1, false>(a, e, h, i, [&](const float* v) { ownbuf[tid * OWNP + f] = v[0]; ++f; },
                            [&](int, int) { return MsgFields{}; });
-    ownbuf[tid * OWNP + OWN] = (float)a.lockout[i];
+    L = (float)a.lockout[i];
+  }
+  __syncthreads();
+  if (tid < t.rows) {                  // one quotient per (receiver, slot), rounded as the `/` of the other kernels rounds it
+    const float y = 1.0f / L;
+#pragma unroll
+    for (int m = 0; m < C; ++m)
+      quot[tid * C + m] = div_by_lockout(msg[4 * (tid + C * el_own + m + (m >= C / 2 ? 1 : 0)) + 1], L, y);
   }
   __syncthreads();
   float* dst = a.out + ((int64_t)t.e0 * a.N + t.h0) * F;   // rows * F contiguous floats
@@ -1666,9 +1686,8 @@ __global__ __launch_bounds__(TILE) void k_obs_rows_default(ObsArgs a) {
     if (f < OWN) return ownbuf[r * OWNP + f];
     const int g = f - OWN;
     const int el = multi ? (int)(((uint32_t)r * a.magic_n) >> 20) : 0;
-    float val = msg[4 * (r + C * el) + g + (g >= 20 ? 4 : 0)];
-    if ((g & 3) == 1) val = val / ownbuf[r * OWNP + OWN];   // sender's seconds_since_off over the RECEIVER's lockout (a true division, as everywhere else)
-    return val;
+    if ((g & 3) == 1) return quot[r * C + (g >> 2)];
+    return msg[4 * (r + C * el) + g + (g >= 20 ? 4 : 0)];
   };
   if (lead == 0) {   // aligned tile (always the case when N * F % 4 == 0): no edge handling inside the loop
     for (int o = tid * 4; o < total; o += TILE * 4) {
@@ -1753,7 +1772,7 @@ hipError_t launch_obs_vector(const ObsArgs& a_in, int layout, hipStream_t s) {
   }
   if (layout == MDR_OBS_ROWS && circular && a.c == 10 && a.F == 51 && a.defect_prob <= 0.0f) {
     constexpr int RT = 256;   // 256 * 51 = 13056 < 13107: the kernel's mul-shift division is exact
-    const size_t lds_bytes = (RT * 12 + (RT + (RT / 11) * 10) * 4) * sizeof(float);   // N >= 11: at most RT / 11 env segments
+    const size_t lds_bytes = (RT * (11 + 10) + (RT + (RT / 11) * 10) * 4) * sizeof(float);   // N >= 11: at most RT / 11 env segments
     const int64_t tiles = obs_tile_count<RT>(a.E, a.N);
     if (tiles < (int64_t)1 << 31)
       return launch_with_lds(k_obs_rows_default<RT>, dim3((unsigned)tiles), dim3(RT), lds_bytes, s, a);
@@ -1761,7 +1780,7 @@ hipError_t launch_obs_vector(const ObsArgs& a_in, int layout, hipStream_t s) {
   if (layout == MDR_OBS_ROWS && circular && a.c <= 32 && (a.c + 1) * (int)nf < 65536) {
     constexpr int RT = 256;
     const size_t own = (size_t)(a.F - a.c * (int)nf) | 1;
-    const size_t lds_bytes = (RT * own + (RT + a.c) * nf + 2 * RT + a.F) * sizeof(float);
+    const size_t lds_bytes = (RT * own + (RT + a.c) * nf + 3 * RT + a.F) * sizeof(float);
     const int64_t tiles = a.E * (int64_t)((a.N + RT - 1) / RT);
     if (lds_bytes <= lds_cap && tiles < (int64_t)1 << 31)
       return launch_with_lds(k_obs_rows<RT>, dim3((unsigned)tiles), dim3(RT), lds_bytes, s, a);
