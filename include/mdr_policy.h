@@ -1,0 +1,58 @@
+/*
+ * mdr_policy.h - fused policy forward + action sampling for rollout collection.
+ *
+ * Replaces, for all agents of all envs at once, what the reference does per agent and step on the CPU:
+ *   PPO.select_action (agents/ppo.py:68-75): actor_net(state) -> Categorical(action_prob).sample() -> (action, prob)
+ *   Actor.forward      (agents/network.py:14-33): Linear/ReLU stack (two hidden layers) with a softmax head, 2 actions
+ *
+ * One kernel: observation rows [A][F] -> layer 1 -> ReLU -> layer 2 -> ReLU -> logits -> softmax -> sample.
+ * The two dense layers run on the matrix cores in exact fp32 (v_mfma_f32_32x32x2_f32: a k-ordered fp32 fma chain, no
+ * reduced precision), the hidden activations never leave the registers, biases ride along as one extra input / hidden
+ * unit that is constant 1.  The weights are handed over pre-arranged in MFMA fragment order (mdr_actor_pack_* below
+ * describe it; mdr_amd/policy.py builds it from a torch state_dict).
+ *
+ * Part of libmdr_hip.so; plain C ABI, device pointers, stream-ordered, never synchronises.
+ */
+#ifndef MDR_POLICY_H
+#define MDR_POLICY_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDR_ACTOR_MAX_HIDDEN 127 /* per hidden layer: 127 units + the constant-1 unit fill four 32-row MFMA blocks */
+
+typedef struct mdr_actor {
+  uint32_t struct_size;
+  int32_t num_state;   /* F: floats per observation row */
+  int32_t hidden1;     /* units of hidden layer 1 (<= MDR_ACTOR_MAX_HIDDEN) */
+  int32_t hidden2;     /* units of hidden layer 2 (<= MDR_ACTOR_MAX_HIDDEN) */
+  /* device, float32, MFMA fragment order (see mdr_actor_frag1_floats / mdr_actor_frag2_floats):
+   *   frag1[s][mb][lane]  s < S1 = ceil((F + 1) / 2):  W1e[32 mb + (lane & 31)][(lane >> 5) * S1 + s]
+   *   frag2[q][mb][lane]  q < S2 (mdr_actor_steps2):   W2e[32 mb + (lane & 31)][k2(q, lane >> 5)],
+   *                       k2(q, h) = 32 (q >> 4) + (q & 3) + 8 ((q >> 2) & 3) + 4 h   (the accumulator row a lane holds)
+   *   wdiff[mb][reg][h]   = W3e[0][row] - W3e[1][row],  row = 32 mb + (reg & 3) + 8 (reg >> 2) + 4 h
+   * with the bias-extended matrices  W1e = [[W1 b1] [0 1]],  W2e = [[W2 b2] [0 1]],  W3e = [W3 b3]  (zero padded). */
+  const float *frag1;
+  const float *frag2;
+  const float *wdiff;  /* [4][16][2] */
+} mdr_actor_t;
+
+int64_t mdr_actor_steps1(int32_t num_state);                 /* S1 */
+int64_t mdr_actor_steps2(int32_t hidden1);                   /* S2: accumulator (block, register) pairs holding a row <= hidden1 */
+int64_t mdr_actor_frag1_floats(int32_t num_state);           /* S1 * 4 * 64 */
+int64_t mdr_actor_frag2_floats(int32_t hidden1);             /* S2 * 4 * 64 */
+
+/* For every agent a < nb_agents: probs = softmax(actor(obs[a])), u = Philox4x32-10(key = seed, counter = (a, step, stream))
+ * uniform in (0,1), action = u < probs[0] ? 0 : 1  (Categorical(probs).sample()), a_prob = probs[action].
+ * `action` uint8 [nb_agents], `a_prob` float [nb_agents] (may be NULL), `probs` float [nb_agents][2] (may be NULL).
+ * Returns 0, or -1 (invalid argument) / -3 (HIP error) / -4 (shape without a kernel). */
+int mdr_actor_sample(const mdr_actor_t *actor, const float *obs, int64_t nb_agents, uint64_t seed, uint64_t step,
+                     uint8_t *action, float *a_prob, float *probs, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,93 @@
+"""Fused policy forward + action sampling on the matrix cores (include/mdr_policy.h).
+
+``FusedActor`` takes the weights of an ``ActorMLP`` (the reference's Actor, agents/network.py:14-33, two hidden layers,
+two actions), lays them out once in MFMA fragment order and then runs, per call, ONE kernel over all agents:
+observation rows -> probabilities -> sampled actions (PPO.select_action, agents/ppo.py:68-75, for every agent at once).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _native as nat
+
+MAX_HIDDEN = 127
+
+
+class MdrActor(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("num_state", C.c_int32), ("hidden1", C.c_int32), ("hidden2", C.c_int32),
+                ("frag1", C.c_void_p), ("frag2", C.c_void_p), ("wdiff", C.c_void_p)]
+
+
+def _acc_row(reg: np.ndarray, half: np.ndarray) -> np.ndarray:
+    return (reg & 3) + 8 * (reg >> 2) + 4 * half
+
+
+class FusedActor:
+    def __init__(self, w1, b1, w2, b2, w3, b3, device="cuda:0"):
+        """w1 [H1, F], b1 [H1], w2 [H2, H1], b2 [H2], w3 [2, H2], b3 [2] (torch.nn.Linear layout)."""
+        self._lib = nat.load()
+        w1, b1, w2, b2, w3, b3 = (torch.as_tensor(t, dtype=torch.float32).detach().cpu() for t in (w1, b1, w2, b2, w3, b3))
+        H1, F = w1.shape
+        H2 = w2.shape[0]
+        if w2.shape[1] != H1 or tuple(w3.shape) != (2, H2):
+            raise ValueError("expected Linear(F,H1) - Linear(H1,H2) - Linear(H2,2)")
+        if H1 > MAX_HIDDEN or H2 > MAX_HIDDEN:
+            raise ValueError("hidden layers of at most %d units" % MAX_HIDDEN)
+        self.num_state, self.hidden1, self.hidden2 = int(F), int(H1), int(H2)
+        self.device = torch.device(device)
+        S1 = int(self._lib.mdr_actor_steps1(F))
+        S2 = int(self._lib.mdr_actor_steps2(H1))
+        lane = np.arange(64)
+        r, h = lane & 31, lane >> 5
+        rows = (32 * np.arange(4)[:, None] + r[None, :])                     # [mb, lane] output row of the fragment
+        # bias-extended, zero-padded matrices: input feature F / hidden unit H is the constant 1
+        w1e = torch.zeros((128, 2 * S1))
+        w1e[:H1, :F], w1e[:H1, F], w1e[H1, F] = w1, b1, 1.0
+        w2e = torch.zeros((128, 128))
+        w2e[:H2, :H1], w2e[:H2, H1], w2e[H2, H1] = w2, b2, 1.0
+        w3e = torch.zeros((2, 128))
+        w3e[:, :H2], w3e[:, H2] = w3, b3
+        k1 = h[None, :] * S1 + np.arange(S1)[:, None]                          # [s, lane]
+        frag1 = w1e[torch.from_numpy(rows)[None, :, :], torch.from_numpy(k1)[:, None, :]]           # [S1, 4, 64]
+        q = np.arange(S2)
+        k2 = 32 * (q >> 4)[:, None] + _acc_row((q & 15)[:, None], h[None, :])  # [q, lane]
+        frag2 = w2e[torch.from_numpy(rows)[None, :, :], torch.from_numpy(k2)[:, None, :]]           # [S2, 4, 64]
+        reg = np.arange(16)
+        row3 = 32 * np.arange(4)[:, None, None] + _acc_row(reg[None, :, None], np.arange(2)[None, None, :])   # [mb, reg, h]
+        wdiff = (w3e[0] - w3e[1])[torch.from_numpy(row3)]                       # [4, 16, 2]
+        self._frag1 = frag1.contiguous().to(self.device)
+        self._frag2 = frag2.contiguous().to(self.device)
+        self._wdiff = wdiff.contiguous().to(self.device)
+        assert self._frag1.numel() == self._lib.mdr_actor_frag1_floats(F) and self._frag2.numel() == self._lib.mdr_actor_frag2_floats(H1)
+        self._desc = MdrActor(C.sizeof(MdrActor), F, H1, H2, self._frag1.data_ptr(), self._frag2.data_ptr(), self._wdiff.data_ptr())
+
+    @classmethod
+    def from_module(cls, actor, device=None) -> "FusedActor":
+        """From an ``ActorMLP`` / the reference's ``Actor`` (``fc`` ModuleList of three Linear layers)."""
+        fc = list(actor.fc)
+        if len(fc) != 3:
+            raise ValueError("the fused kernel covers two hidden layers (config.py: layers = [100, 100])")
+        dev = device if device is not None else fc[0].weight.device
+        return cls(fc[0].weight, fc[0].bias, fc[1].weight, fc[1].bias, fc[2].weight, fc[2].bias, device=dev)
+
+    def sample(self, obs: torch.Tensor, seed: int, step: int, want_probs: bool = False,
+               action: Optional[torch.Tensor] = None, a_prob: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, ...]:
+        """obs float32 [A, F] (contiguous, on the device) -> (action uint8 [A], a_prob float32 [A][, probs [A, 2]])."""
+        if obs.dtype != torch.float32 or obs.device != self.device or not obs.is_contiguous() or obs.dim() != 2 or obs.shape[1] != self.num_state:
+            raise ValueError("obs must be a contiguous float32 [A, %d] tensor on %s" % (self.num_state, self.device))
+        A = obs.shape[0]
+        action = torch.empty(A, dtype=torch.uint8, device=self.device) if action is None else action
+        a_prob = torch.empty(A, dtype=torch.float32, device=self.device) if a_prob is None else a_prob
+        probs = torch.empty((A, 2), dtype=torch.float32, device=self.device) if want_probs else None
+        with torch.cuda.device(self.device):
+            rc = self._lib.mdr_actor_sample(C.byref(self._desc), C.c_void_p(obs.data_ptr()), A, C.c_uint64(seed & (2 ** 64 - 1)),
+                                            C.c_uint64(step & (2 ** 64 - 1)), C.c_void_p(action.data_ptr()), C.c_void_p(a_prob.data_ptr()),
+                                            C.c_void_p(probs.data_ptr()) if want_probs else None,
+                                            C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("mdr_actor_sample failed: %s" % self._lib.mdr_status_string(rc).decode())
+        return (action, a_prob, probs) if want_probs else (action, a_prob)

@@ -52,6 +52,13 @@ class CriticMLP(nn.Module):
         return self.fc[-1](x)
 
 
+def _fusable(actor) -> bool:
+    fc = getattr(actor, "fc", None)
+    if fc is None or len(fc) != 3 or not all(isinstance(m, nn.Linear) for m in fc):
+        return False
+    return fc[0].out_features <= 127 and fc[1].out_features <= 127 and fc[2].out_features == 2 and fc[0].weight.is_cuda
+
+
 def discounted_returns(reward: torch.Tensor, done: torch.Tensor, gamma: float,
                        bootstrap: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The Monte-Carlo return scan of PPO.update (agents/ppo.py:123-134) along dim 0 of ``reward`` [T, ...]:
@@ -72,8 +79,14 @@ def discounted_returns(reward: torch.Tensor, done: torch.Tensor, gamma: float,
 
 @torch.no_grad()
 def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.99, critic: Optional[nn.Module] = None,
-                        generator: Optional[torch.Generator] = None, store_states: bool = True) -> Dict[str, torch.Tensor]:
+                        generator: Optional[torch.Generator] = None, store_states: bool = True,
+                        fused: Optional[bool] = None, seed: int = 0) -> Dict[str, torch.Tensor]:
     """Roll ``nb_steps`` with actions sampled from ``actor`` for every agent of every env.
+
+    ``fused`` (default: whenever the actor has the reference's shape - two hidden layers of <= 127 units, two actions -
+    and no torch ``generator`` is given): the actor forward, softmax and ``Categorical.sample`` run as ONE HIP kernel on
+    the matrix cores in exact fp32 (``mdr_amd.policy.FusedActor``), the draws coming from Philox4x32-10 keyed by
+    ``seed`` with the env's step counter in the counter; otherwise torch GEMMs + ``torch.multinomial``.
 
     Returns tensors with the agents flattened as [T, E*N, ...] in the reference's per-agent order:
     ``state`` [T+1, E*N, F] (``state[t+1]`` is ``next_state[t]``; omitted if ``store_states`` is False), ``action`` int64,
@@ -87,15 +100,28 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
     action = torch.empty((T, E * N), dtype=torch.int64, device=dev)
     a_prob = torch.empty((T, E * N), dtype=torch.float32, device=dev)
     reward = torch.empty((T, E * N), dtype=torch.float32, device=dev)
+    policy = None
+    if fused is None:
+        fused = generator is None and _fusable(actor)
+    if fused:
+        from .policy import FusedActor
+        policy = FusedActor.from_module(actor, device=dev)
+        act_u8 = torch.empty(E * N, dtype=torch.uint8, device=dev)
     obs = env.obs_vector("rows").view(E * N, F_len)
+    step0 = env.steps_taken
     for t in range(T):
         if store_states:
             states[t].copy_(obs)
-        probs = actor(obs)
-        a = torch.multinomial(probs, 1, generator=generator).squeeze(1)        # Categorical(action_prob).sample()
-        action[t] = a
-        a_prob[t] = probs.gather(1, a[:, None]).squeeze(1)
-        _, r, _, _ = env.step(a.to(torch.uint8).view(E, N))
+        if policy is not None:      # agents/ppo.py:68-75 for all agents: one kernel, a_prob written in place
+            policy.sample(obs, seed, step0 + t, action=act_u8, a_prob=a_prob[t])
+            action[t] = act_u8
+            _, r, _, _ = env.step(act_u8.view(E, N))
+        else:
+            probs = actor(obs)
+            a = torch.multinomial(probs, 1, generator=generator).squeeze(1)        # Categorical(action_prob).sample()
+            action[t] = a
+            a_prob[t] = probs.gather(1, a[:, None]).squeeze(1)
+            _, r, _, _ = env.step(a.to(torch.uint8).view(E, N))
         reward[t] = r.reshape(-1)
         obs = env.obs_vector("rows").view(E * N, F_len)
     if store_states:

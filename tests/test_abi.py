@@ -9,12 +9,15 @@ import pytest
 import mdr_amd
 from mdr_amd import _native as nat
 
-HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mdr.h")
+INCLUDE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+HEADER = os.path.join(INCLUDE, "mdr.h")
 
 
 def _header():
-    with open(HEADER) as f:
-        text = f.read()
+    text = ""
+    for name in ("mdr.h", "mdr_policy.h"):
+        with open(os.path.join(INCLUDE, name)) as f:
+            text += f.read()
     return re.sub(r"/\*.*?\*/", "", text, flags=re.S)
 
 
@@ -34,7 +37,7 @@ def _struct_fields(text, name):
 def test_library_is_built_and_exports_header_symbols():
     mdr_amd.build_native()
     lib = mdr_amd.load_native()
-    declared = set(re.findall(r"\b(mdr_[a-z_]+)\s*\(", _header()))
+    declared = set(re.findall(r"\b(mdr_[a-z0-9_]+)\s*\(", _header()))
     assert declared == set(nat.EXPORTS), declared ^ set(nat.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
@@ -44,8 +47,11 @@ def test_library_is_built_and_exports_header_symbols():
 
 
 @pytest.mark.parametrize("cname,cls", [("mdr_config", nat.MdrConfig), ("mdr_buffers", nat.MdrBuffers), ("mdr_episode", nat.MdrEpisode),
-                                        ("mdr_obs_spec", nat.MdrObsSpec), ("mdr_rollout_out", nat.MdrRolloutOut), ("mdr_interp_grid", nat.MdrInterpGrid)])
+                                        ("mdr_obs_spec", nat.MdrObsSpec), ("mdr_rollout_out", nat.MdrRolloutOut), ("mdr_interp_grid", nat.MdrInterpGrid),
+                                        ("mdr_actor", None)])
 def test_ctypes_mirror_matches_header(cname, cls):
+    if cls is None:
+        from mdr_amd.policy import MdrActor as cls
     assert _struct_fields(_header(), cname) == [f[0] for f in cls._fields_]
 
 

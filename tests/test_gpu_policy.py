@@ -1,0 +1,105 @@
+"""Fused policy forward + sampling (include/mdr_policy.h) against a plain PyTorch fp32 forward of the same Actor.
+
+The reference's PPO.select_action (agents/ppo.py:68-75): probs = actor_net(state); action ~ Categorical(probs);
+returns (action, probs[action]).  Tolerance: fp32 MFMA is a k-ordered fp32 fma chain, torch's GEMM sums in another
+order -> probabilities to 2e-6 absolute / 1e-5 relative."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _actor(F, layers, seed=0, scale=1.0):
+    from mdr_amd.rollout import ActorMLP
+    torch.manual_seed(seed)
+    actor = ActorMLP(F, 2, layers).to("cuda:0")
+    with torch.no_grad():
+        for lin in actor.fc:
+            lin.weight.mul_(scale)
+            lin.bias.uniform_(-0.5, 0.5)
+    return actor
+
+
+@pytest.mark.parametrize("A,F,layers", [(1, 51, (100, 100)), (31, 51, (100, 100)), (33, 51, (100, 100)), (1000, 51, (100, 100)),
+                                        (4097, 47, (100, 100)), (777, 133, (100, 100)), (500, 11, (64, 32)), (300, 51, (127, 127)),
+                                        (300, 50, (1, 1)), (300000, 51, (100, 100))])
+def test_fused_actor_matches_torch_forward(A, F, layers):
+    from mdr_amd.policy import FusedActor
+    actor = _actor(F, layers, seed=A, scale=3.0)
+    fused = FusedActor.from_module(actor)
+    g = torch.Generator(device="cuda:0").manual_seed(1)
+    obs = torch.randn((A, F), device="cuda:0", generator=g) * 2.0
+    with torch.no_grad():
+        ref = actor(obs)
+    action, a_prob, probs = fused.sample(obs, seed=7, step=3, want_probs=True)
+    torch.testing.assert_close(probs, ref, rtol=1e-5, atol=2e-6)
+    assert torch.equal(a_prob, probs.gather(1, action.long()[:, None]).squeeze(1))       # the probability of the action taken
+    assert set(action.unique().tolist()) <= {0, 1}
+    assert float((probs.sum(1) - 1).abs().max()) < 1e-6
+
+
+def test_weight_layout_is_checked_with_asymmetric_integer_data():
+    """Exact small-integer weights and inputs (every product and sum exact in fp32): the logits' difference must be exact,
+    which a swapped A/B operand, a wrong k order between the layers or a transposed block would not survive."""
+    from mdr_amd.policy import FusedActor
+    F, H1, H2, A = 51, 100, 100, 257
+    rng = np.random.default_rng(0)
+    w1 = rng.integers(-2, 3, (H1, F)).astype(np.float32)
+    b1 = rng.integers(-3, 4, H1).astype(np.float32)
+    w2 = rng.integers(-1, 2, (H2, H1)).astype(np.float32) * (rng.random((H2, H1)) < 0.2)
+    b2 = rng.integers(-3, 4, H2).astype(np.float32)
+    w3 = rng.integers(-1, 2, (2, H2)).astype(np.float32) * (rng.random((2, H2)) < 0.3)
+    b3 = np.array([1.0, -2.0], dtype=np.float32)
+    x = rng.integers(-2, 3, (A, F)).astype(np.float32)
+    h1 = np.maximum(x.astype(np.float64) @ w1.T + b1, 0)
+    h2 = np.maximum(h1 @ w2.T + b2, 0)
+    logits = h2 @ w3.T + b3
+    assert np.abs(h2).max() < 2 ** 22                    # everything stays in fp32's exact-integer range
+    d = logits[:, 0] - logits[:, 1]
+    p0 = 1.0 / (1.0 + np.exp(-d))
+    fused = FusedActor(w1, b1, w2.astype(np.float32), b2, w3.astype(np.float32), b3)
+    _, _, probs = fused.sample(torch.from_numpy(x).cuda(), seed=1, step=0, want_probs=True)
+    np.testing.assert_allclose(probs[:, 0].cpu().numpy(), p0, rtol=2e-6, atol=1e-30)
+    np.testing.assert_allclose(probs[:, 1].cpu().numpy(), 1.0 / (1.0 + np.exp(d)), rtol=2e-6, atol=1e-30)
+
+
+def test_sampling_follows_the_probabilities_and_the_step_counter():
+    from mdr_amd.policy import FusedActor
+    A, F = 1 << 20, 51
+    actor = _actor(F, (100, 100), seed=5, scale=0.0)          # zero weights: the same probabilities for every agent
+    with torch.no_grad():
+        actor.fc[2].bias.copy_(torch.tensor([0.3, -0.55]))
+        for lin in actor.fc[:2]:
+            lin.bias.zero_()
+    fused = FusedActor.from_module(actor)
+    obs = torch.zeros((A, F), device="cuda:0")
+    a0, p0, probs = fused.sample(obs, seed=11, step=0, want_probs=True)
+    p = float(probs[0, 0])
+    assert abs(p - 1 / (1 + np.exp(-0.85))) < 1e-6
+    frac = float((a0 == 0).float().mean())
+    assert abs(frac - p) < 5 * np.sqrt(p * (1 - p) / A)         # binomial 5 sigma
+    a1, _ = fused.sample(obs, seed=11, step=1)
+    a0b, _ = fused.sample(obs, seed=11, step=0)
+    a2, _ = fused.sample(obs, seed=12, step=0)
+    assert torch.equal(a0, a0b)                                  # counter-based: same (seed, step) -> same draws
+    assert 0.3 < float((a0 != a1).float().mean()) < 0.6         # independent draws differ with prob 2 p (1 - p) = 0.42
+    assert 0.3 < float((a0 != a2).float().mean()) < 0.6
+    # neighbouring agents are independent
+    x = (a0[:-1] == 0).float() - p
+    y = (a0[1:] == 0).float() - p
+    assert abs(float((x * y).mean())) < 5 * p * (1 - p) / np.sqrt(A)
+
+
+def test_fused_actor_argument_checks():
+    from mdr_amd.policy import FusedActor
+    from mdr_amd.rollout import ActorMLP
+    with pytest.raises(ValueError):
+        FusedActor.from_module(ActorMLP(51, 2, (100,)).to("cuda:0"))
+    with pytest.raises(ValueError):
+        FusedActor.from_module(ActorMLP(51, 2, (128, 100)).to("cuda:0"))
+    fused = FusedActor.from_module(ActorMLP(51, 2, (100, 100)).to("cuda:0"))
+    with pytest.raises(ValueError):
+        fused.sample(torch.zeros((4, 50), device="cuda:0"), 0, 0)
+    with pytest.raises(ValueError):
+        fused.sample(torch.zeros((4, 51), device="cuda:0", dtype=torch.float64), 0, 0)
