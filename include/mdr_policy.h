@@ -30,8 +30,8 @@ typedef struct mdr_actor {
   int32_t hidden1;     /* units of hidden layer 1 (<= MDR_ACTOR_MAX_HIDDEN) */
   int32_t hidden2;     /* units of hidden layer 2 (<= MDR_ACTOR_MAX_HIDDEN) */
   /* device, float32, MFMA fragment order (see mdr_actor_frag1_floats / mdr_actor_frag2_floats):
-   *   frag1[s][mb][lane]  s < S1 = ceil((F + 1) / 2):  W1e[32 mb + (lane & 31)][(lane >> 5) * S1 + s]
-   *   frag2[q][mb][lane]  q < S2 (mdr_actor_steps2):   W2e[32 mb + (lane & 31)][k2(q, lane >> 5)],
+   *   frag1[s][lane][mb]  s < S1 = ceil((F + 1) / 2):  W1e[32 mb + (lane & 31)][(lane >> 5) * S1 + s]   (mb < 4: one float4 per lane)
+   *   frag2[q][lane][mb]  q < S2 (mdr_actor_steps2):   W2e[32 mb + (lane & 31)][k2(q, lane >> 5)],
    *                       k2(q, h) = 32 (q >> 4) + (q & 3) + 8 ((q >> 2) & 3) + 4 h   (the accumulator row a lane holds)
    *   wdiff[mb][reg][h]   = W3e[0][row] - W3e[1][row],  row = 32 mb + (reg & 3) + 8 (reg >> 2) + 4 h
    * with the bias-extended matrices  W1e = [[W1 b1] [0 1]],  W2e = [[W2 b2] [0 1]],  W3e = [W3 b3]  (zero padded). */

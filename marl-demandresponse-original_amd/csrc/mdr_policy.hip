@@ -48,10 +48,13 @@ struct ActorArgs {
   uint32_t k0, k1, step_lo, step_hi;
 };
 
+// X1: compile-time bound on S1 (the lane's S1 input features are prefetched into registers, the next tile's while layer 2
+// runs); 0 = any S1, features loaded as layer 1 consumes them.  S2C: compile-time S2, 0 = run-time.
+template <int X1, int S2C>
 __global__ __launch_bounds__(64 * WAVES) void k_actor_sample(ActorArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* f1 = lds;                       // [S1][4][64]
-  float* f2 = f1 + a.S1 * 256;           // [S2][4][64]
+  float* f1 = lds;                       // [S1][64][4]
+  float* f2 = f1 + a.S1 * 256;           // [S2][64][4]
   float* wd = f2 + a.S2 * 256;           // [4][16][2]
   const int tid = threadIdx.x;
   for (int i = tid * 4; i < a.S1 * 256; i += 64 * WAVES * 4) *reinterpret_cast<float4*>(f1 + i) = *reinterpret_cast<const float4*>(a.frag1 + i);
@@ -64,23 +67,56 @@ __global__ __launch_bounds__(64 * WAVES) void k_actor_sample(ActorArgs a) {
   const int64_t wave = (int64_t)blockIdx.x * WAVES + (tid >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * WAVES;
   const int kbase = h * a.S1;            // this lane half's input features: [kbase, kbase + S1)
+  const int S2 = S2C ? S2C : a.S2;
+  constexpr int XR = X1 ? X1 : 1;
+  float xr[XR];
+  auto row_of = [&](int64_t t) {
+    const int64_t agent = t * 32 + r;
+    return a.obs + (agent < a.A ? agent : a.A - 1) * (int64_t)a.F;
+  };
+  auto feature = [&](const float* x, int s) {
+    const int k = kbase + s;
+    return k < a.F ? x[k] : (k == a.F ? 1.0f : 0.0f);
+  };
+  auto prefetch = [&](int64_t t) {
+    if (X1 == 0 || t >= a.ntiles) return;
+    const float* x = row_of(t);
+#pragma unroll
+    for (int s = 0; s < XR; ++s)
+      if (s < a.S1) xr[s] = feature(x, s);
+  };
+  prefetch(wave);
   for (int64_t t = wave; t < a.ntiles; t += nwaves) {
     const int64_t agent = t * 32 + r;
     const bool valid = agent < a.A;
-    const float* x = a.obs + (valid ? agent : a.A - 1) * (int64_t)a.F;
     f32x16 acc[4];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mb][i] = 0.0f;
     // ---- layer 1
-#pragma unroll 4
-    for (int s = 0; s < a.S1; ++s) {
-      const int k = kbase + s;
-      const float b = k < a.F ? x[k] : (k == a.F ? 1.0f : 0.0f);
-      const float* w = f1 + s * 256 + lane;
+    if (X1) {
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[mb * 64], b, acc[mb], 0, 0, 0);
+      for (int s = 0; s < XR; ++s) {
+        if (s < a.S1) {
+          const float4 w = *reinterpret_cast<const float4*>(f1 + s * 256 + lane * 4);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, xr[s], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, xr[s], acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, xr[s], acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, xr[s], acc[3], 0, 0, 0);
+        }
+      }
+      prefetch(t + nwaves);   // in flight while layer 2 runs
+    } else {
+      const float* x = row_of(t);
+      for (int s = 0; s < a.S1; ++s) {
+        const float b = feature(x, s);
+        const float4 w = *reinterpret_cast<const float4*>(f1 + s * 256 + lane * 4);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, b, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, b, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, b, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, b, acc[3], 0, 0, 0);
+      }
     }
     // ---- layer 2: relu(H1) straight out of the accumulators
     f32x16 out[4];
@@ -90,11 +126,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_actor_sample(ActorArgs a) {
       for (int i = 0; i < 16; ++i) out[mb][i] = 0.0f;
 #pragma unroll
     for (int q = 0; q < 64; ++q) {
-      if (q < a.S2) {
+      if (q < S2) {
         const float b = fmaxf(acc[q >> 4][q & 15], 0.0f);
-        const float* w = f2 + q * 256 + lane;
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) out[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[mb * 64], b, out[mb], 0, 0, 0);
+        const float4 w = *reinterpret_cast<const float4*>(f2 + q * 256 + lane * 4);
+        out[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, b, out[0], 0, 0, 0);
+        out[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, b, out[1], 0, 0, 0);
+        out[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, b, out[2], 0, 0, 0);
+        out[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, b, out[3], 0, 0, 0);
       }
     }
     // ---- head: d = logit0 - logit1 over this lane's 64 rows, then the other half's
@@ -157,14 +195,19 @@ int mdr_actor_sample(const mdr_actor_t* actor, const float* obs, int64_t nb_agen
   a.step_lo = (uint32_t)(step & 0xFFFFFFFFull); a.step_hi = (uint32_t)(step >> 32);
   const size_t lds_bytes = ((size_t)(a.S1 + a.S2) * 256 + 128) * sizeof(float);
   if (lds_bytes > 160 * 1024) return MDR_ERR_UNSUPPORTED;   // num_state beyond ~190 with 100-unit layers
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_actor_sample), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (e != hipSuccess) return MDR_ERR_HIP;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
   const int64_t want = (a.ntiles + WAVES - 1) / WAVES;
   const unsigned grid = (unsigned)(want < cus ? want : cus);   // persistent: the weights are staged once per workgroup
-  hipLaunchKernelGGL(k_actor_sample, dim3(grid), dim3(64 * WAVES), lds_bytes, (hipStream_t)stream, a);
-  return hipGetLastError() == hipSuccess ? MDR_OK : MDR_ERR_HIP;
+  auto launch = [&](auto kernel) -> int {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+      return MDR_ERR_HIP;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * WAVES), lds_bytes, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? MDR_OK : MDR_ERR_HIP;
+  };
+  if (a.S1 <= 32 && a.S2 == 52) return launch(k_actor_sample<32, 52>);   // the reference's shape: num_state <= 62, layers [100, 100]
+  if (a.S1 <= 32) return launch(k_actor_sample<32, 0>);
+  return launch(k_actor_sample<0, 0>);
 }
 
 }  // extern "C"

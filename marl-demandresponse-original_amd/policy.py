@@ -52,10 +52,10 @@ class FusedActor:
         w3e = torch.zeros((2, 128))
         w3e[:, :H2], w3e[:, H2] = w3, b3
         k1 = h[None, :] * S1 + np.arange(S1)[:, None]                          # [s, lane]
-        frag1 = w1e[torch.from_numpy(rows)[None, :, :], torch.from_numpy(k1)[:, None, :]]           # [S1, 4, 64]
+        frag1 = w1e[torch.from_numpy(rows)[None, :, :], torch.from_numpy(k1)[:, None, :]].permute(0, 2, 1)   # [S1, 64, 4]
         q = np.arange(S2)
         k2 = 32 * (q >> 4)[:, None] + _acc_row((q & 15)[:, None], h[None, :])  # [q, lane]
-        frag2 = w2e[torch.from_numpy(rows)[None, :, :], torch.from_numpy(k2)[:, None, :]]           # [S2, 4, 64]
+        frag2 = w2e[torch.from_numpy(rows)[None, :, :], torch.from_numpy(k2)[:, None, :]].permute(0, 2, 1)   # [S2, 64, 4]
         reg = np.arange(16)
         row3 = 32 * np.arange(4)[:, None, None] + _acc_row(reg[None, :, None], np.arange(2)[None, None, :])   # [mb, reg, h]
         wdiff = (w3e[0] - w3e[1])[torch.from_numpy(row3)]                       # [4, 16, 2]
