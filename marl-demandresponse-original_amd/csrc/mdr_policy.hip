@@ -48,6 +48,9 @@ struct ActorArgs {
   uint32_t k0, k1, step_lo, step_hi;
 };
 
+// max(x, 0) in one instruction (v_med3_f32; fmaxf costs a canonicalising v_max_f32 x, x before the v_max_f32 x, 0)
+__device__ __forceinline__ float relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_huge_valf()); }
+
 // X1: compile-time bound on S1 (the lane's S1 input features are prefetched into registers, the next tile's while layer 2
 // runs); 0 = any S1, features loaded as layer 1 consumes them.  S2C: compile-time S2, 0 = run-time.
 template <int X1, int S2C>
@@ -106,7 +109,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_actor_sample(ActorArgs a) {
           acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, xr[s], acc[3], 0, 0, 0);
         }
       }
-      prefetch(t + nwaves);   // in flight while layer 2 runs
     } else {
       const float* x = row_of(t);
       for (int s = 0; s < a.S1; ++s) {
@@ -124,10 +126,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_actor_sample(ActorArgs a) {
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) out[mb][i] = 0.0f;
+    // The next tile's input features are fetched between the k-steps, one load per step: every such load touches 64
+    // different cache lines (~64 cycles in the texture addresser), and a wave that issues them all back to back cannot
+    // issue MFMAs meanwhile (in-order issue) - measured 5 % of the kernel against this interleaving.
+    const bool more = X1 != 0 && t + nwaves < a.ntiles;
+    const float* xn = row_of(more ? t + nwaves : t);
 #pragma unroll
     for (int q = 0; q < 64; ++q) {
+      if (X1 != 0 && q < XR && q < a.S1 && more) xr[q < XR ? q : 0] = feature(xn, q);
       if (q < S2) {
-        const float b = fmaxf(acc[q >> 4][q & 15], 0.0f);
+        const float b = relu(acc[q >> 4][q & 15]);
         const float4 w = *reinterpret_cast<const float4*>(f2 + q * 256 + lane * 4);
         out[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, b, out[0], 0, 0, 0);
         out[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, b, out[1], 0, 0, 0);
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_actor_sample(ActorArgs a) {
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) d = fmaf(wd[(mb * 16 + i) * 2 + h], fmaxf(out[mb][i], 0.0f), d);
+      for (int i = 0; i < 16; ++i) d = fmaf(wd[(mb * 16 + i) * 2 + h], relu(out[mb][i]), d);
     d += __shfl_xor(d, 32);
     const float p0 = 1.0f / (1.0f + expf(-d));
     const float p1 = 1.0f / (1.0f + expf(d));
