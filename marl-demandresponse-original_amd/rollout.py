@@ -52,6 +52,17 @@ class CriticMLP(nn.Module):
         return self.fc[-1](x)
 
 
+def _fused_policy(actor, dev):
+    """FusedActor of `actor`, re-packed only when a parameter changed (torch bumps `_version` on in-place updates)."""
+    from .policy import FusedActor
+    key = tuple((p.data_ptr(), p._version) for p in actor.parameters()) + (str(dev),)
+    cached = getattr(actor, "_mdr_fused", None)
+    if cached is None or cached[0] != key:
+        cached = (key, FusedActor.from_module(actor, device=dev))
+        actor._mdr_fused = cached
+    return cached[1]
+
+
 def _fusable(actor) -> bool:
     fc = getattr(actor, "fc", None)
     if fc is None or len(fc) != 3 or not all(isinstance(m, nn.Linear) for m in fc):
@@ -104,18 +115,20 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
     if fused is None:
         fused = generator is None and _fusable(actor)
     if fused:
-        from .policy import FusedActor
-        policy = FusedActor.from_module(actor, device=dev)
-        act_u8 = torch.empty(E * N, dtype=torch.uint8, device=dev)
-    obs = env.obs_vector("rows").view(E * N, F_len)
+        policy = _fused_policy(actor, dev)
+        act_u8 = torch.empty((T, E * N), dtype=torch.uint8, device=dev)
+
+    def observe(t):      # straight into the transition buffer when states are kept: no 4 F bytes/agent copy per step
+        if store_states:
+            return env.obs_vector("rows", out=states[t].view(E, N, F_len)).view(E * N, F_len)
+        return env.obs_vector("rows").view(E * N, F_len)
+
+    obs = observe(0)
     step0 = env.steps_taken
     for t in range(T):
-        if store_states:
-            states[t].copy_(obs)
-        if policy is not None:      # agents/ppo.py:68-75 for all agents: one kernel, a_prob written in place
-            policy.sample(obs, seed, step0 + t, action=act_u8, a_prob=a_prob[t])
-            action[t] = act_u8
-            _, r, _, _ = env.step(act_u8.view(E, N))
+        if policy is not None:      # agents/ppo.py:68-75 for all agents: one kernel, action and a_prob written in place
+            policy.sample(obs, seed, step0 + t, action=act_u8[t], a_prob=a_prob[t])
+            _, r, _, _ = env.step(act_u8[t].view(E, N))
         else:
             probs = actor(obs)
             a = torch.multinomial(probs, 1, generator=generator).squeeze(1)        # Categorical(action_prob).sample()
@@ -123,9 +136,9 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
             a_prob[t] = probs.gather(1, a[:, None]).squeeze(1)
             _, r, _, _ = env.step(a.to(torch.uint8).view(E, N))
         reward[t] = r.reshape(-1)
-        obs = env.obs_vector("rows").view(E * N, F_len)
-    if store_states:
-        states[T].copy_(obs)
+        obs = observe(t + 1)
+    if policy is not None:
+        action.copy_(act_u8)        # one widening pass at the end (the reference stores Categorical's int64)
     done = torch.zeros((T, E * N), dtype=torch.bool, device=dev)
     done[T - 1] = True
     bootstrap = None

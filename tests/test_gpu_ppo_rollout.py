@@ -66,3 +66,42 @@ def test_collect_rollout_shapes_sampling_and_returns():
     env2 = _env(E, N)
     ro2 = collect_ppo_rollout(env2, actor, T, gamma=0.9, critic=critic, generator=torch.Generator(device="cuda").manual_seed(1))
     assert torch.equal(ro["action"], ro2["action"]) and torch.equal(ro["reward"], ro2["reward"])
+
+
+def test_collect_rollout_with_the_fused_policy_kernel():
+    """fused=True (the default for the reference's actor shape): actor forward + Categorical.sample in one MFMA kernel."""
+    from mdr_amd.rollout import ActorMLP, CriticMLP, collect_ppo_rollout
+    E, N, T = 96, 50, 10
+    env = _env(E, N)
+    F = env.obs_vector_length()
+    torch.manual_seed(3)
+    actor = ActorMLP(F).cuda()
+    critic = CriticMLP(F).cuda()
+    ro = collect_ppo_rollout(env, actor, T, gamma=0.9, critic=critic, seed=5)
+    assert hasattr(actor, "_mdr_fused")                                   # the fused path ran
+    assert ro["action"].dtype == torch.int64 and set(ro["action"].unique().tolist()) <= {0, 1}
+    # the stored probability is the actor's (torch fp32) probability of the stored action on the stored state
+    for t in (0, 4, T - 1):
+        p = actor(ro["state"][t])
+        torch.testing.assert_close(p.gather(1, ro["action"][t][:, None]).squeeze(1), ro["a_prob"][t], rtol=1e-5, atol=2e-6)
+    p1 = torch.stack([actor(ro["state"][t])[:, 1] for t in range(T)])
+    assert abs(ro["action"].float().mean().item() - p1.mean().item()) < 0.01
+    # state[t + 1] is the env's observation after step t, written straight into the buffer
+    torch.testing.assert_close(ro["state"][T], env.obs_vector("rows").view(E * N, F))
+    twin = _env(E, N)
+    twin_obs = twin.obs_vector("rows").view(E * N, F)
+    assert torch.equal(ro["state"][0], twin_obs)
+    twin.step(ro["action"][0].to(torch.uint8).view(E, N))
+    assert torch.equal(ro["state"][1], twin.obs_vector("rows").view(E * N, F))
+    assert torch.equal(ro["reward"][0], twin.t["reward"].reshape(-1))
+    # counter-based draws: same seed and step counters -> same rollout; another seed -> another one
+    ro2 = collect_ppo_rollout(_env(E, N), actor, T, gamma=0.9, critic=critic, seed=5)
+    ro3 = collect_ppo_rollout(_env(E, N), actor, T, gamma=0.9, critic=critic, seed=6)
+    assert torch.equal(ro["action"], ro2["action"]) and torch.equal(ro["reward"], ro2["reward"])
+    assert not torch.equal(ro["action"], ro3["action"])
+    # a weight update invalidates the packed copy
+    packed = actor._mdr_fused[1]
+    with torch.no_grad():
+        actor.fc[2].bias.add_(1.0)
+    collect_ppo_rollout(_env(E, N), actor, 2, seed=5)
+    assert actor._mdr_fused[1] is not packed
