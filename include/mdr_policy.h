@@ -24,26 +24,38 @@ extern "C" {
 
 #define MDR_ACTOR_MAX_HIDDEN 127 /* per hidden layer: 127 units + the constant-1 unit fill four 32-row MFMA blocks */
 
+enum mdr_actor_layout {
+  MDR_ACTOR_FRAG32 = 0, /* v_mfma_f32_32x32x2_f32: 32 agents per wavefront, any num_state that fits the LDS */
+  MDR_ACTOR_FRAG16 = 1  /* v_mfma_f32_16x16x4_f32: 16 agents per wavefront, hidden units padded to 112 instead of 128 rows and a
+                           quarter of the accumulator registers; num_state <= 63 */
+};
+
 typedef struct mdr_actor {
   uint32_t struct_size;
+  int32_t layout;      /* mdr_actor_layout: how frag1 / frag2 / wdiff are arranged */
   int32_t num_state;   /* F: floats per observation row */
   int32_t hidden1;     /* units of hidden layer 1 (<= MDR_ACTOR_MAX_HIDDEN) */
   int32_t hidden2;     /* units of hidden layer 2 (<= MDR_ACTOR_MAX_HIDDEN) */
-  /* device, float32, MFMA fragment order (see mdr_actor_frag1_floats / mdr_actor_frag2_floats):
-   *   frag1[s][lane][mb]  s < S1 = ceil((F + 1) / 2):  W1e[32 mb + (lane & 31)][(lane >> 5) * S1 + s]   (mb < 4: one float4 per lane)
-   *   frag2[q][lane][mb]  q < S2 (mdr_actor_steps2):   W2e[32 mb + (lane & 31)][k2(q, lane >> 5)],
-   *                       k2(q, h) = 32 (q >> 4) + (q & 3) + 8 ((q >> 2) & 3) + 4 h   (the accumulator row a lane holds)
-   *   wdiff[mb][reg][h]   = W3e[0][row] - W3e[1][row],  row = 32 mb + (reg & 3) + 8 (reg >> 2) + 4 h
-   * with the bias-extended matrices  W1e = [[W1 b1] [0 1]],  W2e = [[W2 b2] [0 1]],  W3e = [W3 b3]  (zero padded). */
+  int32_t reserved0;
+  /* device, float32, MFMA fragment order, with the bias-extended zero-padded matrices
+   *   W1e = [[W1 b1] [0 1]] (128 rows),  W2e = [[W2 b2] [0 1]] (128 x 128),  W3e = [W3 b3]:
+   * MDR_ACTOR_FRAG32 (S1 = ceil((F + 1) / 2), S2 = mdr_actor_steps2, r = lane & 31, h = lane >> 5):
+   *   frag1[s][lane][mb < 4]  = W1e[32 mb + r][h S1 + s]
+   *   frag2[q][lane][mb < 4]  = W2e[32 mb + r][k2],  k2 = 32 (q >> 4) + (q & 3) + 8 ((q >> 2) & 3) + 4 h  (the accumulator row the lane holds)
+   *   wdiff[mb < 4][reg < 16][h] = W3e[0][row] - W3e[1][row],  row = 32 mb + (reg & 3) + 8 (reg >> 2) + 4 h
+   * MDR_ACTOR_FRAG16 (S1 = ceil((F + 1) / 4), S2 = 4 ceil((H1 + 1) / 16), r = lane & 15, g = lane >> 4):
+   *   frag1[s][lane][mb < 8]  = W1e[16 mb + r][g S1 + s]
+   *   frag2[q][lane][mb < 8]  = W2e[16 mb + r][16 (q >> 2) + 4 g + (q & 3)]
+   *   wdiff[mb < 8][reg < 4][g]  = W3e[0][row] - W3e[1][row],  row = 16 mb + 4 g + reg */
   const float *frag1;
   const float *frag2;
-  const float *wdiff;  /* [4][16][2] */
+  const float *wdiff;  /* 128 floats */
 } mdr_actor_t;
 
-int64_t mdr_actor_steps1(int32_t num_state);                 /* S1 */
-int64_t mdr_actor_steps2(int32_t hidden1);                   /* S2: accumulator (block, register) pairs holding a row <= hidden1 */
-int64_t mdr_actor_frag1_floats(int32_t num_state);           /* S1 * 4 * 64 */
-int64_t mdr_actor_frag2_floats(int32_t hidden1);             /* S2 * 4 * 64 */
+int64_t mdr_actor_steps1(int32_t layout, int32_t num_state);        /* S1 */
+int64_t mdr_actor_steps2(int32_t layout, int32_t hidden1);          /* S2 */
+int64_t mdr_actor_frag1_floats(int32_t layout, int32_t num_state);  /* S1 * 64 lanes * (4 | 8) */
+int64_t mdr_actor_frag2_floats(int32_t layout, int32_t hidden1);    /* S2 * 64 lanes * (4 | 8) */
 
 /* For every agent a < nb_agents: probs = softmax(actor(obs[a])), u = Philox4x32-10(key = seed, counter = (a, step, stream))
  * uniform in (0,1), action = u < probs[0] ? 0 : 1  (Categorical(probs).sample()), a_prob = probs[action].

@@ -178,10 +178,10 @@ def load():
         "mdr_env_obs_vector_ext": (C.c_int, [vp, C.POINTER(MdrObsSpec), vp, i64, vp, vp]),
         "mdr_env_cursor": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
         "mdr_env_set_cursor": (C.c_int, [vp, u64, u32, i64, i64]),
-        "mdr_actor_steps1": (i64, [i32]),
-        "mdr_actor_steps2": (i64, [i32]),
-        "mdr_actor_frag1_floats": (i64, [i32]),
-        "mdr_actor_frag2_floats": (i64, [i32]),
+        "mdr_actor_steps1": (i64, [i32, i32]),
+        "mdr_actor_steps2": (i64, [i32, i32]),
+        "mdr_actor_frag1_floats": (i64, [i32, i32]),
+        "mdr_actor_frag2_floats": (i64, [i32, i32]),
         "mdr_actor_sample": (C.c_int, [vp, vp, i64, u64, u64, vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():

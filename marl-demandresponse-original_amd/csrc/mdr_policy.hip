@@ -166,53 +166,172 @@ __global__ __launch_bounds__(64 * WAVES) void k_actor_sample(ActorArgs a) {
   }
 }
 
+// ---- the same network on v_mfma_f32_16x16x4_f32: 16 agents per wavefront, hidden units in MB blocks of 16 rows.
+// 101 rows pad to 112 (7 blocks) instead of 128, a lane carries 4 accumulator registers per block instead of 16 (56
+// instead of 128 for both layers), so twice as many waves fit a SIMD.  C/D: col = lane & 15, row = 4 (lane >> 4) + reg;
+// A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15].  Layer 2's k-step q = (kb, reg) takes register
+// [kb][reg] of layer 1: lane group g = lane >> 4 supplies row 16 kb + 4 g + reg - again no lane movement.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int WAVES16 = 16;
+
+template <int MB>
+__global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* f1 = lds;                       // [S1][64][8]
+  float* f2 = f1 + a.S1 * 512;           // [S2][64][8]
+  float* wd = f2 + a.S2 * 512;           // [8][4][4]
+  const int tid = threadIdx.x;
+  for (int i = tid * 4; i < a.S1 * 512; i += 64 * WAVES16 * 4) *reinterpret_cast<float4*>(f1 + i) = *reinterpret_cast<const float4*>(a.frag1 + i);
+  for (int i = tid * 4; i < a.S2 * 512; i += 64 * WAVES16 * 4) *reinterpret_cast<float4*>(f2 + i) = *reinterpret_cast<const float4*>(a.frag2 + i);
+  if (tid < 128) wd[tid] = a.wdiff[tid];
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int r = lane & 15, g = lane >> 4;
+  const int64_t wave = (int64_t)blockIdx.x * WAVES16 + (tid >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * WAVES16;
+  const int kbase = g * a.S1;            // this lane group's input features: [kbase, kbase + S1)
+  float xr[16];
+  auto row_of = [&](int64_t t) {
+    const int64_t agent = t * 16 + r;
+    return a.obs + (agent < a.A ? agent : a.A - 1) * (int64_t)a.F;
+  };
+  auto feature = [&](const float* x, int s) {
+    const int k = kbase + s;
+    const float v = x[min(k, a.F - 1)];
+    return k < a.F ? v : (k == a.F ? 1.0f : 0.0f);
+  };
+  if (wave < a.ntiles) {
+    const float* x = row_of(wave);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) xr[s] = feature(x, s < a.S1 ? s : 0);
+  }
+  for (int64_t t = wave; t < a.ntiles; t += nwaves) {
+    const int64_t agent = t * 16 + r;
+    const bool valid = agent < a.A;
+    f32x4 acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // ---- layer 1
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (s < a.S1) {
+        const float4 w0 = *reinterpret_cast<const float4*>(f1 + s * 512 + lane * 8);
+        const float4 w1 = *reinterpret_cast<const float4*>(f1 + s * 512 + lane * 8 + 4);
+        const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[mb], xr[s], acc[mb], 0, 0, 0);
+      }
+    }
+    // ---- layer 2 (the next tile's features are loaded between its k-steps, one per step)
+    const bool more = t + nwaves < a.ntiles;
+    const float* xn = row_of(more ? t + nwaves : t);
+    f32x4 out[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) out[mb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int q = 0; q < 4 * MB; ++q) {
+      if (q < 16 && q < a.S1 && more) xr[q < 16 ? q : 0] = feature(xn, q);
+      if (q < a.S2) {
+        const float b = relu(acc[q >> 2][q & 3]);
+        const float4 w0 = *reinterpret_cast<const float4*>(f2 + q * 512 + lane * 8);
+        const float4 w1 = *reinterpret_cast<const float4*>(f2 + q * 512 + lane * 8 + 4);
+        const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) out[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[mb], b, out[mb], 0, 0, 0);
+      }
+    }
+    // ---- head: this lane's 4 MB rows, then the other three lane groups'
+    float d = 0.0f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) d = fmaf(wd[(mb * 4 + i) * 4 + g], relu(out[mb][i]), d);
+    d += __shfl_xor(d, 16);
+    d += __shfl_xor(d, 32);
+    const float p0 = 1.0f / (1.0f + expf(-d));
+    const float p1 = 1.0f / (1.0f + expf(d));
+    if (g == 0 && valid) {
+      const u32x4 rnd = philox4x32_10((uint32_t)agent, (uint32_t)((uint64_t)agent >> 32), a.step_lo, TAG_ACTION ^ a.step_hi, a.k0, a.k1);
+      const float u = ((float)(rnd.x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const int act = u < p0 ? 0 : 1;
+      a.action[agent] = (uint8_t)act;
+      if (a.a_prob) a.a_prob[agent] = act ? p1 : p0;
+      if (a.probs) {
+        a.probs[agent * 2] = p0;
+        a.probs[agent * 2 + 1] = p1;
+      }
+    }
+  }
+}
+
 int acc_row_half0(int q) { return 32 * (q >> 4) + (q & 3) + 8 * ((q >> 2) & 3); }
 
-int steps1(int num_state) { return (num_state + 2) / 2; }   // ceil((F + 1) / 2): F features + the constant 1
+// layout MDR_ACTOR_FRAG32: ceil((F + 1) / 2) k-steps of 2; MDR_ACTOR_FRAG16: ceil((F + 1) / 4) k-steps of 4
+int steps1(int layout, int num_state) { return layout == MDR_ACTOR_FRAG16 ? (num_state + 4) / 4 : (num_state + 2) / 2; }
 
-int steps2(int hidden1) {   // (block, register) pairs whose half-0 row is <= hidden1 (rows 0..hidden1-1 and the constant unit)
-  int n = 0;
+int steps2(int layout, int hidden1) {
+  if (layout == MDR_ACTOR_FRAG16) return 4 * ((hidden1 + 16) / 16);   // every register of the 16-row blocks holding rows <= hidden1
+  int n = 0;                                                             // FRAG32: (block, register) pairs whose half-0 row is <= hidden1
   for (int q = 0; q < 64; ++q)
     if (acc_row_half0(q) <= hidden1) ++n;
   return n;
 }
 
+int floats_per_step(int layout) { return layout == MDR_ACTOR_FRAG16 ? 512 : 256; }
+
+bool layout_ok(int layout) { return layout == MDR_ACTOR_FRAG32 || layout == MDR_ACTOR_FRAG16; }
+
 }  // namespace
 
 extern "C" {
 
-int64_t mdr_actor_steps1(int32_t num_state) { return num_state > 0 ? steps1(num_state) : -1; }
-int64_t mdr_actor_steps2(int32_t hidden1) { return (hidden1 > 0 && hidden1 <= MDR_ACTOR_MAX_HIDDEN) ? steps2(hidden1) : -1; }
-int64_t mdr_actor_frag1_floats(int32_t num_state) { return num_state > 0 ? (int64_t)steps1(num_state) * 256 : -1; }
-int64_t mdr_actor_frag2_floats(int32_t hidden1) { return mdr_actor_steps2(hidden1) < 0 ? -1 : mdr_actor_steps2(hidden1) * 256; }
+int64_t mdr_actor_steps1(int32_t layout, int32_t num_state) { return (layout_ok(layout) && num_state > 0) ? steps1(layout, num_state) : -1; }
+int64_t mdr_actor_steps2(int32_t layout, int32_t hidden1) {
+  return (layout_ok(layout) && hidden1 > 0 && hidden1 <= MDR_ACTOR_MAX_HIDDEN) ? steps2(layout, hidden1) : -1;
+}
+int64_t mdr_actor_frag1_floats(int32_t layout, int32_t num_state) {
+  return mdr_actor_steps1(layout, num_state) < 0 ? -1 : mdr_actor_steps1(layout, num_state) * floats_per_step(layout);
+}
+int64_t mdr_actor_frag2_floats(int32_t layout, int32_t hidden1) {
+  return mdr_actor_steps2(layout, hidden1) < 0 ? -1 : mdr_actor_steps2(layout, hidden1) * floats_per_step(layout);
+}
 
 int mdr_actor_sample(const mdr_actor_t* actor, const float* obs, int64_t nb_agents, uint64_t seed, uint64_t step, uint8_t* action,
                      float* a_prob, float* probs, void* stream) {
   if (!actor || actor->struct_size != sizeof(mdr_actor_t) || !obs || !action || nb_agents < 0) return MDR_ERR_INVALID;
-  if (!actor->frag1 || !actor->frag2 || !actor->wdiff) return MDR_ERR_INVALID;
+  if (!actor->frag1 || !actor->frag2 || !actor->wdiff || !layout_ok(actor->layout)) return MDR_ERR_INVALID;
   if (actor->num_state <= 0 || actor->hidden1 <= 0 || actor->hidden2 <= 0) return MDR_ERR_INVALID;
   if (actor->hidden1 > MDR_ACTOR_MAX_HIDDEN || actor->hidden2 > MDR_ACTOR_MAX_HIDDEN) return MDR_ERR_UNSUPPORTED;
   if (nb_agents == 0) return MDR_OK;
+  const int layout = actor->layout;
+  const bool l16 = layout == MDR_ACTOR_FRAG16;
+  if (l16 && actor->num_state > 63) return MDR_ERR_UNSUPPORTED;   // 16 k-steps of 4 features (incl. the constant 1): pack FRAG32 instead
   ActorArgs a{};
   a.frag1 = actor->frag1; a.frag2 = actor->frag2; a.wdiff = actor->wdiff;
   a.obs = obs; a.action = action; a.a_prob = a_prob; a.probs = probs;
   a.A = nb_agents;
-  a.ntiles = (nb_agents + 31) / 32;
-  a.F = actor->num_state; a.S1 = steps1(actor->num_state); a.S2 = steps2(actor->hidden1);
+  const int tile = l16 ? 16 : 32, waves = l16 ? WAVES16 : WAVES;
+  a.ntiles = (nb_agents + tile - 1) / tile;
+  a.F = actor->num_state; a.S1 = steps1(layout, actor->num_state); a.S2 = steps2(layout, actor->hidden1);
   a.k0 = (uint32_t)(seed & 0xFFFFFFFFull); a.k1 = (uint32_t)(seed >> 32);
   a.step_lo = (uint32_t)(step & 0xFFFFFFFFull); a.step_hi = (uint32_t)(step >> 32);
-  const size_t lds_bytes = ((size_t)(a.S1 + a.S2) * 256 + 128) * sizeof(float);
+  const size_t lds_bytes = ((size_t)(a.S1 + a.S2) * floats_per_step(layout) + 128) * sizeof(float);
   if (lds_bytes > 160 * 1024) return MDR_ERR_UNSUPPORTED;   // num_state beyond ~190 with 100-unit layers
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-  const int64_t want = (a.ntiles + WAVES - 1) / WAVES;
+  const int64_t want = (a.ntiles + waves - 1) / waves;
   const unsigned grid = (unsigned)(want < cus ? want : cus);   // persistent: the weights are staged once per workgroup
   auto launch = [&](auto kernel) -> int {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
       return MDR_ERR_HIP;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * WAVES), lds_bytes, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * waves), lds_bytes, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? MDR_OK : MDR_ERR_HIP;
   };
+  if (l16) {
+    const int hmax = actor->hidden1 > actor->hidden2 ? actor->hidden1 : actor->hidden2;
+    return hmax + 1 <= 112 ? launch(k_actor_sample16<7>) : launch(k_actor_sample16<8>);
+  }
   if (a.S1 <= 32 && a.S2 == 52) return launch(k_actor_sample<32, 52>);   // the reference's shape: num_state <= 62, layers [100, 100]
   if (a.S1 <= 32) return launch(k_actor_sample<32, 0>);
   return launch(k_actor_sample<0, 0>);

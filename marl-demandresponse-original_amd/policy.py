@@ -17,8 +17,12 @@ from . import _native as nat
 MAX_HIDDEN = 127
 
 
+FRAG32, FRAG16 = 0, 1
+
+
 class MdrActor(C.Structure):
-    _fields_ = [("struct_size", C.c_uint32), ("num_state", C.c_int32), ("hidden1", C.c_int32), ("hidden2", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("layout", C.c_int32), ("num_state", C.c_int32), ("hidden1", C.c_int32),
+                ("hidden2", C.c_int32), ("reserved0", C.c_int32),
                 ("frag1", C.c_void_p), ("frag2", C.c_void_p), ("wdiff", C.c_void_p)]
 
 
@@ -27,8 +31,9 @@ def _acc_row(reg: np.ndarray, half: np.ndarray) -> np.ndarray:
 
 
 class FusedActor:
-    def __init__(self, w1, b1, w2, b2, w3, b3, device="cuda:0"):
-        """w1 [H1, F], b1 [H1], w2 [H2, H1], b2 [H2], w3 [2, H2], b3 [2] (torch.nn.Linear layout)."""
+    def __init__(self, w1, b1, w2, b2, w3, b3, device="cuda:0", layout: Optional[int] = None):
+        """w1 [H1, F], b1 [H1], w2 [H2, H1], b2 [H2], w3 [2, H2], b3 [2] (torch.nn.Linear layout).
+        ``layout``: FRAG16 (v_mfma_f32_16x16x4_f32, the default whenever F <= 63) or FRAG32 (v_mfma_f32_32x32x2_f32)."""
         self._lib = nat.load()
         w1, b1, w2, b2, w3, b3 = (torch.as_tensor(t, dtype=torch.float32).detach().cpu() for t in (w1, b1, w2, b2, w3, b3))
         H1, F = w1.shape
@@ -37,42 +42,59 @@ class FusedActor:
             raise ValueError("expected Linear(F,H1) - Linear(H1,H2) - Linear(H2,2)")
         if H1 > MAX_HIDDEN or H2 > MAX_HIDDEN:
             raise ValueError("hidden layers of at most %d units" % MAX_HIDDEN)
+        if layout is None:
+            layout = FRAG16 if F <= 63 else FRAG32
+        self.layout = int(layout)
         self.num_state, self.hidden1, self.hidden2 = int(F), int(H1), int(H2)
         self.device = torch.device(device)
-        S1 = int(self._lib.mdr_actor_steps1(F))
-        S2 = int(self._lib.mdr_actor_steps2(H1))
+        S1 = int(self._lib.mdr_actor_steps1(self.layout, F))
+        S2 = int(self._lib.mdr_actor_steps2(self.layout, H1))
+        if S1 < 0 or S2 < 0:
+            raise ValueError("unknown layout %r" % (layout,))
         lane = np.arange(64)
-        r, h = lane & 31, lane >> 5
-        rows = (32 * np.arange(4)[:, None] + r[None, :])                     # [mb, lane] output row of the fragment
+        kw = 4 if self.layout == FRAG16 else 2                                  # k per MFMA step
+        bw = 16 if self.layout == FRAG16 else 32                                # rows per block
+        nb = 128 // bw                                                          # blocks stored per lane (8 | 4)
+        r, g = lane & (bw - 1), lane // bw                                      # row in block, lane group (= k within a step)
+        rows = bw * np.arange(nb)[:, None] + r[None, :]                         # [mb, lane] output row of the fragment
         # bias-extended, zero-padded matrices: input feature F / hidden unit H is the constant 1
-        w1e = torch.zeros((128, 2 * S1))
+        w1e = torch.zeros((128, kw * S1))
         w1e[:H1, :F], w1e[:H1, F], w1e[H1, F] = w1, b1, 1.0
         w2e = torch.zeros((128, 128))
         w2e[:H2, :H1], w2e[:H2, H1], w2e[H2, H1] = w2, b2, 1.0
         w3e = torch.zeros((2, 128))
         w3e[:, :H2], w3e[:, H2] = w3, b3
-        k1 = h[None, :] * S1 + np.arange(S1)[:, None]                          # [s, lane]
-        frag1 = w1e[torch.from_numpy(rows)[None, :, :], torch.from_numpy(k1)[:, None, :]].permute(0, 2, 1)   # [S1, 64, 4]
+        k1 = g[None, :] * S1 + np.arange(S1)[:, None]                           # [s, lane]
         q = np.arange(S2)
-        k2 = 32 * (q >> 4)[:, None] + _acc_row((q & 15)[:, None], h[None, :])  # [q, lane]
-        frag2 = w2e[torch.from_numpy(rows)[None, :, :], torch.from_numpy(k2)[:, None, :]].permute(0, 2, 1)   # [S2, 64, 4]
-        reg = np.arange(16)
-        row3 = 32 * np.arange(4)[:, None, None] + _acc_row(reg[None, :, None], np.arange(2)[None, None, :])   # [mb, reg, h]
-        wdiff = (w3e[0] - w3e[1])[torch.from_numpy(row3)]                       # [4, 16, 2]
+        if self.layout == FRAG16:
+            k2 = 16 * (q >> 2)[:, None] + 4 * g[None, :] + (q & 3)[:, None]     # [q, lane]: the accumulator row the lane holds
+            reg = np.arange(4)
+            row3 = 16 * np.arange(8)[:, None, None] + 4 * np.arange(4)[None, None, :] + reg[None, :, None]        # [mb, reg, g]
+        else:
+            k2 = 32 * (q >> 4)[:, None] + _acc_row((q & 15)[:, None], g[None, :])
+            reg = np.arange(16)
+            row3 = 32 * np.arange(4)[:, None, None] + _acc_row(reg[None, :, None], np.arange(2)[None, None, :])   # [mb, reg, h]
+        k2 = np.minimum(k2, 127)
+        frag1 = w1e[torch.from_numpy(rows)[None, :, :], torch.from_numpy(k1)[:, None, :]].permute(0, 2, 1)   # [S1, 64, nb]
+        frag2 = w2e[torch.from_numpy(rows)[None, :, :], torch.from_numpy(k2)[:, None, :]].permute(0, 2, 1)   # [S2, 64, nb]
+        wdiff = (w3e[0] - w3e[1])[torch.from_numpy(row3)]
         self._frag1 = frag1.contiguous().to(self.device)
         self._frag2 = frag2.contiguous().to(self.device)
         self._wdiff = wdiff.contiguous().to(self.device)
-        assert self._frag1.numel() == self._lib.mdr_actor_frag1_floats(F) and self._frag2.numel() == self._lib.mdr_actor_frag2_floats(H1)
-        self._desc = MdrActor(C.sizeof(MdrActor), F, H1, H2, self._frag1.data_ptr(), self._frag2.data_ptr(), self._wdiff.data_ptr())
+        assert self._wdiff.numel() == 128
+        assert self._frag1.numel() == self._lib.mdr_actor_frag1_floats(self.layout, F)
+        assert self._frag2.numel() == self._lib.mdr_actor_frag2_floats(self.layout, H1)
+        self._desc = MdrActor(C.sizeof(MdrActor), self.layout, F, H1, H2, 0, self._frag1.data_ptr(), self._frag2.data_ptr(),
+                              self._wdiff.data_ptr())
 
     @classmethod
-    def from_module(cls, actor, device=None) -> "FusedActor":
+    def from_module(cls, actor, device=None, layout: Optional[int] = None) -> "FusedActor":
         """From an ``ActorMLP`` / the reference's ``Actor`` (``fc`` ModuleList of three Linear layers)."""
         fc = list(actor.fc)
         if len(fc) != 3:
             raise ValueError("the fused kernel covers two hidden layers (config.py: layers = [100, 100])")
         dev = device if device is not None else fc[0].weight.device
-        return cls(fc[0].weight, fc[0].bias, fc[1].weight, fc[1].bias, fc[2].weight, fc[2].bias, device=dev)
+        return cls(fc[0].weight, fc[0].bias, fc[1].weight, fc[1].bias, fc[2].weight, fc[2].bias, device=dev, layout=layout)
 
     def sample(self, obs: torch.Tensor, seed: int, step: int, want_probs: bool = False,
                action: Optional[torch.Tensor] = None, a_prob: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, ...]:

@@ -24,10 +24,15 @@ def _actor(F, layers, seed=0, scale=1.0):
 @pytest.mark.parametrize("A,F,layers", [(1, 51, (100, 100)), (31, 51, (100, 100)), (33, 51, (100, 100)), (1000, 51, (100, 100)),
                                         (4097, 47, (100, 100)), (777, 133, (100, 100)), (500, 11, (64, 32)), (300, 51, (127, 127)),
                                         (300, 50, (1, 1)), (300000, 51, (100, 100))])
-def test_fused_actor_matches_torch_forward(A, F, layers):
+@pytest.mark.parametrize("layout", [0, 1])
+def test_fused_actor_matches_torch_forward(A, F, layers, layout):
     from mdr_amd.policy import FusedActor
+    if layout == 1 and F > 63:
+        with pytest.raises(RuntimeError):
+            FusedActor.from_module(_actor(F, layers), layout=1).sample(torch.zeros((4, F), device="cuda:0"), 0, 0)
+        return
     actor = _actor(F, layers, seed=A, scale=3.0)
-    fused = FusedActor.from_module(actor)
+    fused = FusedActor.from_module(actor, layout=layout)
     g = torch.Generator(device="cuda:0").manual_seed(1)
     obs = torch.randn((A, F), device="cuda:0", generator=g) * 2.0
     with torch.no_grad():
@@ -39,7 +44,8 @@ def test_fused_actor_matches_torch_forward(A, F, layers):
     assert float((probs.sum(1) - 1).abs().max()) < 1e-6
 
 
-def test_weight_layout_is_checked_with_asymmetric_integer_data():
+@pytest.mark.parametrize("layout", [0, 1])
+def test_weight_layout_is_checked_with_asymmetric_integer_data(layout):
     """Exact small-integer weights and inputs (every product and sum exact in fp32): the logits' difference must be exact,
     which a swapped A/B operand, a wrong k order between the layers or a transposed block would not survive."""
     from mdr_amd.policy import FusedActor
@@ -58,7 +64,7 @@ def test_weight_layout_is_checked_with_asymmetric_integer_data():
     assert np.abs(h2).max() < 2 ** 22                    # everything stays in fp32's exact-integer range
     d = logits[:, 0] - logits[:, 1]
     p0 = 1.0 / (1.0 + np.exp(-d))
-    fused = FusedActor(w1, b1, w2.astype(np.float32), b2, w3.astype(np.float32), b3)
+    fused = FusedActor(w1, b1, w2.astype(np.float32), b2, w3.astype(np.float32), b3, layout=layout)
     _, _, probs = fused.sample(torch.from_numpy(x).cuda(), seed=1, step=0, want_probs=True)
     np.testing.assert_allclose(probs[:, 0].cpu().numpy(), p0, rtol=2e-6, atol=1e-30)
     np.testing.assert_allclose(probs[:, 1].cpu().numpy(), 1.0 / (1.0 + np.exp(d)), rtol=2e-6, atol=1e-30)
