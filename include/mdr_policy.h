@@ -59,10 +59,12 @@ int64_t mdr_actor_frag2_floats(int32_t layout, int32_t hidden1);    /* S2 * 64 l
 
 /* For every agent a < nb_agents: probs = softmax(actor(obs[a])), u = Philox4x32-10(key = seed, counter = (a, step, stream))
  * uniform in (0,1), action = u < probs[0] ? 0 : 1  (Categorical(probs).sample()), a_prob = probs[action].
- * `action` uint8 [nb_agents], `a_prob` float [nb_agents] (may be NULL), `probs` float [nb_agents][2] (may be NULL).
- * Returns 0, or -1 (invalid argument) / -3 (HIP error) / -4 (shape without a kernel). */
-int mdr_actor_sample(const mdr_actor_t *actor, const float *obs, int64_t nb_agents, uint64_t seed, uint64_t step,
-                     uint8_t *action, float *a_prob, float *probs, void *stream);
+ * `obs`: observation rows [nb_agents][F] when obs_plane_stride == 0 (mdr_env_obs_vector MDR_OBS_ROWS), or feature planes
+ * [F][obs_plane_stride] with obs_plane_stride >= nb_agents (MDR_OBS_PLANES: the lanes of a wavefront then read consecutive
+ * floats instead of one cache line each).  `action` uint8 [nb_agents], `a_prob` float [nb_agents] (may be NULL), `probs`
+ * float [nb_agents][2] (may be NULL).  Returns 0, or -1 (invalid argument) / -3 (HIP error) / -4 (shape without a kernel). */
+int mdr_actor_sample(const mdr_actor_t *actor, const float *obs, int64_t obs_plane_stride, int64_t nb_agents, uint64_t seed,
+                     uint64_t step, uint8_t *action, float *a_prob, float *probs, void *stream);
 
 #ifdef __cplusplus
 }

@@ -182,7 +182,7 @@ def load():
         "mdr_actor_steps2": (i64, [i32, i32]),
         "mdr_actor_frag1_floats": (i64, [i32, i32]),
         "mdr_actor_frag2_floats": (i64, [i32, i32]),
-        "mdr_actor_sample": (C.c_int, [vp, vp, i64, u64, u64, vp, vp, vp, vp]),
+        "mdr_actor_sample": (C.c_int, [vp, vp, i64, i64, u64, u64, vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -44,6 +44,7 @@ struct ActorArgs {
   float* probs;
   int64_t A;
   int64_t ntiles;
+  int64_t plane;   // 0: obs is [A][F] rows; > 0: feature-major [F][plane] (plane >= A): lanes of a group read consecutive floats
   int F, S1, S2;
   uint32_t k0, k1, step_lo, step_hi;
 };
@@ -73,13 +74,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_actor_sample(ActorArgs a) {
   const int S2 = S2C ? S2C : a.S2;
   constexpr int XR = X1 ? X1 : 1;
   float xr[XR];
+  const int64_t fstride = a.plane ? a.plane : 1;   // distance between two features of one agent
   auto row_of = [&](int64_t t) {
     const int64_t agent = t * 32 + r;
-    return a.obs + (agent < a.A ? agent : a.A - 1) * (int64_t)a.F;
+    return a.obs + (agent < a.A ? agent : a.A - 1) * (a.plane ? 1 : (int64_t)a.F);
   };
   auto feature = [&](const float* x, int s) {
     const int k = kbase + s;
-    return k < a.F ? x[k] : (k == a.F ? 1.0f : 0.0f);
+    return k < a.F ? x[k * fstride] : (k == a.F ? 1.0f : 0.0f);
   };
   auto prefetch = [&](int64_t t) {
     if (X1 == 0 || t >= a.ntiles) return;
@@ -192,13 +194,14 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
   const int64_t nwaves = (int64_t)gridDim.x * WAVES16;
   const int kbase = g * a.S1;            // this lane group's input features: [kbase, kbase + S1)
   float xr[16];
+  const int64_t fstride = a.plane ? a.plane : 1;   // distance between two features of one agent
   auto row_of = [&](int64_t t) {
     const int64_t agent = t * 16 + r;
-    return a.obs + (agent < a.A ? agent : a.A - 1) * (int64_t)a.F;
+    return a.obs + (agent < a.A ? agent : a.A - 1) * (a.plane ? 1 : (int64_t)a.F);
   };
   auto feature = [&](const float* x, int s) {
     const int k = kbase + s;
-    const float v = x[min(k, a.F - 1)];
+    const float v = x[min(k, a.F - 1) * fstride];
     return k < a.F ? v : (k == a.F ? 1.0f : 0.0f);
   };
   if (wave < a.ntiles) {
@@ -297,9 +300,10 @@ int64_t mdr_actor_frag2_floats(int32_t layout, int32_t hidden1) {
   return mdr_actor_steps2(layout, hidden1) < 0 ? -1 : mdr_actor_steps2(layout, hidden1) * floats_per_step(layout);
 }
 
-int mdr_actor_sample(const mdr_actor_t* actor, const float* obs, int64_t nb_agents, uint64_t seed, uint64_t step, uint8_t* action,
-                     float* a_prob, float* probs, void* stream) {
+int mdr_actor_sample(const mdr_actor_t* actor, const float* obs, int64_t obs_plane_stride, int64_t nb_agents, uint64_t seed, uint64_t step,
+                     uint8_t* action, float* a_prob, float* probs, void* stream) {
   if (!actor || actor->struct_size != sizeof(mdr_actor_t) || !obs || !action || nb_agents < 0) return MDR_ERR_INVALID;
+  if (obs_plane_stride != 0 && obs_plane_stride < nb_agents) return MDR_ERR_INVALID;
   if (!actor->frag1 || !actor->frag2 || !actor->wdiff || !layout_ok(actor->layout)) return MDR_ERR_INVALID;
   if (actor->num_state <= 0 || actor->hidden1 <= 0 || actor->hidden2 <= 0) return MDR_ERR_INVALID;
   if (actor->hidden1 > MDR_ACTOR_MAX_HIDDEN || actor->hidden2 > MDR_ACTOR_MAX_HIDDEN) return MDR_ERR_UNSUPPORTED;
@@ -311,6 +315,7 @@ int mdr_actor_sample(const mdr_actor_t* actor, const float* obs, int64_t nb_agen
   a.frag1 = actor->frag1; a.frag2 = actor->frag2; a.wdiff = actor->wdiff;
   a.obs = obs; a.action = action; a.a_prob = a_prob; a.probs = probs;
   a.A = nb_agents;
+  a.plane = obs_plane_stride;
   const int tile = l16 ? 16 : 32, waves = l16 ? WAVES16 : WAVES;
   a.ntiles = (nb_agents + tile - 1) / tile;
   a.F = actor->num_state; a.S1 = steps1(layout, actor->num_state); a.S2 = steps2(layout, actor->hidden1);

@@ -98,15 +98,26 @@ class FusedActor:
 
     def sample(self, obs: torch.Tensor, seed: int, step: int, want_probs: bool = False,
                action: Optional[torch.Tensor] = None, a_prob: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, ...]:
-        """obs float32 [A, F] (contiguous, on the device) -> (action uint8 [A], a_prob float32 [A][, probs [A, 2]])."""
-        if obs.dtype != torch.float32 or obs.device != self.device or not obs.is_contiguous() or obs.dim() != 2 or obs.shape[1] != self.num_state:
-            raise ValueError("obs must be a contiguous float32 [A, %d] tensor on %s" % (self.num_state, self.device))
-        A = obs.shape[0]
+        """obs float32 on the device: rows [A, F] (contiguous) or feature planes - any [F, ...] tensor whose trailing
+        dimensions are contiguous (e.g. ``env.obs_vector("planes")``: [F, E, N] with a padded plane stride), or the
+        transposed view [A, F] of one -> (action uint8 [A], a_prob float32 [A][, probs [A, 2]])."""
+        F = self.num_state
+        if obs.dtype != torch.float32 or obs.device != self.device:
+            raise ValueError("obs must be a float32 tensor on %s" % (self.device,))
+        if obs.dim() == 2 and obs.shape[1] == F and obs.is_contiguous():
+            A, plane = obs.shape[0], 0
+        else:
+            planes = obs.t() if (obs.dim() == 2 and obs.shape[1] == F and obs.stride(1) >= obs.shape[0] and obs.stride(0) == 1) else obs
+            if planes.shape[0] != F or (planes.dim() > 1 and not planes[0].is_contiguous()):
+                raise ValueError("obs must be rows [A, %d] or feature planes [%d, ...]" % (F, F))
+            A, plane = planes[0].numel(), planes.stride(0)
+            if plane < A:
+                raise ValueError("feature planes overlap")
         action = torch.empty(A, dtype=torch.uint8, device=self.device) if action is None else action
         a_prob = torch.empty(A, dtype=torch.float32, device=self.device) if a_prob is None else a_prob
         probs = torch.empty((A, 2), dtype=torch.float32, device=self.device) if want_probs else None
         with torch.cuda.device(self.device):
-            rc = self._lib.mdr_actor_sample(C.byref(self._desc), C.c_void_p(obs.data_ptr()), A, C.c_uint64(seed & (2 ** 64 - 1)),
+            rc = self._lib.mdr_actor_sample(C.byref(self._desc), C.c_void_p(obs.data_ptr()), plane, A, C.c_uint64(seed & (2 ** 64 - 1)),
                                             C.c_uint64(step & (2 ** 64 - 1)), C.c_void_p(action.data_ptr()), C.c_void_p(a_prob.data_ptr()),
                                             C.c_void_p(probs.data_ptr()) if want_probs else None,
                                             C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))

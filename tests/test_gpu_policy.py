@@ -109,3 +109,26 @@ def test_fused_actor_argument_checks():
         fused.sample(torch.zeros((4, 50), device="cuda:0"), 0, 0)
     with pytest.raises(ValueError):
         fused.sample(torch.zeros((4, 51), device="cuda:0", dtype=torch.float64), 0, 0)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("A,F", [(1000, 51), (4097, 47), (33, 11)])
+def test_feature_plane_input_gives_the_same_bits_as_rows(A, F, layout):
+    """obs as feature planes [F][stride] (what mdr_env_obs_vector MDR_OBS_PLANES writes) instead of rows [A][F]."""
+    from mdr_amd.policy import FusedActor
+    actor = _actor(F, (100, 100), seed=2, scale=3.0)
+    fused = FusedActor.from_module(actor, layout=layout)
+    rows = torch.randn((A, F), device="cuda:0")
+    a0, p0, pr0 = fused.sample(rows, 3, 4, want_probs=True)
+    planes = rows.t().contiguous()                                   # [F, A]
+    a1, p1, pr1 = fused.sample(planes, 3, 4, want_probs=True)
+    assert torch.equal(a0, a1) and torch.equal(pr0, pr1) and torch.equal(p0, p1)
+    padded = torch.zeros((F, A + 576), device="cuda:0")
+    padded[:, :A] = planes
+    a2, _, pr2 = fused.sample(padded[:, :A].view(F, A) if False else padded.as_strided((F, A), (A + 576, 1)), 3, 4, want_probs=True)
+    assert torch.equal(a0, a2) and torch.equal(pr0, pr2)
+    a3, _, pr3 = fused.sample(planes.t(), 3, 4, want_probs=True)     # the transposed [A, F] view of the planes
+    assert torch.equal(a0, a3) and torch.equal(pr0, pr3)
+    env_like = planes.view(F, 1, A)                                  # [F, E, N] as obs_vector("planes") returns it
+    a4, _ = fused.sample(env_like, 3, 4)
+    assert torch.equal(a0, a4)

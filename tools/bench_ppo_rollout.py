@@ -40,6 +40,9 @@ def main():
         from mdr_amd.policy import FusedActor
         fused = FusedActor.from_module(actor)
         stages["fused_actor_sample"] = lambda: fused.sample(obs, 1, 2)
+        planes = env.obs_vector("planes")
+        stages["obs_vector_planes"] = lambda: env.obs_vector("planes")
+        stages["fused_actor_sample_planes"] = lambda: fused.sample(planes, 1, 2)
         fused32 = FusedActor.from_module(actor, layout=0)
         stages["fused_actor_sample_frag32"] = lambda: fused32.sample(obs, 1, 2)
         stages["sample"] = lambda: (torch.multinomial(probs, 1).squeeze(1), probs.gather(1, a[:, None]))
