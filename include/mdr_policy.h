@@ -26,8 +26,11 @@ extern "C" {
 
 enum mdr_actor_layout {
   MDR_ACTOR_FRAG32 = 0, /* v_mfma_f32_32x32x2_f32: 32 agents per wavefront, any num_state that fits the LDS */
-  MDR_ACTOR_FRAG16 = 1  /* v_mfma_f32_16x16x4_f32: 16 agents per wavefront, hidden units padded to 112 instead of 128 rows and a
+  MDR_ACTOR_FRAG16 = 1, /* v_mfma_f32_16x16x4_f32: 16 agents per wavefront, hidden units padded to 112 instead of 128 rows and a
                            quarter of the accumulator registers; num_state <= 63 */
+  MDR_ACTOR_BF16X3 = 2  /* v_mfma_f32_16x16x32_bf16 on operands split into bf16 head + tail (x = xh + xl): w x ~ wh xh + wl xh +
+                           wh xl, fp32 accumulation - 16 significand bits per operand instead of 24 (probabilities within ~1e-5
+                           of the fp32 forward) at 16 / 3 times the fp32 matrix rate; num_state <= 63.  frag1 / frag2 hold bf16 */
 };
 
 typedef struct mdr_actor {
@@ -46,16 +49,20 @@ typedef struct mdr_actor {
    * MDR_ACTOR_FRAG16 (S1 = ceil((F + 1) / 4), S2 = 4 ceil((H1 + 1) / 16), r = lane & 15, g = lane >> 4):
    *   frag1[s][lane][mb < 8]  = W1e[16 mb + r][g S1 + s]
    *   frag2[q][lane][mb < 8]  = W2e[16 mb + r][16 (q >> 2) + 4 g + (q & 3)]
-   *   wdiff[mb < 8][reg < 4][g]  = W3e[0][row] - W3e[1][row],  row = 16 mb + 4 g + reg */
-  const float *frag1;
-  const float *frag2;
+   *   wdiff[mb < 8][reg < 4][g]  = W3e[0][row] - W3e[1][row],  row = 16 mb + 4 g + reg
+   * MDR_ACTOR_BF16X3 (S1 = ceil((F + 1) / 32), S2 = 4, r = lane & 15, g = lane >> 4, fragments of 8 bf16, t = 0 head / 1 tail):
+   *   frag1[s][mb < 8][t][lane][j < 8] = split_t(W1e[16 mb + r][(4 s + g) 8 + j])
+   *   frag2[s][mb < 8][t][lane][j < 8] = split_t(W2e[16 mb + r][16 (2 s + (j >> 2)) + 4 g + (j & 3)])
+   *   wdiff as MDR_ACTOR_FRAG16;  split_0(w) = bf16(w), split_1(w) = bf16(w - split_0(w)), round to nearest even */
+  const void *frag1;
+  const void *frag2;
   const float *wdiff;  /* 128 floats */
 } mdr_actor_t;
 
 int64_t mdr_actor_steps1(int32_t layout, int32_t num_state);        /* S1 */
 int64_t mdr_actor_steps2(int32_t layout, int32_t hidden1);          /* S2 */
-int64_t mdr_actor_frag1_floats(int32_t layout, int32_t num_state);  /* S1 * 64 lanes * (4 | 8) */
-int64_t mdr_actor_frag2_floats(int32_t layout, int32_t hidden1);    /* S2 * 64 lanes * (4 | 8) */
+int64_t mdr_actor_frag1_floats(int32_t layout, int32_t num_state);  /* size of frag1 in 4-byte units */
+int64_t mdr_actor_frag2_floats(int32_t layout, int32_t hidden1);    /* size of frag2 in 4-byte units */
 
 /* For every agent a < nb_agents: probs = softmax(actor(obs[a])), u = Philox4x32-10(key = seed, counter = (a, step, stream))
  * uniform in (0,1), action = u < probs[0] ? 0 : 1  (Categorical(probs).sample()), a_prob = probs[action].

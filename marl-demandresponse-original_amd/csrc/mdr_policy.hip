@@ -268,12 +268,161 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
   }
 }
 
+// ---- the same network on v_mfma_f32_16x16x32_bf16 with every fp32 operand split into two bf16 halves, x = xh + xl
+// (xh = bf16(x), xl = bf16(x - xh): 16 significand bits): w x ~ wh xh + wl xh + wh xl, three MFMAs at 16x the fp32
+// matrix rate, fp32 accumulation; the dropped wl xl term is 2^-16 of the product.  16 agents per wavefront, K = 32 per
+// k-step.  A[row = lane & 15][k = 8 (lane >> 4) + j], B[k = 8 (lane >> 4) + j][col = lane & 15], j < 8; C/D as 16x16x4.
+// Layer 1: k-step s, lane group g, element j <-> input feature (4 s + g) 8 + j (a contiguous run per lane).
+// Layer 2: k-step s covers the row blocks 2 s and 2 s + 1 of layer 1: element j <-> row 16 (2 s + (j >> 2)) + 4 g + (j & 3),
+// i.e. register [2 s + (j >> 2)][j & 3] of the lane itself - again no LDS and no lane movement for the activations.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {   // (bf16(hi) << 16) | bf16(lo), round to nearest even
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// eight fp32 values -> their bf16 head and tail fragments
+__device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
+  uint32_t h[4], l[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    h[p] = cvt_pk_bf16(v[2 * p], v[2 * p + 1]);
+    const float a = __uint_as_float(h[p] << 16), b = __uint_as_float(h[p] & 0xFFFF0000u);
+    l[p] = cvt_pk_bf16(v[2 * p] - a, v[2 * p + 1] - b);
+  }
+  hi = uint4{h[0], h[1], h[2], h[3]};
+  lo = uint4{l[0], l[1], l[2], l[3]};
+}
+
+template <int MB>
+__global__ __launch_bounds__(64 * WAVES16) void k_actor_sample_bf16(ActorArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int S2B = (MB + 1) / 2;
+  uint4* f1 = reinterpret_cast<uint4*>(lds);                    // [S1][8][2][64] fragments of 8 bf16 (8 row blocks stored, MB used)
+  uint4* f2 = f1 + a.S1 * 1024;                                 // [S2B][8][2][64]
+  float* wd = reinterpret_cast<float*>(f2 + S2B * 1024);    // [8][4][4]
+  const int tid = threadIdx.x;
+  const uint4* g1 = reinterpret_cast<const uint4*>(a.frag1);
+  const uint4* g2 = reinterpret_cast<const uint4*>(a.frag2);
+  for (int i = tid; i < a.S1 * 1024; i += 64 * WAVES16) f1[i] = g1[i];
+  for (int i = tid; i < S2B * 1024; i += 64 * WAVES16) f2[i] = g2[i];
+  if (tid < 128) wd[tid] = a.wdiff[tid];
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int r = lane & 15, g = lane >> 4;
+  const int64_t wave = (int64_t)blockIdx.x * WAVES16 + (tid >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * WAVES16;
+  const int64_t fstride = a.plane ? a.plane : 1;
+  float xr[16];                           // S1 <= 2 k-steps (F <= 63): 8 features per step
+  auto row_of = [&](int64_t t) {
+    const int64_t agent = t * 16 + r;
+    return a.obs + (agent < a.A ? agent : a.A - 1) * (a.plane ? 1 : (int64_t)a.F);
+  };
+  auto feature = [&](const float* x, int i) {   // i = 8 s + j
+    const int k = ((i >> 3) * 4 + g) * 8 + (i & 7);
+    const float v = x[min(k, a.F - 1) * fstride];
+    return k < a.F ? v : (k == a.F ? 1.0f : 0.0f);
+  };
+  if (wave < a.ntiles) {
+    const float* x = row_of(wave);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xr[i] = feature(x, i < 8 * a.S1 ? i : 0);
+  }
+  for (int64_t t = wave; t < a.ntiles; t += nwaves) {
+    const int64_t agent = t * 16 + r;
+    const bool valid = agent < a.A;
+    f32x4 acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // ---- layer 1
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (s < a.S1) {
+        uint4 bh, bl;
+        split8(xr + 8 * s, bh, bl);
+        const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bl = __builtin_bit_cast(bf16x8, bl);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const bf16x8 Ah = __builtin_bit_cast(bf16x8, f1[((s * 8 + mb) * 2 + 0) * 64 + lane]);
+          const bf16x8 Al = __builtin_bit_cast(bf16x8, f1[((s * 8 + mb) * 2 + 1) * 64 + lane]);
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, acc[mb], 0, 0, 0);
+        }
+      }
+    }
+    // ---- layer 2 (the next tile's features are loaded between its k-steps)
+    const bool more = t + nwaves < a.ntiles;
+    const float* xn = row_of(more ? t + nwaves : t);
+    f32x4 out[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) out[mb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int s = 0; s < S2B; ++s) {
+      if (more) {
+#pragma unroll
+        for (int i = 4 * s; i < 4 * s + 4 && i < 16; ++i)
+          if (i < 8 * a.S1) xr[i] = feature(xn, i);
+      }
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (2 * s + (j >> 2) < MB) ? relu(acc[2 * s + (j >> 2) < MB ? 2 * s + (j >> 2) : 0][j & 3]) : 0.0f;
+      uint4 bh, bl;
+      split8(v, bh, bl);
+      const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bl = __builtin_bit_cast(bf16x8, bl);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const bf16x8 Ah = __builtin_bit_cast(bf16x8, f2[((s * 8 + mb) * 2 + 0) * 64 + lane]);
+        const bf16x8 Al = __builtin_bit_cast(bf16x8, f2[((s * 8 + mb) * 2 + 1) * 64 + lane]);
+        out[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, out[mb], 0, 0, 0);
+        out[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, out[mb], 0, 0, 0);
+        out[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, out[mb], 0, 0, 0);
+      }
+    }
+    if (more && S2B * 4 < 16) {
+#pragma unroll
+      for (int i = S2B * 4; i < 16; ++i)
+        if (i < 8 * a.S1) xr[i] = feature(xn, i);
+    }
+    // ---- head: this lane's 4 MB rows, then the other three lane groups'
+    float d = 0.0f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) d = fmaf(wd[(mb * 4 + i) * 4 + g], relu(out[mb][i]), d);
+    d += __shfl_xor(d, 16);
+    d += __shfl_xor(d, 32);
+    const float p0 = 1.0f / (1.0f + expf(-d));
+    const float p1 = 1.0f / (1.0f + expf(d));
+    if (g == 0 && valid) {
+      const u32x4 rnd = philox4x32_10((uint32_t)agent, (uint32_t)((uint64_t)agent >> 32), a.step_lo, TAG_ACTION ^ a.step_hi, a.k0, a.k1);
+      const float u = ((float)(rnd.x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const int act = u < p0 ? 0 : 1;
+      a.action[agent] = (uint8_t)act;
+      if (a.a_prob) a.a_prob[agent] = act ? p1 : p0;
+      if (a.probs) {
+        a.probs[agent * 2] = p0;
+        a.probs[agent * 2 + 1] = p1;
+      }
+    }
+  }
+}
+
 int acc_row_half0(int q) { return 32 * (q >> 4) + (q & 3) + 8 * ((q >> 2) & 3); }
 
 // layout MDR_ACTOR_FRAG32: ceil((F + 1) / 2) k-steps of 2; MDR_ACTOR_FRAG16: ceil((F + 1) / 4) k-steps of 4
-int steps1(int layout, int num_state) { return layout == MDR_ACTOR_FRAG16 ? (num_state + 4) / 4 : (num_state + 2) / 2; }
+int blocks16(int h1, int h2) { return ((h1 > h2 ? h1 : h2) + 1 <= 112) ? 7 : 8; }   // 16-row blocks holding the hidden units + the constant
+
+int steps1(int layout, int num_state) {
+  if (layout == MDR_ACTOR_BF16X3) return (num_state + 32) / 32;   // ceil((F + 1) / 32)
+  return layout == MDR_ACTOR_FRAG16 ? (num_state + 4) / 4 : (num_state + 2) / 2;
+}
 
 int steps2(int layout, int hidden1) {
+  if (layout == MDR_ACTOR_BF16X3) return 4;                           // k-steps of two 16-row blocks each: all 8 stored blocks
   if (layout == MDR_ACTOR_FRAG16) return 4 * ((hidden1 + 16) / 16);   // every register of the 16-row blocks holding rows <= hidden1
   int n = 0;                                                             // FRAG32: (block, register) pairs whose half-0 row is <= hidden1
   for (int q = 0; q < 64; ++q)
@@ -281,9 +430,11 @@ int steps2(int layout, int hidden1) {
   return n;
 }
 
-int floats_per_step(int layout) { return layout == MDR_ACTOR_FRAG16 ? 512 : 256; }
+int floats_per_step(int layout) {   // 4-byte units per k-step: 64 lanes x (4 | 8 floats), or 8 row blocks x (head, tail) x 64 lanes x 8 bf16
+  return layout == MDR_ACTOR_BF16X3 ? 4096 : (layout == MDR_ACTOR_FRAG16 ? 512 : 256);
+}
 
-bool layout_ok(int layout) { return layout == MDR_ACTOR_FRAG32 || layout == MDR_ACTOR_FRAG16; }
+bool layout_ok(int layout) { return layout == MDR_ACTOR_FRAG32 || layout == MDR_ACTOR_FRAG16 || layout == MDR_ACTOR_BF16X3; }
 
 }  // namespace
 
@@ -309,10 +460,11 @@ int mdr_actor_sample(const mdr_actor_t* actor, const float* obs, int64_t obs_pla
   if (actor->hidden1 > MDR_ACTOR_MAX_HIDDEN || actor->hidden2 > MDR_ACTOR_MAX_HIDDEN) return MDR_ERR_UNSUPPORTED;
   if (nb_agents == 0) return MDR_OK;
   const int layout = actor->layout;
-  const bool l16 = layout == MDR_ACTOR_FRAG16;
-  if (l16 && actor->num_state > 63) return MDR_ERR_UNSUPPORTED;   // 16 k-steps of 4 features (incl. the constant 1): pack FRAG32 instead
+  const bool lbf = layout == MDR_ACTOR_BF16X3;
+  const bool l16 = layout == MDR_ACTOR_FRAG16 || lbf;             // 16 agents per wavefront
+  if (l16 && actor->num_state > 63) return MDR_ERR_UNSUPPORTED;   // 16 features per lane (incl. the constant 1): pack FRAG32 instead
   ActorArgs a{};
-  a.frag1 = actor->frag1; a.frag2 = actor->frag2; a.wdiff = actor->wdiff;
+  a.frag1 = static_cast<const float*>(actor->frag1); a.frag2 = static_cast<const float*>(actor->frag2); a.wdiff = actor->wdiff;
   a.obs = obs; a.action = action; a.a_prob = a_prob; a.probs = probs;
   a.A = nb_agents;
   a.plane = obs_plane_stride;
@@ -333,10 +485,9 @@ int mdr_actor_sample(const mdr_actor_t* actor, const float* obs, int64_t obs_pla
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * waves), lds_bytes, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? MDR_OK : MDR_ERR_HIP;
   };
-  if (l16) {
-    const int hmax = actor->hidden1 > actor->hidden2 ? actor->hidden1 : actor->hidden2;
-    return hmax + 1 <= 112 ? launch(k_actor_sample16<7>) : launch(k_actor_sample16<8>);
-  }
+  const int mb = blocks16(actor->hidden1, actor->hidden2);
+  if (lbf) return mb == 7 ? launch(k_actor_sample_bf16<7>) : launch(k_actor_sample_bf16<8>);
+  if (l16) return mb == 7 ? launch(k_actor_sample16<7>) : launch(k_actor_sample16<8>);
   if (a.S1 <= 32 && a.S2 == 52) return launch(k_actor_sample<32, 52>);   // the reference's shape: num_state <= 62, layers [100, 100]
   if (a.S1 <= 32) return launch(k_actor_sample<32, 0>);
   return launch(k_actor_sample<0, 0>);

@@ -17,7 +17,7 @@ from . import _native as nat
 MAX_HIDDEN = 127
 
 
-FRAG32, FRAG16 = 0, 1
+FRAG32, FRAG16, BF16X3 = 0, 1, 2
 
 
 class MdrActor(C.Structure):
@@ -33,7 +33,9 @@ def _acc_row(reg: np.ndarray, half: np.ndarray) -> np.ndarray:
 class FusedActor:
     def __init__(self, w1, b1, w2, b2, w3, b3, device="cuda:0", layout: Optional[int] = None):
         """w1 [H1, F], b1 [H1], w2 [H2, H1], b2 [H2], w3 [2, H2], b3 [2] (torch.nn.Linear layout).
-        ``layout``: FRAG16 (v_mfma_f32_16x16x4_f32, the default whenever F <= 63) or FRAG32 (v_mfma_f32_32x32x2_f32)."""
+        ``layout``: FRAG16 (v_mfma_f32_16x16x4_f32, exact fp32, the default whenever F <= 63), FRAG32
+        (v_mfma_f32_32x32x2_f32, exact fp32, any F) or BF16X3 (bf16 MFMA on head + tail halves of every operand:
+        probabilities within ~1e-5 of the fp32 forward, several times faster; F <= 63)."""
         self._lib = nat.load()
         w1, b1, w2, b2, w3, b3 = (torch.as_tensor(t, dtype=torch.float32).detach().cpu() for t in (w1, b1, w2, b2, w3, b3))
         H1, F = w1.shape
@@ -51,6 +53,9 @@ class FusedActor:
         S2 = int(self._lib.mdr_actor_steps2(self.layout, H1))
         if S1 < 0 or S2 < 0:
             raise ValueError("unknown layout %r" % (layout,))
+        if self.layout == BF16X3:
+            self._pack_bf16x3(w1, b1, w2, b2, w3, b3, S1, S2)
+            return
         lane = np.arange(64)
         kw = 4 if self.layout == FRAG16 else 2                                  # k per MFMA step
         bw = 16 if self.layout == FRAG16 else 32                                # rows per block
@@ -84,6 +89,40 @@ class FusedActor:
         assert self._wdiff.numel() == 128
         assert self._frag1.numel() == self._lib.mdr_actor_frag1_floats(self.layout, F)
         assert self._frag2.numel() == self._lib.mdr_actor_frag2_floats(self.layout, H1)
+        self._desc = MdrActor(C.sizeof(MdrActor), self.layout, F, H1, H2, 0, self._frag1.data_ptr(), self._frag2.data_ptr(),
+                              self._wdiff.data_ptr())
+
+    def _pack_bf16x3(self, w1, b1, w2, b2, w3, b3, S1, S2):
+        """MDR_ACTOR_BF16X3: every weight as a bf16 head + tail, fragments of 8 k-values per lane (include/mdr_policy.h)."""
+        F, H1, H2 = self.num_state, self.hidden1, self.hidden2
+        lane = np.arange(64)
+        r, g = lane & 15, lane >> 4
+        j = np.arange(8)
+        rows = 16 * np.arange(8)[:, None] + r[None, :]                          # [mb, lane]
+        w1e = torch.zeros((128, 32 * S1))
+        w1e[:H1, :F], w1e[:H1, F], w1e[H1, F] = w1, b1, 1.0
+        w2e = torch.zeros((128, 128))
+        w2e[:H2, :H1], w2e[:H2, H1], w2e[H2, H1] = w2, b2, 1.0
+        w3e = torch.zeros((2, 128))
+        w3e[:, :H2], w3e[:, H2] = w3, b3
+        k1 = (4 * np.arange(S1)[:, None, None] + g[None, :, None]) * 8 + j[None, None, :]                   # [s, lane, j]
+        k2 = 16 * (2 * np.arange(S2)[:, None, None] + (j >> 2)[None, None, :]) + 4 * g[None, :, None] + (j & 3)[None, None, :]
+
+        def frags(we, k):                                                       # -> [s, mb, 2, lane, j] bf16 bit patterns
+            kk = torch.from_numpy(np.minimum(k, we.shape[1] - 1))
+            vals = we[torch.from_numpy(rows)[None, :, :, None], kk[:, None, :, :]]              # [s, mb, lane, j]
+            vals = torch.where(torch.from_numpy(k < we.shape[1])[:, None, :, :], vals, torch.zeros(()))
+            head = vals.to(torch.bfloat16)
+            tail = (vals - head.float()).to(torch.bfloat16)
+            return torch.stack([head, tail], dim=2).contiguous()
+
+        reg = np.arange(4)
+        row3 = 16 * np.arange(8)[:, None, None] + 4 * np.arange(4)[None, None, :] + reg[None, :, None]       # [mb, reg, g]
+        self._frag1 = frags(w1e, k1).view(torch.int16).to(self.device)
+        self._frag2 = frags(w2e, k2).view(torch.int16).to(self.device)
+        self._wdiff = (w3e[0] - w3e[1])[torch.from_numpy(row3)].contiguous().to(self.device)
+        assert self._frag1.numel() * 2 == 4 * self._lib.mdr_actor_frag1_floats(self.layout, F)
+        assert self._frag2.numel() * 2 == 4 * self._lib.mdr_actor_frag2_floats(self.layout, H1)
         self._desc = MdrActor(C.sizeof(MdrActor), self.layout, F, H1, H2, 0, self._frag1.data_ptr(), self._frag2.data_ptr(),
                               self._wdiff.data_ptr())
 

@@ -43,6 +43,8 @@ def main():
         planes = env.obs_vector("planes")
         stages["obs_vector_planes"] = lambda: env.obs_vector("planes")
         stages["fused_actor_sample_planes"] = lambda: fused.sample(planes, 1, 2)
+        fusedbf = FusedActor.from_module(actor, layout=2)
+        stages["fused_actor_sample_bf16x3"] = lambda: fusedbf.sample(obs, 1, 2)
         fused32 = FusedActor.from_module(actor, layout=0)
         stages["fused_actor_sample_frag32"] = lambda: fused32.sample(obs, 1, 2)
         stages["sample"] = lambda: (torch.multinomial(probs, 1).squeeze(1), probs.gather(1, a[:, None]))
