@@ -53,10 +53,13 @@ typedef struct mdr_actor {
    * MDR_ACTOR_BF16X3 (S1 = ceil((F + 1) / 32), S2 = 4, r = lane & 15, g = lane >> 4, fragments of 8 bf16, t = 0 head / 1 tail):
    *   frag1[s][mb < 8][t][lane][j < 8] = split_t(W1e[16 mb + r][(4 s + g) 8 + j])
    *   frag2[s][mb < 8][t][lane][j < 8] = split_t(W2e[16 mb + r][16 (2 s + (j >> 2)) + 4 g + (j & 3)])
-   *   wdiff as MDR_ACTOR_FRAG16;  split_0(w) = bf16(w), split_1(w) = bf16(w - split_0(w)), round to nearest even */
+   *   split_0(w) = bf16(w), split_1(w) = bf16(w - split_0(w)), round to nearest even.  Here the biases are NOT folded into
+   *   W1e / W2e (no constant-1 column / row): they start the accumulators, and wdiff holds 388 floats:
+   *   wdiff[mb][reg][g] as MDR_ACTOR_FRAG16 | b1[mb < 8][g < 4][reg < 4] (row 16 mb + 4 g + reg, 0 past H1) | b2 likewise |
+   *   b3[0] - b3[1] | 3 x 0 */
   const void *frag1;
   const void *frag2;
-  const float *wdiff;  /* 128 floats */
+  const float *wdiff;  /* 128 floats (388 for MDR_ACTOR_BF16X3) */
 } mdr_actor_t;
 
 int64_t mdr_actor_steps1(int32_t layout, int32_t num_state);        /* S1 */

@@ -296,47 +296,62 @@ __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
   lo = uint4{l[0], l[1], l[2], l[3]};
 }
 
+constexpr int WAVESB = 12;   // 3 per SIMD: ~170 registers per lane (16 waves leave 128, which spills)
+
 template <int MB>
-__global__ __launch_bounds__(64 * WAVES16) void k_actor_sample_bf16(ActorArgs a) {
+__global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int S2B = (MB + 1) / 2;
   uint4* f1 = reinterpret_cast<uint4*>(lds);                    // [S1][8][2][64] fragments of 8 bf16 (8 row blocks stored, MB used)
   uint4* f2 = f1 + a.S1 * 1024;                                 // [S2B][8][2][64]
-  float* wd = reinterpret_cast<float*>(f2 + S2B * 1024);    // [8][4][4]
+  float* wd = reinterpret_cast<float*>(f2 + S2B * 1024);        // [8][4][4] head weights, then the biases (below)
   const int tid = threadIdx.x;
   const uint4* g1 = reinterpret_cast<const uint4*>(a.frag1);
   const uint4* g2 = reinterpret_cast<const uint4*>(a.frag2);
-  for (int i = tid; i < a.S1 * 1024; i += 64 * WAVES16) f1[i] = g1[i];
-  for (int i = tid; i < S2B * 1024; i += 64 * WAVES16) f2[i] = g2[i];
-  if (tid < 128) wd[tid] = a.wdiff[tid];
+  for (int i = tid; i < a.S1 * 1024; i += 64 * WAVESB) f1[i] = g1[i];
+  for (int i = tid; i < S2B * 1024; i += 64 * WAVESB) f2[i] = g2[i];
+  if (tid < 388) wd[tid] = a.wdiff[tid];   // wdiff[128] | b1[8][4 groups][4] | b2[8][4][4] | b3[0] - b3[1], pad
   __syncthreads();
 
   const int lane = tid & 63;
   const int r = lane & 15, g = lane >> 4;
-  const int64_t wave = (int64_t)blockIdx.x * WAVES16 + (tid >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * WAVES16;
+  const int64_t wave = (int64_t)blockIdx.x * WAVESB + (tid >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * WAVESB;
   const int64_t fstride = a.plane ? a.plane : 1;
-  float xr[16];                           // S1 <= 2 k-steps (F <= 63): 8 features per step
+  // Biases start the accumulators (the C operand) instead of riding as a constant-1 feature: no per-feature selects -
+  // features past F are read at the clamped index F - 1 and meet zero weights.
+  // (re-read from LDS every tile: 56 more live registers would not fit the 128 a 16-wave workgroup leaves per lane)
+  const f32x4* bias1 = reinterpret_cast<const f32x4*>(wd + 128) + g;   // [mb] at stride 4 vectors
+  const f32x4* bias2 = reinterpret_cast<const f32x4*>(wd + 256) + g;
+  const float bias3 = wd[384];
+  float xr[16];                           // S1 <= 2 k-steps (F <= 64): 8 features per step
   auto row_of = [&](int64_t t) {
     const int64_t agent = t * 16 + r;
     return a.obs + (agent < a.A ? agent : a.A - 1) * (a.plane ? 1 : (int64_t)a.F);
   };
   auto feature = [&](const float* x, int i) {   // i = 8 s + j
     const int k = ((i >> 3) * 4 + g) * 8 + (i & 7);
-    const float v = x[min(k, a.F - 1) * fstride];
-    return k < a.F ? v : (k == a.F ? 1.0f : 0.0f);
+    return x[min(k, a.F - 1) * fstride];
   };
   if (wave < a.ntiles) {
     const float* x = row_of(wave);
 #pragma unroll
     for (int i = 0; i < 16; ++i) xr[i] = feature(x, i < 8 * a.S1 ? i : 0);
   }
-  for (int64_t t = wave; t < a.ntiles; t += nwaves) {
+  // One Philox call serves four tiles: lane group g draws for the tile this wave reaches g iterations from now (the
+  // counter is that tile's agent index, so the draw stays a function of (seed, step, agent) alone).
+  uint32_t rnd = 0;
+  int it = 0;
+  for (int64_t t = wave; t < a.ntiles; t += nwaves, ++it) {
     const int64_t agent = t * 16 + r;
     const bool valid = agent < a.A;
+    if ((it & 3) == 0) {
+      const int64_t ag = (t + g * nwaves) * 16 + r;
+      rnd = philox4x32_10((uint32_t)ag, (uint32_t)((uint64_t)ag >> 32), a.step_lo, TAG_ACTION ^ a.step_hi, a.k0, a.k1).x;
+    }
     f32x4 acc[MB];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = bias1[mb * 4];
     // ---- layer 1
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -359,7 +374,7 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample_bf16(ActorArgs a)
     const float* xn = row_of(more ? t + nwaves : t);
     f32x4 out[MB];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) out[mb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int mb = 0; mb < MB; ++mb) out[mb] = bias2[mb * 4];
 #pragma unroll
     for (int s = 0; s < S2B; ++s) {
       if (more) {
@@ -395,11 +410,13 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample_bf16(ActorArgs a)
       for (int i = 0; i < 4; ++i) d = fmaf(wd[(mb * 4 + i) * 4 + g], relu(out[mb][i]), d);
     d += __shfl_xor(d, 16);
     d += __shfl_xor(d, 32);
-    const float p0 = 1.0f / (1.0f + expf(-d));
-    const float p1 = 1.0f / (1.0f + expf(d));
+    d += bias3;
+    const float e = expf(-d);                          // exp(l1 - l0); inf for d < -88: p0 = 0, p1 = 1
+    const float p0 = 1.0f / (1.0f + e);
+    const float p1 = e > 1e30f ? 1.0f : e * p0;
+    const uint32_t draw = (uint32_t)__shfl((int)rnd, r + 16 * (it & 3));   // the group that drew for this tile
     if (g == 0 && valid) {
-      const u32x4 rnd = philox4x32_10((uint32_t)agent, (uint32_t)((uint64_t)agent >> 32), a.step_lo, TAG_ACTION ^ a.step_hi, a.k0, a.k1);
-      const float u = ((float)(rnd.x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float u = ((float)(draw >> 8) + 0.5f) * (1.0f / 16777216.0f);
       const int act = u < p0 ? 0 : 1;
       a.action[agent] = (uint8_t)act;
       if (a.a_prob) a.a_prob[agent] = act ? p1 : p0;
@@ -468,12 +485,12 @@ int mdr_actor_sample(const mdr_actor_t* actor, const float* obs, int64_t obs_pla
   a.obs = obs; a.action = action; a.a_prob = a_prob; a.probs = probs;
   a.A = nb_agents;
   a.plane = obs_plane_stride;
-  const int tile = l16 ? 16 : 32, waves = l16 ? WAVES16 : WAVES;
+  const int tile = l16 ? 16 : 32, waves = lbf ? WAVESB : (l16 ? WAVES16 : WAVES);
   a.ntiles = (nb_agents + tile - 1) / tile;
   a.F = actor->num_state; a.S1 = steps1(layout, actor->num_state); a.S2 = steps2(layout, actor->hidden1);
   a.k0 = (uint32_t)(seed & 0xFFFFFFFFull); a.k1 = (uint32_t)(seed >> 32);
   a.step_lo = (uint32_t)(step & 0xFFFFFFFFull); a.step_hi = (uint32_t)(step >> 32);
-  const size_t lds_bytes = ((size_t)(a.S1 + a.S2) * floats_per_step(layout) + 128) * sizeof(float);
+  const size_t lds_bytes = ((size_t)(a.S1 + a.S2) * floats_per_step(layout) + 512) * sizeof(float);   // + head weights (and biases)
   if (lds_bytes > 160 * 1024) return MDR_ERR_UNSUPPORTED;   // num_state beyond ~190 with 100-unit layers
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;

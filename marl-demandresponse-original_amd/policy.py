@@ -99,12 +99,15 @@ class FusedActor:
         r, g = lane & 15, lane >> 4
         j = np.arange(8)
         rows = 16 * np.arange(8)[:, None] + r[None, :]                          # [mb, lane]
+        # biases start the accumulators in this layout: plain zero-padded matrices, no constant-1 feature / unit
         w1e = torch.zeros((128, 32 * S1))
-        w1e[:H1, :F], w1e[:H1, F], w1e[H1, F] = w1, b1, 1.0
+        w1e[:H1, :F] = w1
         w2e = torch.zeros((128, 128))
-        w2e[:H2, :H1], w2e[:H2, H1], w2e[H2, H1] = w2, b2, 1.0
+        w2e[:H2, :H1] = w2
         w3e = torch.zeros((2, 128))
-        w3e[:, :H2], w3e[:, H2] = w3, b3
+        w3e[:, :H2] = w3
+        b1e, b2e = torch.zeros(128), torch.zeros(128)
+        b1e[:H1], b2e[:H2] = b1, b2
         k1 = (4 * np.arange(S1)[:, None, None] + g[None, :, None]) * 8 + j[None, None, :]                   # [s, lane, j]
         k2 = 16 * (2 * np.arange(S2)[:, None, None] + (j >> 2)[None, None, :]) + 4 * g[None, :, None] + (j & 3)[None, None, :]
 
@@ -120,7 +123,12 @@ class FusedActor:
         row3 = 16 * np.arange(8)[:, None, None] + 4 * np.arange(4)[None, None, :] + reg[None, :, None]       # [mb, reg, g]
         self._frag1 = frags(w1e, k1).view(torch.int16).to(self.device)
         self._frag2 = frags(w2e, k2).view(torch.int16).to(self.device)
-        self._wdiff = (w3e[0] - w3e[1])[torch.from_numpy(row3)].contiguous().to(self.device)
+        rowb = 16 * np.arange(8)[:, None, None] + 4 * np.arange(4)[None, :, None] + reg[None, None, :]       # [mb, g, reg]
+        tail = torch.zeros(4)
+        tail[0] = b3[0] - b3[1]
+        self._wdiff = torch.cat([(w3e[0] - w3e[1])[torch.from_numpy(row3)].reshape(-1), b1e[torch.from_numpy(rowb)].reshape(-1),
+                                 b2e[torch.from_numpy(rowb)].reshape(-1), tail]).contiguous().to(self.device)
+        assert self._wdiff.numel() == 388
         assert self._frag1.numel() * 2 == 4 * self._lib.mdr_actor_frag1_floats(self.layout, F)
         assert self._frag2.numel() * 2 == 4 * self._lib.mdr_actor_frag2_floats(self.layout, H1)
         self._desc = MdrActor(C.sizeof(MdrActor), self.layout, F, H1, H2, 0, self._frag1.data_ptr(), self._frag2.data_ptr(),

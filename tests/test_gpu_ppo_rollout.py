@@ -105,3 +105,19 @@ def test_collect_rollout_with_the_fused_policy_kernel():
         actor.fc[2].bias.add_(1.0)
     collect_ppo_rollout(_env(E, N), actor, 2, seed=5)
     assert actor._mdr_fused[1] is not packed
+
+
+def test_collect_rollout_bf16x3_policy_stays_close_to_the_fp32_actor():
+    from mdr_amd.rollout import ActorMLP, collect_ppo_rollout
+    E, N, T = 64, 50, 6
+    env = _env(E, N)
+    F = env.obs_vector_length()
+    torch.manual_seed(4)
+    actor = ActorMLP(F).cuda()
+    ro = collect_ppo_rollout(env, actor, T, seed=9, policy_precision="bf16x3")
+    for t in range(T):
+        p = actor(ro["state"][t]).gather(1, ro["action"][t][:, None]).squeeze(1)
+        torch.testing.assert_close(ro["a_prob"][t], p, rtol=1e-3, atol=2e-5)
+        assert float((ro["a_prob"][t] - p).abs().mean()) < 5e-6
+    with pytest.raises(ValueError):
+        collect_ppo_rollout(_env(E, N), actor, 2, policy_precision="fp8")

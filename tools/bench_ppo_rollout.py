@@ -63,19 +63,20 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 out[name + "_us"] = round(e0.elapsed_time(e1) / args.steps * 1e3, 1)
-            for key, use_fused in (("torch", False), ("fused", True)):
+            for key, use_fused, prec in (("torch", False, "fp32"), ("fused", True, "fp32"), ("fused_bf16x3", True, "bf16x3")):
                 for _ in range(2):
-                    collect_ppo_rollout(env, actor, 4, store_states=False, fused=use_fused)
+                    collect_ppo_rollout(env, actor, 4, store_states=False, fused=use_fused, policy_precision=prec)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 torch.cuda.synchronize()
                 e0.record()
-                collect_ppo_rollout(env, actor, args.steps, store_states=False, fused=use_fused)
+                collect_ppo_rollout(env, actor, args.steps, store_states=False, fused=use_fused, policy_precision=prec)
                 e1.record()
                 torch.cuda.synchronize()
                 out["rollout_step_us_" + key] = round(e0.elapsed_time(e1) / args.steps * 1e3, 1)
                 out["agent_steps_per_s_" + key] = round(E * N / (out["rollout_step_us_" + key] * 1e-6))
             flops = 2.0 * (F_len * 100 + 100 * 100 + 100 * 2) * E * N
             out["fused_actor_TFLOPs"] = round(flops / (out["fused_actor_sample_us"] * 1e-6) / 1e12, 1)
+            out["fused_actor_bf16x3_TFLOPs_fp32_equivalent"] = round(flops / (out["fused_actor_sample_bf16x3_us"] * 1e-6) / 1e12, 1)
         print(json.dumps(out), flush=True)
         del env, actor, obs, probs
         torch.cuda.empty_cache()
