@@ -27,10 +27,10 @@ extern "C" {
 enum mdr_actor_layout {
   MDR_ACTOR_FRAG32 = 0, /* v_mfma_f32_32x32x2_f32: 32 agents per wavefront, any num_state that fits the LDS */
   MDR_ACTOR_FRAG16 = 1, /* v_mfma_f32_16x16x4_f32: 16 agents per wavefront, hidden units padded to 112 instead of 128 rows and a
-                           quarter of the accumulator registers; num_state <= 63 */
+                           quarter of the accumulator registers; num_state <= 64 */
   MDR_ACTOR_BF16X3 = 2  /* v_mfma_f32_16x16x32_bf16 on operands split into bf16 head + tail (x = xh + xl): w x ~ wh xh + wl xh +
                            wh xl, fp32 accumulation - 16 significand bits per operand instead of 24 (probabilities within ~1e-5
-                           of the fp32 forward) at 16 / 3 times the fp32 matrix rate; num_state <= 63.  frag1 / frag2 hold bf16 */
+                           of the fp32 forward) at 16 / 3 times the fp32 matrix rate; num_state <= 64.  frag1 / frag2 hold bf16 */
 };
 
 typedef struct mdr_actor {
@@ -40,26 +40,24 @@ typedef struct mdr_actor {
   int32_t hidden1;     /* units of hidden layer 1 (<= MDR_ACTOR_MAX_HIDDEN) */
   int32_t hidden2;     /* units of hidden layer 2 (<= MDR_ACTOR_MAX_HIDDEN) */
   int32_t reserved0;
-  /* device, float32, MFMA fragment order, with the bias-extended zero-padded matrices
-   *   W1e = [[W1 b1] [0 1]] (128 rows),  W2e = [[W2 b2] [0 1]] (128 x 128),  W3e = [W3 b3]:
-   * MDR_ACTOR_FRAG32 (S1 = ceil((F + 1) / 2), S2 = mdr_actor_steps2, r = lane & 31, h = lane >> 5):
+  /* device, MFMA fragment order.  W1z / W2z / W3z: the weight matrices zero-padded to 128 rows / columns.
+   * MDR_ACTOR_FRAG32 (S1 = ceil((F + 1) / 2), S2 = mdr_actor_steps2, r = lane & 31, h = lane >> 5) carries the biases as a
+   * constant-1 input feature / hidden unit:  W1e = [[W1 b1] [0 1]],  W2e = [[W2 b2] [0 1]],  W3e = [W3 b3]:
    *   frag1[s][lane][mb < 4]  = W1e[32 mb + r][h S1 + s]
    *   frag2[q][lane][mb < 4]  = W2e[32 mb + r][k2],  k2 = 32 (q >> 4) + (q & 3) + 8 ((q >> 2) & 3) + 4 h  (the accumulator row the lane holds)
-   *   wdiff[mb < 4][reg < 16][h] = W3e[0][row] - W3e[1][row],  row = 32 mb + (reg & 3) + 8 (reg >> 2) + 4 h
-   * MDR_ACTOR_FRAG16 (S1 = ceil((F + 1) / 4), S2 = 4 ceil((H1 + 1) / 16), r = lane & 15, g = lane >> 4):
-   *   frag1[s][lane][mb < 8]  = W1e[16 mb + r][g S1 + s]
-   *   frag2[q][lane][mb < 8]  = W2e[16 mb + r][16 (q >> 2) + 4 g + (q & 3)]
-   *   wdiff[mb < 8][reg < 4][g]  = W3e[0][row] - W3e[1][row],  row = 16 mb + 4 g + reg
-   * MDR_ACTOR_BF16X3 (S1 = ceil((F + 1) / 32), S2 = 4, r = lane & 15, g = lane >> 4, fragments of 8 bf16, t = 0 head / 1 tail):
-   *   frag1[s][mb < 8][t][lane][j < 8] = split_t(W1e[16 mb + r][(4 s + g) 8 + j])
-   *   frag2[s][mb < 8][t][lane][j < 8] = split_t(W2e[16 mb + r][16 (2 s + (j >> 2)) + 4 g + (j & 3)])
-   *   split_0(w) = bf16(w), split_1(w) = bf16(w - split_0(w)), round to nearest even.  Here the biases are NOT folded into
-   *   W1e / W2e (no constant-1 column / row): they start the accumulators, and wdiff holds 388 floats:
-   *   wdiff[mb][reg][g] as MDR_ACTOR_FRAG16 | b1[mb < 8][g < 4][reg < 4] (row 16 mb + 4 g + reg, 0 past H1) | b2 likewise |
-   *   b3[0] - b3[1] | 3 x 0 */
+   *   wdiff[mb < 4][reg < 16][h] = W3e[0][row] - W3e[1][row],  row = 32 mb + (reg & 3) + 8 (reg >> 2) + 4 h      (128 floats)
+   * MDR_ACTOR_FRAG16 (S1 = ceil(F / 4), S2 = 4 ceil(H1 / 16), r = lane & 15, g = lane >> 4); the biases start the accumulators:
+   *   frag1[s][lane][mb < 8]  = W1z[16 mb + r][g S1 + s]
+   *   frag2[q][lane][mb < 8]  = W2z[16 mb + r][16 (q >> 2) + 4 g + (q & 3)]
+   *   wdiff (388 floats) = d[mb < 8][reg < 4][g < 4] | b1[mb][g][reg] | b2[mb][g][reg] | b3[0] - b3[1] | 0 0 0,
+   *                        d = W3z[0][row] - W3z[1][row],  b1 / b2 at row (0 past H),  row = 16 mb + 4 g + reg
+   * MDR_ACTOR_BF16X3 (S1 = ceil(F / 32), S2 = 4, r = lane & 15, g = lane >> 4, fragments of 8 bf16, t = 0 head / 1 tail):
+   *   frag1[s][mb < 8][t][lane][j < 8] = split_t(W1z[16 mb + r][(4 s + g) 8 + j])
+   *   frag2[s][mb < 8][t][lane][j < 8] = split_t(W2z[16 mb + r][16 (2 s + (j >> 2)) + 4 g + (j & 3)])
+   *   wdiff as MDR_ACTOR_FRAG16;  split_0(w) = bf16(w), split_1(w) = bf16(w - split_0(w)), round to nearest even */
   const void *frag1;
   const void *frag2;
-  const float *wdiff;  /* 128 floats (388 for MDR_ACTOR_BF16X3) */
+  const float *wdiff;  /* 128 floats (FRAG32) or 388 */
 } mdr_actor_t;
 
 int64_t mdr_actor_steps1(int32_t layout, int32_t num_state);        /* S1 */

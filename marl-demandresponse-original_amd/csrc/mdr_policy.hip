@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
   const int tid = threadIdx.x;
   for (int i = tid * 4; i < a.S1 * 512; i += 64 * WAVES16 * 4) *reinterpret_cast<float4*>(f1 + i) = *reinterpret_cast<const float4*>(a.frag1 + i);
   for (int i = tid * 4; i < a.S2 * 512; i += 64 * WAVES16 * 4) *reinterpret_cast<float4*>(f2 + i) = *reinterpret_cast<const float4*>(a.frag2 + i);
-  if (tid < 128) wd[tid] = a.wdiff[tid];
+  if (tid < 388) wd[tid] = a.wdiff[tid];   // wdiff[128] | b1[8][4 groups][4] | b2[8][4][4] | b3[0] - b3[1], pad
   __syncthreads();
 
   const int lane = tid & 63;
@@ -193,28 +193,37 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
   const int64_t wave = (int64_t)blockIdx.x * WAVES16 + (tid >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * WAVES16;
   const int kbase = g * a.S1;            // this lane group's input features: [kbase, kbase + S1)
+  // Biases start the accumulators (the C operand) instead of riding as a constant-1 feature: no per-feature selects -
+  // features past F are read at the clamped index F - 1 and meet zero weights.
+  const f32x4* bias1 = reinterpret_cast<const f32x4*>(wd + 128) + g;   // [mb] at stride 4 vectors
+  const f32x4* bias2 = reinterpret_cast<const f32x4*>(wd + 256) + g;
+  const float bias3 = wd[384];
   float xr[16];
   const int64_t fstride = a.plane ? a.plane : 1;   // distance between two features of one agent
   auto row_of = [&](int64_t t) {
     const int64_t agent = t * 16 + r;
     return a.obs + (agent < a.A ? agent : a.A - 1) * (a.plane ? 1 : (int64_t)a.F);
   };
-  auto feature = [&](const float* x, int s) {
-    const int k = kbase + s;
-    const float v = x[min(k, a.F - 1) * fstride];
-    return k < a.F ? v : (k == a.F ? 1.0f : 0.0f);
-  };
+  auto feature = [&](const float* x, int s) { return x[min(kbase + s, a.F - 1) * fstride]; };
   if (wave < a.ntiles) {
     const float* x = row_of(wave);
 #pragma unroll
     for (int s = 0; s < 16; ++s) xr[s] = feature(x, s < a.S1 ? s : 0);
   }
-  for (int64_t t = wave; t < a.ntiles; t += nwaves) {
+  // One Philox call serves four tiles: lane group g draws for the tile this wave reaches g iterations from now (the
+  // counter is that tile's agent index, so the draw stays a function of (seed, step, agent) alone).
+  uint32_t rnd = 0;
+  int it = 0;
+  for (int64_t t = wave; t < a.ntiles; t += nwaves, ++it) {
     const int64_t agent = t * 16 + r;
     const bool valid = agent < a.A;
+    if ((it & 3) == 0) {
+      const int64_t ag = (t + g * nwaves) * 16 + r;
+      rnd = philox4x32_10((uint32_t)ag, (uint32_t)((uint64_t)ag >> 32), a.step_lo, TAG_ACTION ^ a.step_hi, a.k0, a.k1).x;
+    }
     f32x4 acc[MB];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = bias1[mb * 4];
     // ---- layer 1
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
     const float* xn = row_of(more ? t + nwaves : t);
     f32x4 out[MB];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) out[mb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int mb = 0; mb < MB; ++mb) out[mb] = bias2[mb * 4];
 #pragma unroll
     for (int q = 0; q < 4 * MB; ++q) {
       if (q < 16 && q < a.S1 && more) xr[q < 16 ? q : 0] = feature(xn, q);
@@ -252,11 +261,13 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
       for (int i = 0; i < 4; ++i) d = fmaf(wd[(mb * 4 + i) * 4 + g], relu(out[mb][i]), d);
     d += __shfl_xor(d, 16);
     d += __shfl_xor(d, 32);
-    const float p0 = 1.0f / (1.0f + expf(-d));
-    const float p1 = 1.0f / (1.0f + expf(d));
+    d += bias3;
+    const float e = expf(-d);                          // exp(l1 - l0); inf for d < -88: p0 = 0, p1 = 1
+    const float p0 = 1.0f / (1.0f + e);
+    const float p1 = e > 1e30f ? 1.0f : e * p0;
+    const uint32_t draw = (uint32_t)__shfl((int)rnd, r + 16 * (it & 3));   // the group that drew for this tile
     if (g == 0 && valid) {
-      const u32x4 rnd = philox4x32_10((uint32_t)agent, (uint32_t)((uint64_t)agent >> 32), a.step_lo, TAG_ACTION ^ a.step_hi, a.k0, a.k1);
-      const float u = ((float)(rnd.x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float u = ((float)(draw >> 8) + 0.5f) * (1.0f / 16777216.0f);
       const int act = u < p0 ? 0 : 1;
       a.action[agent] = (uint8_t)act;
       if (a.a_prob) a.a_prob[agent] = act ? p1 : p0;
@@ -431,16 +442,16 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) 
 int acc_row_half0(int q) { return 32 * (q >> 4) + (q & 3) + 8 * ((q >> 2) & 3); }
 
 // layout MDR_ACTOR_FRAG32: ceil((F + 1) / 2) k-steps of 2; MDR_ACTOR_FRAG16: ceil((F + 1) / 4) k-steps of 4
-int blocks16(int h1, int h2) { return ((h1 > h2 ? h1 : h2) + 1 <= 112) ? 7 : 8; }   // 16-row blocks holding the hidden units + the constant
+int blocks16(int h1, int h2) { return ((h1 > h2 ? h1 : h2) <= 112) ? 7 : 8; }   // 16-row blocks holding the hidden units
 
 int steps1(int layout, int num_state) {
-  if (layout == MDR_ACTOR_BF16X3) return (num_state + 32) / 32;   // ceil((F + 1) / 32)
-  return layout == MDR_ACTOR_FRAG16 ? (num_state + 4) / 4 : (num_state + 2) / 2;
+  if (layout == MDR_ACTOR_BF16X3) return (num_state + 31) / 32;   // ceil(F / 32)
+  return layout == MDR_ACTOR_FRAG16 ? (num_state + 3) / 4 : (num_state + 2) / 2;   // FRAG16: no constant-1 feature
 }
 
 int steps2(int layout, int hidden1) {
   if (layout == MDR_ACTOR_BF16X3) return 4;                           // k-steps of two 16-row blocks each: all 8 stored blocks
-  if (layout == MDR_ACTOR_FRAG16) return 4 * ((hidden1 + 16) / 16);   // every register of the 16-row blocks holding rows <= hidden1
+  if (layout == MDR_ACTOR_FRAG16) return 4 * ((hidden1 + 15) / 16);   // every register of the 16-row blocks holding rows < hidden1
   int n = 0;                                                             // FRAG32: (block, register) pairs whose half-0 row is <= hidden1
   for (int q = 0; q < 64; ++q)
     if (acc_row_half0(q) <= hidden1) ++n;
@@ -479,7 +490,7 @@ int mdr_actor_sample(const mdr_actor_t* actor, const float* obs, int64_t obs_pla
   const int layout = actor->layout;
   const bool lbf = layout == MDR_ACTOR_BF16X3;
   const bool l16 = layout == MDR_ACTOR_FRAG16 || lbf;             // 16 agents per wavefront
-  if (l16 && actor->num_state > 63) return MDR_ERR_UNSUPPORTED;   // 16 features per lane (incl. the constant 1): pack FRAG32 instead
+  if (l16 && actor->num_state > 64) return MDR_ERR_UNSUPPORTED;   // 16 features per lane: pack FRAG32 instead
   ActorArgs a{};
   a.frag1 = static_cast<const float*>(actor->frag1); a.frag2 = static_cast<const float*>(actor->frag2); a.wdiff = actor->wdiff;
   a.obs = obs; a.action = action; a.a_prob = a_prob; a.probs = probs;

@@ -45,7 +45,7 @@ class FusedActor:
         if H1 > MAX_HIDDEN or H2 > MAX_HIDDEN:
             raise ValueError("hidden layers of at most %d units" % MAX_HIDDEN)
         if layout is None:
-            layout = FRAG16 if F <= 63 else FRAG32
+            layout = FRAG16 if F <= 64 else FRAG32
         self.layout = int(layout)
         self.num_state, self.hidden1, self.hidden2 = int(F), int(H1), int(H2)
         self.device = torch.device(device)
@@ -64,11 +64,13 @@ class FusedActor:
         rows = bw * np.arange(nb)[:, None] + r[None, :]                         # [mb, lane] output row of the fragment
         # bias-extended, zero-padded matrices: input feature F / hidden unit H is the constant 1
         w1e = torch.zeros((128, kw * S1))
-        w1e[:H1, :F], w1e[:H1, F], w1e[H1, F] = w1, b1, 1.0
         w2e = torch.zeros((128, 128))
-        w2e[:H2, :H1], w2e[:H2, H1], w2e[H2, H1] = w2, b2, 1.0
         w3e = torch.zeros((2, 128))
-        w3e[:, :H2], w3e[:, H2] = w3, b3
+        w1e[:H1, :F], w2e[:H2, :H1], w3e[:, :H2] = w1, w2, w3
+        if self.layout == FRAG32:      # biases as a constant-1 input feature / hidden unit
+            w1e[:H1, F], w1e[H1, F] = b1, 1.0
+            w2e[:H2, H1], w2e[H2, H1] = b2, 1.0
+            w3e[:, H2] = b3
         k1 = g[None, :] * S1 + np.arange(S1)[:, None]                           # [s, lane]
         q = np.arange(S2)
         if self.layout == FRAG16:
@@ -82,15 +84,26 @@ class FusedActor:
         k2 = np.minimum(k2, 127)
         frag1 = w1e[torch.from_numpy(rows)[None, :, :], torch.from_numpy(k1)[:, None, :]].permute(0, 2, 1)   # [S1, 64, nb]
         frag2 = w2e[torch.from_numpy(rows)[None, :, :], torch.from_numpy(k2)[:, None, :]].permute(0, 2, 1)   # [S2, 64, nb]
-        wdiff = (w3e[0] - w3e[1])[torch.from_numpy(row3)]
+        wdiff = (w3e[0] - w3e[1])[torch.from_numpy(row3)].reshape(-1)
+        if self.layout == FRAG16:      # biases start the accumulators: appended behind the head weights
+            wdiff = torch.cat([wdiff, self._bias_block(b1, b2, b3)])
         self._frag1 = frag1.contiguous().to(self.device)
         self._frag2 = frag2.contiguous().to(self.device)
         self._wdiff = wdiff.contiguous().to(self.device)
-        assert self._wdiff.numel() == 128
+        assert self._wdiff.numel() == (128 if self.layout == FRAG32 else 388)
         assert self._frag1.numel() == self._lib.mdr_actor_frag1_floats(self.layout, F)
         assert self._frag2.numel() == self._lib.mdr_actor_frag2_floats(self.layout, H1)
         self._desc = MdrActor(C.sizeof(MdrActor), self.layout, F, H1, H2, 0, self._frag1.data_ptr(), self._frag2.data_ptr(),
                               self._wdiff.data_ptr())
+
+    def _bias_block(self, b1, b2, b3) -> torch.Tensor:
+        """b1[mb][g][reg] | b2[mb][g][reg] | b3[0] - b3[1] | 0 0 0  (row = 16 mb + 4 g + reg), 260 floats."""
+        b1e, b2e = torch.zeros(128), torch.zeros(128)
+        b1e[:self.hidden1], b2e[:self.hidden2] = b1, b2
+        rowb = torch.from_numpy(16 * np.arange(8)[:, None, None] + 4 * np.arange(4)[None, :, None] + np.arange(4)[None, None, :])
+        tail = torch.zeros(4)
+        tail[0] = b3[0] - b3[1]
+        return torch.cat([b1e[rowb].reshape(-1), b2e[rowb].reshape(-1), tail])
 
     def _pack_bf16x3(self, w1, b1, w2, b2, w3, b3, S1, S2):
         """MDR_ACTOR_BF16X3: every weight as a bf16 head + tail, fragments of 8 k-values per lane (include/mdr_policy.h)."""
@@ -106,8 +119,6 @@ class FusedActor:
         w2e[:H2, :H1] = w2
         w3e = torch.zeros((2, 128))
         w3e[:, :H2] = w3
-        b1e, b2e = torch.zeros(128), torch.zeros(128)
-        b1e[:H1], b2e[:H2] = b1, b2
         k1 = (4 * np.arange(S1)[:, None, None] + g[None, :, None]) * 8 + j[None, None, :]                   # [s, lane, j]
         k2 = 16 * (2 * np.arange(S2)[:, None, None] + (j >> 2)[None, None, :]) + 4 * g[None, :, None] + (j & 3)[None, None, :]
 
@@ -123,11 +134,8 @@ class FusedActor:
         row3 = 16 * np.arange(8)[:, None, None] + 4 * np.arange(4)[None, None, :] + reg[None, :, None]       # [mb, reg, g]
         self._frag1 = frags(w1e, k1).view(torch.int16).to(self.device)
         self._frag2 = frags(w2e, k2).view(torch.int16).to(self.device)
-        rowb = 16 * np.arange(8)[:, None, None] + 4 * np.arange(4)[None, :, None] + reg[None, None, :]       # [mb, g, reg]
-        tail = torch.zeros(4)
-        tail[0] = b3[0] - b3[1]
-        self._wdiff = torch.cat([(w3e[0] - w3e[1])[torch.from_numpy(row3)].reshape(-1), b1e[torch.from_numpy(rowb)].reshape(-1),
-                                 b2e[torch.from_numpy(rowb)].reshape(-1), tail]).contiguous().to(self.device)
+        self._wdiff = torch.cat([(w3e[0] - w3e[1])[torch.from_numpy(row3)].reshape(-1),
+                                 self._bias_block(b1, b2, b3)]).contiguous().to(self.device)
         assert self._wdiff.numel() == 388
         assert self._frag1.numel() * 2 == 4 * self._lib.mdr_actor_frag1_floats(self.layout, F)
         assert self._frag2.numel() * 2 == 4 * self._lib.mdr_actor_frag2_floats(self.layout, H1)

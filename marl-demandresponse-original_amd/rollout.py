@@ -60,7 +60,7 @@ def _fused_policy(actor, dev, precision: str = "fp32"):
     key = tuple((p.data_ptr(), p._version) for p in actor.parameters()) + (str(dev), precision)
     cached = getattr(actor, "_mdr_fused", None)
     if cached is None or cached[0] != key:
-        layout = BF16X3 if precision == "bf16x3" and actor.fc[0].in_features <= 63 else None
+        layout = BF16X3 if precision == "bf16x3" and actor.fc[0].in_features <= 64 else None
         cached = (key, FusedActor.from_module(actor, device=dev, layout=layout))
         actor._mdr_fused = cached
     return cached[1]

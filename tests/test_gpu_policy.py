@@ -27,7 +27,7 @@ def _actor(F, layers, seed=0, scale=1.0):
 @pytest.mark.parametrize("layout", [0, 1, 2])
 def test_fused_actor_matches_torch_forward(A, F, layers, layout):
     from mdr_amd.policy import FusedActor
-    if layout >= 1 and F > 63:
+    if layout >= 1 and F > 64:
         with pytest.raises(RuntimeError):
             FusedActor.from_module(_actor(F, layers), layout=1).sample(torch.zeros((4, F), device="cuda:0"), 0, 0)
         return
