@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MDR_ABI_VERSION 1
+#define MDR_ABI_VERSION 2
 #define MDR_MAX_SINUSOIDS 8
 #define MDR_MAX_CAPACITIES 16
 #define MDR_OBS_COLUMNS 7
@@ -150,6 +150,11 @@ typedef struct mdr_buffers {
   /* scratch for the split (multi-workgroup per env) path: [E][mdr_partials_per_env()][3] */
   double *partials;
   double *base_power;              /* [E] PowerGrid.base_power (written in interpolation mode) */
+  /* Optional (NULL = off): graph mode.  int32 [2] = {table row, time index} kept on the device: the step and observation
+   * kernels then take their table rows from it instead of from launch arguments, and every step ends with a one-thread
+   * launch that advances it - so a captured mdr_env_step / mdr_env_obs_vector (hipGraph, torch.cuda.CUDAGraph) keeps walking
+   * through the episode when it is replayed.  See mdr_env_graph_room / mdr_env_graph_replayed. */
+  int32_t *cursor;
 } mdr_buffers_t;
 
 /* Raw episode parameters for mdr_env_load_episode (replay of an episode sampled elsewhere).
@@ -311,6 +316,17 @@ int mdr_env_obs_vector_ext(mdr_env_t *env, const mdr_obs_spec_t *spec, const flo
 
 /* Cursor: k = number of steps taken this episode (env.datetime == start_datetime + k * time_step, env 189);
  * j0 = time index of table row 0. */
+/* Graph mode (mdr_buffers_t.cursor bound).  The launch-bound regime - a policy in the loop on small batches, where a step is
+ * six short kernels - is served by capturing ONE step (observation, policy, mdr_env_step) into a graph and replaying it.
+ * The host does not run during a replay, so it is told afterwards:
+ *   mdr_env_graph_room      how many steps the time tables still cover (replays allowed before the next host-side refill /
+ *                           interpolatePower update); capture needs room >= 1;
+ *   mdr_env_graph_replayed  `n` steps were replayed: the host cursor catches up, refills the tables and runs a due
+ *                           interpolation update (launches on `stream`, outside any capture).
+ * Ordinary (non-captured) calls keep working in graph mode; each step then costs one extra one-thread launch. */
+int64_t mdr_env_graph_room(const mdr_env_t *env);
+int mdr_env_graph_replayed(mdr_env_t *env, int64_t n, void *stream);
+
 int mdr_env_cursor(const mdr_env_t *env, int64_t *k, int64_t *j0);
 /* Re-create a cursor on a new handle whose buffers were cloned from another env: copy.deepcopy(env) as
  * utils.test_*_agent use it (utils.py:890, 931, 970, 1008). */

@@ -70,9 +70,10 @@ int64_t mdr_actor_frag2_floats(int32_t layout, int32_t hidden1);    /* size of f
  * `obs`: observation rows [nb_agents][F] when obs_plane_stride == 0 (mdr_env_obs_vector MDR_OBS_ROWS), or feature planes
  * [F][obs_plane_stride] with obs_plane_stride >= nb_agents (MDR_OBS_PLANES: the lanes of a wavefront then read consecutive
  * floats instead of one cache line each).  `action` uint8 [nb_agents], `a_prob` float [nb_agents] (may be NULL), `probs`
- * float [nb_agents][2] (may be NULL).  Returns 0, or -1 (invalid argument) / -3 (HIP error) / -4 (shape without a kernel). */
+ * float [nb_agents][2] (may be NULL).  `step_dev` (device int32, may be NULL) is added to `step` on the device - point it at
+ * the time index of mdr_buffers_t.cursor ([1]) so that a captured launch draws fresh numbers at every replay.  Returns 0, or -1 (invalid argument) / -3 (HIP error) / -4 (shape without a kernel). */
 int mdr_actor_sample(const mdr_actor_t *actor, const float *obs, int64_t obs_plane_stride, int64_t nb_agents, uint64_t seed,
-                     uint64_t step, uint8_t *action, float *a_prob, float *probs, void *stream);
+                     uint64_t step, const int32_t *step_dev, uint8_t *action, float *a_prob, float *probs, void *stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDR_HIP_LIB") or os.path.join(HERE, "csrc", "libmdr_hip.so")   # MDR_HIP_LIB: experiment builds
 
-MDR_ABI_VERSION = 1
+MDR_ABI_VERSION = 2
 MDR_MAX_SINUSOIDS = 8
 MDR_MAX_CAPACITIES = 16
 MDR_OBS_COLUMNS = 7
@@ -68,7 +68,7 @@ class MdrBuffers(C.Structure):
         ("t0", _i64p), ("phase", _f64p), ("ratio", _f64p), ("max_power", _f64p),
         ("P", _f64p), ("tot_sum", _f64p), ("tot_max", _f64p),
         ("tab_od", _f32p), ("tab_solar", _f32p), ("tab_signal", _f64p),
-        ("partials", _f64p), ("base_power", _f64p),
+        ("partials", _f64p), ("base_power", _f64p), ("cursor", C.c_void_p),
     ]
 
 
@@ -126,7 +126,7 @@ EXPORTS = (
     "mdr_env_step_begin", "mdr_env_step_end", "mdr_env_step_end_gathered",
     "mdr_env_interp_due", "mdr_env_interp_local", "mdr_env_interp_apply", "mdr_obs_vector_length", "mdr_env_obs_vector",
     "mdr_obs_message_fields", "mdr_env_obs_messages", "mdr_env_obs_vector_ext",
-    "mdr_env_cursor", "mdr_env_set_cursor",
+    "mdr_env_graph_room", "mdr_env_graph_replayed", "mdr_env_cursor", "mdr_env_set_cursor",
     # include/mdr_policy.h
     "mdr_actor_steps1", "mdr_actor_steps2", "mdr_actor_frag1_floats", "mdr_actor_frag2_floats", "mdr_actor_sample",
 )
@@ -182,7 +182,9 @@ def load():
         "mdr_actor_steps2": (i64, [i32, i32]),
         "mdr_actor_frag1_floats": (i64, [i32, i32]),
         "mdr_actor_frag2_floats": (i64, [i32, i32]),
-        "mdr_actor_sample": (C.c_int, [vp, vp, i64, i64, u64, u64, vp, vp, vp, vp]),
+        "mdr_actor_sample": (C.c_int, [vp, vp, i64, i64, u64, u64, vp, vp, vp, vp, vp]),
+        "mdr_env_graph_room": (i64, [vp]),
+        "mdr_env_graph_replayed": (C.c_int, [vp, i64, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

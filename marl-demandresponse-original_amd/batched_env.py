@@ -43,7 +43,8 @@ class BatchedDemandResponseEnv:
     def __init__(self, config: dict, nb_envs: int = 1, device=None, seed: int = 0, test: bool = False,
                  table_steps: int = 64, env_offset: int = 0,
                  house_shard: Optional[Tuple[int, int]] = None, process_group=None,
-                 stagger_bytes: int = 2304, interp_grid=None, regenerate_missing_grid: bool = True):
+                 stagger_bytes: int = 2304, interp_grid=None, regenerate_missing_grid: bool = True,
+                 graph_mode: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedDemandResponseEnv needs a ROCm device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -66,6 +67,7 @@ class BatchedDemandResponseEnv:
         self._od_table = None
         self._regenerate_missing_grid = bool(regenerate_missing_grid)
         self._stagger = int(stagger_bytes)
+        self.graph_mode = bool(graph_mode)      # device-resident cursor: steps / observations can be captured in a graph
         self._handle = C.c_void_p()
         self._cfg = self._make_config()
         rc = self._lib.mdr_env_create(C.byref(self._cfg), C.byref(self._handle))
@@ -126,6 +128,7 @@ class BatchedDemandResponseEnv:
         items += [("tot", torch.float64, (3, E))]     # local aggregates as ONE block: tot_sum = tot[0:2], tot_max = tot[2]
         items += [("tab_od", torch.float32, (K1, E)), ("tab_solar", torch.float32, (K1, E)), ("tab_signal", torch.float64, (K1, E))]
         items += [("partials", torch.float64, (E, nblk, 3))]
+        items += [("cursor", torch.int32, (2,))]      # graph mode: {table row, time index} kept on the device
         return items
 
     def _allocate(self):
@@ -151,6 +154,8 @@ class BatchedDemandResponseEnv:
         for fname, _ in nat.MdrBuffers._fields_:
             if fname in ("struct_size", "reserved0"):
                 continue
+            if fname == "cursor" and not self.graph_mode:
+                continue                                    # NULL: launch arguments carry the table rows
             setattr(b, fname, self.t[fname].data_ptr())
         self._buffers = b
         nat.check(self._lib, self._handle, self._lib.mdr_env_bind(self._handle, C.byref(b)), "mdr_env_bind")
@@ -397,6 +402,23 @@ class BatchedDemandResponseEnv:
             nat.check(self._lib, self._handle, rc, "mdr_env_rollout_fused")
         return res
 
+    # ------------------------------------------------------------------ graph mode (device-resident cursor)
+    def graph_room(self) -> int:
+        """Steps the time tables still cover: how often a captured step may be replayed before ``graph_replayed``."""
+        return int(self._lib.mdr_env_graph_room(self._handle))
+
+    def graph_replayed(self, n: int) -> None:
+        """Tell the host side that a captured step was replayed ``n`` times (refills the tables, runs a due update)."""
+        with torch.cuda.device(self.device):
+            nat.check(self._lib, self._handle, self._lib.mdr_env_graph_replayed(self._handle, int(n), self._stream()), "mdr_env_graph_replayed")
+
+    @property
+    def device_time_index(self) -> torch.Tensor:
+        """int32 [1] view of the device cursor's time index (graph mode): what FusedActor.sample takes as ``step_dev``."""
+        if not self.graph_mode:
+            raise RuntimeError("graph_mode is off")
+        return self.t["cursor"][1:]
+
     # ------------------------------------------------------------------ full normStateDict vector
     def _obs_spec(self, layout: str, with_links: bool = True) -> nat.MdrObsSpec:
         from .comm import build_comm_links, nb_comm
@@ -600,7 +622,7 @@ class BatchedDemandResponseEnv:
                                          seed=self.seed, test=self.test, table_steps=self.table_steps,
                                          env_offset=self.env_offset,
                                          house_shard=(self.house_offset, self.nb_houses) if self.sharded else None,
-                                         process_group=self.process_group, stagger_bytes=self._stagger,
+                                         process_group=self.process_group, stagger_bytes=self._stagger, graph_mode=self.graph_mode,
                                          interp_grid=getattr(self, "_interp_grid_host", None))
         if self.episode >= 0:
             other.load_state_dict(self.state_dict())

@@ -17,6 +17,7 @@ struct mdr_env {
   bool has_tables = false;    // begin_episode done
   bool split_pending = false; // step_begin issued, step_end outstanding
   bool interp_due = false;    // sharded houses, interpolation mode: the base power of the current time index awaits its exchange
+  int64_t dev_row = -1, dev_k = -1;   // graph mode: what the device-resident cursor holds (as far as the host knows)
   uint64_t seed = 0;
   uint32_t episode = 0;
   int64_t k = 0;              // steps taken this episode
@@ -229,6 +230,37 @@ int refresh_interp(mdr_env* env, int64_t j, hipStream_t s) {
 
 bool interp_mode(const mdr_env* env) { return env->cfg.base_power_mode == 1; }
 bool sharded(const mdr_env* env) { return env->cfg.nb_houses_total != env->cfg.nb_houses; }
+bool graph_mode(const mdr_env* env) { return env->bound && env->buf.cursor != nullptr; }
+
+bool capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+
+// Graph mode: make the device cursor say (k - j0, k).  Never inside a capture - a captured reset would rewind every replay.
+int sync_cursor(mdr_env* env, hipStream_t s) {
+  if (!graph_mode(env)) return MDR_OK;
+  const int64_t row = env->k - env->j0;
+  if (env->dev_row == row && env->dev_k == env->k) return MDR_OK;
+  if (capturing(s)) return fail(env, MDR_ERR_INVALID, "graph mode: the device cursor is stale; make one un-captured call (or mdr_env_graph_replayed) before capturing");
+  hipError_t e = mdr::launch_cursor_set(env->buf.cursor, (int32_t)row, (int32_t)env->k, s);
+  if (e != hipSuccess) return hip_fail(env, e, "cursor_set");
+  env->dev_row = row;
+  env->dev_k = env->k;
+  return MDR_OK;
+}
+
+// Graph mode: the launch carries table row 0 / 1 and the kernels add the device cursor; then one thread advances it.
+void graph_rows(const mdr_env* env, mdr::StepArgs* a) {
+  const mdr_buffers_t& b = env->buf;
+  a->od_old = b.tab_od;
+  a->solar_new = b.tab_solar + env->cfg.nb_envs;
+  a->sig_old = b.tab_signal;
+  a->sig_new = b.tab_signal + env->cfg.nb_envs;
+  a->cursor = b.cursor;
+  a->cursor_max = env->cfg.table_steps - 1;
+}
+
 
 // Called after a step that brought the cursor onto an interpolation update: new base power, new tables from the
 // current time index, and the reg_signal observation plane of the step just taken re-written with the final signal.
@@ -247,6 +279,7 @@ int step_args(mdr_env* env, uint8_t* actions, int action_source, hipStream_t s, 
   if (actions && c.nb_houses % 2 == 0 && ((uintptr_t)actions & 1u) != 0)  // uchar2 accesses when N is even
     return fail(env, MDR_ERR_INVALID, "actions must be 2-byte aligned when nb_houses is even");
   if (env->k + 1 - env->j0 > c.table_steps) {
+    if (capturing(s)) return fail(env, MDR_ERR_INVALID, "the time tables end here: a refill cannot be captured (mdr_env_graph_room() is 0)");
     int rc = fill_tables(env, env->k, s);
     if (rc != MDR_OK) return rc;
   }
@@ -350,6 +383,7 @@ int mdr_env_bind(mdr_env_t* env, const mdr_buffers_t* buffers) {
   if (!msg.empty()) return fail(env, MDR_ERR_INVALID, msg);
   env->buf = *buffers;
   env->bound = true;
+  env->dev_row = env->dev_k = -1;
   env->err.clear();
   return MDR_OK;
 }
@@ -449,10 +483,49 @@ int mdr_env_step(mdr_env_t* env, uint8_t* actions, int action_source, void* stre
   mdr::StepArgs a;
   int rc = step_args(env, actions, action_source, (hipStream_t)stream, &a);
   if (rc != MDR_OK) return rc;
+  const bool graph = graph_mode(env);
+  if (graph) {
+    rc = sync_cursor(env, (hipStream_t)stream);
+    if (rc != MDR_OK) return rc;
+    graph_rows(env, &a);
+  }
+  const bool recording = graph && capturing((hipStream_t)stream);   // launches are recorded, not run: the host state must not move
   hipError_t e = mdr::launch_step(a, env->plan, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "step");
+  if (graph) {
+    e = mdr::launch_cursor_advance(env->buf.cursor, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(env, e, "cursor_advance");
+    if (recording) return MDR_OK;    // mdr_env_graph_replayed accounts for every replay (and runs a due interpolation update)
+    env->dev_row += 1;
+    env->dev_k += 1;
+  }
   env->k += 1;
   return interp_boundary(env, (hipStream_t)stream, nullptr);
+}
+
+int64_t mdr_env_graph_room(const mdr_env_t* env) {
+  if (!env || !env->bound || !env->has_tables) return 0;
+  int64_t room = env->cfg.table_steps - (env->k - env->j0);
+  if (interp_mode(env)) room = std::min<int64_t>(room, env->interp_steps - (env->k % env->interp_steps));
+  return room < 0 ? 0 : room;
+}
+
+int mdr_env_graph_replayed(mdr_env_t* env, int64_t n, void* stream) {
+  if (!env) return MDR_ERR_INVALID;
+  if (!graph_mode(env)) return fail(env, MDR_ERR_INVALID, "graph mode is off: bind mdr_buffers_t.cursor");
+  if (!env->has_tables) return fail(env, MDR_ERR_UNBOUND, "no episode: call reset/load_episode and begin_episode first");
+  if (n < 0 || n > mdr_env_graph_room(env)) return fail(env, MDR_ERR_INVALID, "more steps replayed than mdr_env_graph_room() allowed");
+  if (capturing((hipStream_t)stream)) return fail(env, MDR_ERR_INVALID, "mdr_env_graph_replayed inside a capture");
+  env->k += n;                       // the device advanced itself n times
+  env->dev_row += n;
+  env->dev_k += n;
+  int rc = interp_boundary(env, (hipStream_t)stream, nullptr);   // a due interpolatePower update (rebuilds the tables)
+  if (rc != MDR_OK) return rc;
+  if (env->k - env->j0 >= env->cfg.table_steps) {                // the tables are used up: refill from the current time index
+    rc = fill_tables(env, env->k, (hipStream_t)stream);
+    if (rc != MDR_OK) return rc;
+  }
+  return sync_cursor(env, (hipStream_t)stream);
 }
 
 int mdr_env_rollout(mdr_env_t* env, uint8_t* actions, int action_source, int32_t nb_steps, void* stream) {
@@ -608,6 +681,11 @@ static int obs_args(mdr_env_t* env, const mdr_obs_spec_t* spec, bool need_layout
   a.sig_now = b.tab_signal + row * c.nb_envs;
   a.od_now = b.tab_od + row * c.nb_envs;
   a.solar_now = b.tab_solar + row * c.nb_envs;
+  if (graph_mode(env)) {   // rows and time index from the device cursor (see mdr_buffers_t.cursor)
+    a.sig_now = b.tab_signal; a.od_now = b.tab_od; a.solar_now = b.tab_solar;
+    a.cursor = b.cursor;
+    a.cursor_max = c.table_steps - 1;
+  }
   a.t0 = b.t0;
   a.links = spec->random_links ? nullptr : spec->links;
   a.random_links = spec->random_links ? 1 : 0;
@@ -639,6 +717,7 @@ int mdr_env_obs_vector(mdr_env_t* env, const mdr_obs_spec_t* spec, float* out, v
     return fail(env, MDR_ERR_UNSUPPORTED, "sharded houses: mdr_env_obs_messages, halo exchange, mdr_env_obs_vector_ext");
   mdr::ObsArgs a;
   int rc = obs_args(env, spec, true, &a);
+  if (rc == MDR_OK) rc = sync_cursor(env, (hipStream_t)stream);
   if (rc != MDR_OK) return rc;
   a.out = out;
   hipError_t e = mdr::launch_obs_vector(a, spec->layout, (hipStream_t)stream);
@@ -655,6 +734,7 @@ int mdr_env_obs_messages(mdr_env_t* env, const mdr_obs_spec_t* spec, float* mess
   if (!env || !spec || !messages) return MDR_ERR_INVALID;
   mdr::ObsArgs a;
   int rc = obs_args(env, spec, false, &a);
+  if (rc == MDR_OK) rc = sync_cursor(env, (hipStream_t)stream);
   if (rc != MDR_OK) return rc;
   if (entries_per_env < env->cfg.nb_houses) return fail(env, MDR_ERR_INVALID, "entries_per_env smaller than nb_houses");
   a.msg_ext_out = messages;
@@ -669,6 +749,7 @@ int mdr_env_obs_vector_ext(mdr_env_t* env, const mdr_obs_spec_t* spec, const flo
   if (!env || !spec || !out) return MDR_ERR_INVALID;
   mdr::ObsArgs a;
   int rc = obs_args(env, spec, true, &a);
+  if (rc == MDR_OK) rc = sync_cursor(env, (hipStream_t)stream);
   if (rc != MDR_OK) return rc;
   if (spec->random_links) return fail(env, MDR_ERR_UNSUPPORTED, "random_sample links need every house's message: not available through record slots");
   if (spec->nb_comm > 0 && (!messages || !spec->links)) return fail(env, MDR_ERR_INVALID, "messages and a link table of record slots are required");

@@ -85,6 +85,10 @@ struct StepArgs {
   int world;
   const float *od_old, *solar_new;     // table rows for this step: OD temp at time index k-1, solar at k
   const double *sig_old, *sig_new;     // regulation signal at k-1 (reward) and k (observation)
+  // graph mode (mdr_buffers_t.cursor): the four pointers above address table row 0 / 1 and the kernels add cursor[0] rows,
+  // so that a captured launch keeps stepping through the tables when it is replayed; nullptr = host-computed rows
+  const int32_t* cursor;
+  int32_t cursor_max;                  // last valid row (table_steps - 1): a graph replayed too often re-reads it instead of running off the tables
   int64_t plane;                       // E * N: stride between observation planes
   int E, N, dt, penalty_mode, action_source, nblk;
   float c_temp;                        // alpha_temp / norm_temp_penalty
@@ -110,6 +114,8 @@ struct ObsArgs {
   int64_t plane;            // E * N
   int64_t out_plane;        // stride between output feature planes (>= plane)
   int64_t k;                // steps taken (time index)
+  const int32_t* cursor;    // graph mode: {table row, time index} on the device (sig_now / od_now / solar_now address row 0, k unused)
+  int32_t cursor_max;
   int E, N, c, F, dt;
   int f_hour, f_day, f_solar, f_thermal, f_hvac, m_thermal, m_hvac;
   int64_t env_offset, house_offset;
@@ -152,6 +158,8 @@ hipError_t launch_load(const EpisodeArgs& a, const mdr_episode_t& ep, hipStream_
 hipError_t launch_tables(const TableArgs& a, hipStream_t s);
 hipError_t launch_interp_base(const InterpArgs& a, hipStream_t s);
 hipError_t launch_patch_signal_plane(const StepArgs& a, hipStream_t s);   // obs plane 5 <- sig_old row
+hipError_t launch_cursor_advance(int32_t* cursor, hipStream_t s);                       // cursor[0] += 1, cursor[1] += 1
+hipError_t launch_cursor_set(int32_t* cursor, int32_t row, int32_t k, hipStream_t s);
 hipError_t launch_signal_error(const StepArgs& a, double* sq_signal_error_sum, hipStream_t s);   // += (sig_old - P)^2
 hipError_t launch_reset_obs(const StepArgs& a, hipStream_t s);  // uses sig_old = table row 0
 hipError_t launch_step(const StepArgs& a, const StepPlan& p, hipStream_t s);

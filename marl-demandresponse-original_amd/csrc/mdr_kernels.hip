@@ -291,6 +291,45 @@ __global__ __launch_bounds__(256) void k_fill_tables(TableArgs a) {
 // =================================================================================================
 // Step kernels
 // =================================================================================================
+// Graph mode: a captured launch carries the pointers of table row 0; the device-resident cursor says where the episode is.
+__device__ __forceinline__ void rebase(StepArgs& a) {
+  if (a.cursor == nullptr) return;
+  const int64_t off = (int64_t)min(a.cursor[0], a.cursor_max) * a.E;
+  a.od_old += off;
+  a.solar_new += off;
+  a.sig_old += off;
+  a.sig_new += off;
+}
+
+__device__ __forceinline__ void rebase(ObsArgs& a) {
+  if (a.cursor == nullptr) return;
+  const int64_t off = (int64_t)min(a.cursor[0], a.cursor_max + 1) * a.E;
+  a.sig_now += off;
+  a.od_now += off;
+  a.solar_now += off;
+  a.k = a.cursor[1];
+}
+
+__global__ void k_cursor_advance(int32_t* cursor) {
+  cursor[0] += 1;
+  cursor[1] += 1;
+}
+
+__global__ void k_cursor_set(int32_t* cursor, int32_t row, int32_t k) {
+  cursor[0] = row;
+  cursor[1] = k;
+}
+
+hipError_t launch_cursor_advance(int32_t* cursor, hipStream_t s) {
+  hipLaunchKernelGGL(k_cursor_advance, dim3(1), dim3(1), 0, s, cursor);
+  return hipGetLastError();
+}
+
+hipError_t launch_cursor_set(int32_t* cursor, int32_t row, int32_t k, hipStream_t s) {
+  hipLaunchKernelGGL(k_cursor_set, dim3(1), dim3(1), 0, s, cursor, row, k);
+  return hipGetLastError();
+}
+
 __device__ __forceinline__ float temp_penalty(const StepArgs& a, float pen, double sum_pen, float max_pen) {
   if (a.penalty_mode == MDR_PENALTY_INDIVIDUAL_L2) return pen;
   const float common = (float)(sum_pen * a.inv_n_total);
@@ -511,6 +550,7 @@ __device__ __forceinline__ void store_reward_power(const StepArgs& a, int64_t i,
 
 template <int VEC, int TILES, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_step_fused(StepArgs a) {
+  rebase(a);
   __shared__ double lds[3 * (THREADS / 64)];
   const int e = blockIdx.x;
   const float od_old = a.od_old[e];
@@ -725,6 +765,7 @@ __global__ __launch_bounds__(THREADS) void k_rollout_fused(StepArgs a, RolloutAr
 // 16 / 8 bytes wide for the agent counts the reference actually trains with (cli.py: 20 and 50 houses).
 template <int GROUP, int VEC>
 __global__ __launch_bounds__(256) void k_step_group(StepArgs a) {
+  rebase(a);
   const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / GROUP;
   const int lane = threadIdx.x % GROUP;
   const bool env_ok = gid < a.E;
@@ -762,6 +803,7 @@ __global__ __launch_bounds__(256) void k_step_group(StepArgs a) {
 // vector axis - 4 consecutive envs per thread, every per-house array AND the per-env table rows read 16 bytes wide.
 // No reduction: the cluster is the house.
 __global__ __launch_bounds__(256) void k_step_single_house(StepArgs a) {
+  rebase(a);
   const int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (e0 >= a.E) return;   // E % 4 == 0
   float Ta[4], Tm[4], k01[4], s0[4], k10[4], s1[4], iu[4], q[4], pm[4], tg[4], db[4], od[4], solar[4];
@@ -951,6 +993,7 @@ __global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs r
 // grid = (nblk, E); workgroup b of env e owns houses [b * 256 * VEC, (b + 1) * 256 * VEC)
 template <int VEC>
 __global__ __launch_bounds__(256) void k_step_partial(StepArgs a) {
+  rebase(a);
   __shared__ double lds[3 * 4];
   const int e = blockIdx.y;
   const int h = ((int)blockIdx.x * 256 + (int)threadIdx.x) * VEC;
@@ -1002,6 +1045,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(StepArgs a) {
 // rewards and the two power columns from the (possibly all-reduced) totals; re-derives the penalty
 template <int VEC>
 __global__ __launch_bounds__(256) void k_step_finish(StepArgs a) {
+  rebase(a);
   const int e = blockIdx.y;
   const int h = ((int)blockIdx.x * 256 + (int)threadIdx.x) * VEC;
   double P, sum_pen;
@@ -1304,6 +1348,7 @@ __device__ __forceinline__ MsgFields sender_from_ext(const ObsArgs& a, int e, in
 
 // SingleHouse.message (env 624-662) of every local house as one record of mf floats: what a shard exports to its peers
 __global__ __launch_bounds__(256) void k_obs_messages(ObsArgs a) {
+  rebase(a);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.plane) return;
   const int e = (int)(i / a.N);
@@ -1328,6 +1373,7 @@ __global__ __launch_bounds__(256) void k_obs_messages(ObsArgs a) {
 // EXT: the senders are message records (sender_from_ext) addressed through the link table - the sharded-houses form.
 template <int LAYOUT, bool RANDOM, bool EXT = false>
 __global__ __launch_bounds__(256) void k_obs_vector(ObsArgs a) {
+  rebase(a);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.plane) return;
   const int e = (int)(i / a.N);
@@ -1416,6 +1462,7 @@ __device__ __forceinline__ void stage_tile_senders(const ObsArgs& a, const ObsTi
 // feature plane is written with 4 * VEC-byte non-temporal stores.
 template <int VEC, bool RANDOM>
 __global__ __launch_bounds__(256) void k_obs_planes(ObsArgs a) {
+  rebase(a);
   constexpr int OBS_PTILE = 256 * VEC;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -1453,6 +1500,7 @@ __global__ __launch_bounds__(256) void k_obs_planes(ObsArgs a) {
 //  block, planes -> F rows of TILE floats.  TILE = 64 keeps a workgroup at one wavefront (LDS ~13 KB at F = 51).
 template <int LAYOUT, int TILE, bool RANDOM>
 __global__ __launch_bounds__(TILE) void k_obs_tiled(ObsArgs a) {
+  rebase(a);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int tpe = (a.N + TILE - 1) / TILE;              // 1-D grid: tile id -> (env, first house)
@@ -1531,6 +1579,7 @@ __global__ __launch_bounds__(TILE) void k_obs_tiled(ObsArgs a) {
 // array once while the 10x message fan-out is served from LDS.
 template <int TILE>
 __global__ __launch_bounds__(TILE) void k_obs_rows(ObsArgs a) {
+  rebase(a);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int tpe = (a.N + TILE - 1) / TILE;              // 1-D grid: tile id -> (env, first house)
@@ -1647,6 +1696,7 @@ __global__ __launch_bounds__(TILE) void k_obs_rows(ObsArgs a) {
 // output rows are generated directly in output order and streamed with 16-byte non-temporal stores.
 template <int TILE>
 __global__ __launch_bounds__(TILE) void k_obs_rows_default(ObsArgs a) {
+  rebase(a);
   constexpr int OWN = 11, MF = 4, C = 10, F = OWN + C * MF, OWNP = 11;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;

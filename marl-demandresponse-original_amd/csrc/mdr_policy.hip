@@ -47,6 +47,7 @@ struct ActorArgs {
   int64_t plane;   // 0: obs is [A][F] rows; > 0: feature-major [F][plane] (plane >= A): lanes of a group read consecutive floats
   int F, S1, S2;
   uint32_t k0, k1, step_lo, step_hi;
+  const int32_t* step_dev;   // optional: added to the step counter on the device (graph replays: the env's time index)
 };
 
 // max(x, 0) in one instruction (v_med3_f32; fmaxf costs a canonicalising v_max_f32 x, x before the v_max_f32 x, 0)
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_actor_sample(ActorArgs a) {
     const float p0 = 1.0f / (1.0f + expf(-d));
     const float p1 = 1.0f / (1.0f + expf(d));
     if (h == 0 && valid) {
-      const u32x4 rnd = philox4x32_10((uint32_t)agent, (uint32_t)((uint64_t)agent >> 32), a.step_lo, TAG_ACTION ^ a.step_hi, a.k0, a.k1);
+      const u32x4 rnd = philox4x32_10((uint32_t)agent, (uint32_t)((uint64_t)agent >> 32), a.step_lo + (a.step_dev ? (uint32_t)*a.step_dev : 0u), TAG_ACTION ^ a.step_hi, a.k0, a.k1);
       const float u = ((float)(rnd.x >> 8) + 0.5f) * (1.0f / 16777216.0f);
       const int act = u < p0 ? 0 : 1;
       a.action[agent] = (uint8_t)act;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
     const bool valid = agent < a.A;
     if ((it & 3) == 0) {
       const int64_t ag = (t + g * nwaves) * 16 + r;
-      rnd = philox4x32_10((uint32_t)ag, (uint32_t)((uint64_t)ag >> 32), a.step_lo, TAG_ACTION ^ a.step_hi, a.k0, a.k1).x;
+      rnd = philox4x32_10((uint32_t)ag, (uint32_t)((uint64_t)ag >> 32), a.step_lo + (a.step_dev ? (uint32_t)*a.step_dev : 0u), TAG_ACTION ^ a.step_hi, a.k0, a.k1).x;
     }
     f32x4 acc[MB];
 #pragma unroll
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) 
     const bool valid = agent < a.A;
     if ((it & 3) == 0) {
       const int64_t ag = (t + g * nwaves) * 16 + r;
-      rnd = philox4x32_10((uint32_t)ag, (uint32_t)((uint64_t)ag >> 32), a.step_lo, TAG_ACTION ^ a.step_hi, a.k0, a.k1).x;
+      rnd = philox4x32_10((uint32_t)ag, (uint32_t)((uint64_t)ag >> 32), a.step_lo + (a.step_dev ? (uint32_t)*a.step_dev : 0u), TAG_ACTION ^ a.step_hi, a.k0, a.k1).x;
     }
     f32x4 acc[MB];
 #pragma unroll
@@ -480,7 +481,7 @@ int64_t mdr_actor_frag2_floats(int32_t layout, int32_t hidden1) {
 }
 
 int mdr_actor_sample(const mdr_actor_t* actor, const float* obs, int64_t obs_plane_stride, int64_t nb_agents, uint64_t seed, uint64_t step,
-                     uint8_t* action, float* a_prob, float* probs, void* stream) {
+                     const int32_t* step_dev, uint8_t* action, float* a_prob, float* probs, void* stream) {
   if (!actor || actor->struct_size != sizeof(mdr_actor_t) || !obs || !action || nb_agents < 0) return MDR_ERR_INVALID;
   if (obs_plane_stride != 0 && obs_plane_stride < nb_agents) return MDR_ERR_INVALID;
   if (!actor->frag1 || !actor->frag2 || !actor->wdiff || !layout_ok(actor->layout)) return MDR_ERR_INVALID;
@@ -501,6 +502,7 @@ int mdr_actor_sample(const mdr_actor_t* actor, const float* obs, int64_t obs_pla
   a.F = actor->num_state; a.S1 = steps1(layout, actor->num_state); a.S2 = steps2(layout, actor->hidden1);
   a.k0 = (uint32_t)(seed & 0xFFFFFFFFull); a.k1 = (uint32_t)(seed >> 32);
   a.step_lo = (uint32_t)(step & 0xFFFFFFFFull); a.step_hi = (uint32_t)(step >> 32);
+  a.step_dev = step_dev;
   const size_t lds_bytes = ((size_t)(a.S1 + a.S2) * floats_per_step(layout) + 512) * sizeof(float);   // + head weights (and biases)
   if (lds_bytes > 160 * 1024) return MDR_ERR_UNSUPPORTED;   // num_state beyond ~190 with 100-unit layers
   int dev = 0, cus = 256;

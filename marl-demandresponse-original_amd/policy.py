@@ -152,10 +152,12 @@ class FusedActor:
         return cls(fc[0].weight, fc[0].bias, fc[1].weight, fc[1].bias, fc[2].weight, fc[2].bias, device=dev, layout=layout)
 
     def sample(self, obs: torch.Tensor, seed: int, step: int, want_probs: bool = False,
-               action: Optional[torch.Tensor] = None, a_prob: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, ...]:
+               action: Optional[torch.Tensor] = None, a_prob: Optional[torch.Tensor] = None,
+               step_dev: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, ...]:
         """obs float32 on the device: rows [A, F] (contiguous) or feature planes - any [F, ...] tensor whose trailing
         dimensions are contiguous (e.g. ``env.obs_vector("planes")``: [F, E, N] with a padded plane stride), or the
-        transposed view [A, F] of one -> (action uint8 [A], a_prob float32 [A][, probs [A, 2]])."""
+        transposed view [A, F] of one -> (action uint8 [A], a_prob float32 [A][, probs [A, 2]]).  ``step_dev``: device
+        int32 added to ``step`` inside the kernel (``env.device_time_index`` when the call is captured in a graph)."""
         F = self.num_state
         if obs.dtype != torch.float32 or obs.device != self.device:
             raise ValueError("obs must be a float32 tensor on %s" % (self.device,))
@@ -172,8 +174,11 @@ class FusedActor:
         a_prob = torch.empty(A, dtype=torch.float32, device=self.device) if a_prob is None else a_prob
         probs = torch.empty((A, 2), dtype=torch.float32, device=self.device) if want_probs else None
         with torch.cuda.device(self.device):
+            if step_dev is not None and (step_dev.dtype != torch.int32 or step_dev.device != self.device):
+                raise ValueError("step_dev must be an int32 tensor on the device (env.device_time_index)")
             rc = self._lib.mdr_actor_sample(C.byref(self._desc), C.c_void_p(obs.data_ptr()), plane, A, C.c_uint64(seed & (2 ** 64 - 1)),
-                                            C.c_uint64(step & (2 ** 64 - 1)), C.c_void_p(action.data_ptr()), C.c_void_p(a_prob.data_ptr()),
+                                            C.c_uint64(step & (2 ** 64 - 1)), C.c_void_p(step_dev.data_ptr()) if step_dev is not None else None,
+                                            C.c_void_p(action.data_ptr()), C.c_void_p(a_prob.data_ptr()),
                                             C.c_void_p(probs.data_ptr()) if want_probs else None,
                                             C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         if rc != 0:

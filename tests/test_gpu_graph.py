@@ -1,0 +1,137 @@
+"""Graph mode: the device-resident cursor lets ONE captured step (observation -> policy -> mdr_env_step) be replayed through
+an episode (hipGraph via torch.cuda.CUDAGraph).  The replayed episode must be the eager one, bit for bit."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(N, **patches):
+    import mdr_amd
+    cfg = mdr_amd.default_config()
+    cfg["default_env_prop"]["cluster_prop"]["nb_agents"] = N
+    cfg["default_env_prop"]["power_grid_prop"]["base_power_mode"] = "constant"
+    cfg["default_env_prop"]["power_grid_prop"]["signal_mode"] = "perlin"
+    cfg["noise_house_prop"]["noise_mode"] = "big_noise"
+    cfg["noise_hvac_prop"]["noise_mode"] = "big_noise"
+    for dotted, v in patches.items():
+        node = cfg
+        parts = dotted.split(".")
+        for p in parts[:-1]:
+            node = node[p]
+        node[parts[-1]] = v
+    return cfg
+
+
+def _policy_step(env, fused, obs_buf, act, prob, step_dev):
+    env.obs_vector("rows", out=obs_buf)
+    fused.sample(obs_buf.view(-1, obs_buf.shape[-1]), 77, 0, action=act, a_prob=prob, step_dev=step_dev)
+    env.step(act.view(env.nb_envs, env.nb_houses))
+
+
+@pytest.mark.parametrize("E,N,table_steps", [(64, 50, 16), (3, 1024, 64), (1, 10, 8), (5, 5000, 32)])
+def test_replayed_graph_equals_eager_episode(E, N, table_steps):
+    import mdr_amd
+    from mdr_amd.policy import FusedActor
+    from mdr_amd.rollout import ActorMLP
+    cfg = _cfg(N)
+    torch.manual_seed(1)
+    T = 3 * table_steps + 5                      # crosses several table refills
+    eager = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=3, table_steps=table_steps, graph_mode=True)
+    graph = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=3, table_steps=table_steps, graph_mode=True)
+    plain = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=3, table_steps=table_steps)
+    F = eager.obs_vector_length()
+    fused = FusedActor.from_module(ActorMLP(F).cuda())
+    bufs = {}
+    for name, env in (("eager", eager), ("graph", graph), ("plain", plain)):
+        env.reset(episode=0)
+        bufs[name] = (torch.empty((E, N, F), device="cuda:0"), torch.empty(E * N, dtype=torch.uint8, device="cuda:0"),
+                      torch.empty(E * N, device="cuda:0"))
+    # eager in graph mode and the ordinary env (host-computed rows, host step counter) walk the same episode
+    for t in range(T):
+        _policy_step(eager, fused, *bufs["eager"], eager.device_time_index)
+        o, a, p = bufs["plain"]
+        plain.obs_vector("rows", out=o)
+        fused.sample(o.view(-1, F), 77, t, action=a, a_prob=p)
+        plain.step(a.view(E, N))
+    for k in ("Ta", "Tm", "sso", "flags", "reward", "obs", "P"):
+        assert torch.equal(eager.t[k], plain.t[k]), k
+    assert eager.steps_taken == plain.steps_taken == T
+    # capture one step, replay it through the episode
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                 # warm-up on the capture stream (also syncs the device cursor)
+        _policy_step(graph, fused, *bufs["graph"], graph.device_time_index)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        _policy_step(graph, fused, *bufs["graph"], graph.device_time_index)
+    assert graph.steps_taken == 1                 # the capture itself did not run or count
+    done = 1
+    while done < T:
+        n = min(graph.graph_room(), T - done)
+        assert n >= 1
+        for _ in range(n):
+            g.replay()
+        graph.graph_replayed(n)
+        done += n
+    torch.cuda.synchronize()
+    assert graph.steps_taken == T
+    for k in ("Ta", "Tm", "sso", "flags", "reward", "obs", "P", "actions"):
+        assert torch.equal(graph.t[k], eager.t[k]), k
+    assert torch.equal(bufs["graph"][1], bufs["eager"][1]) and torch.equal(bufs["graph"][2], bufs["eager"][2])
+    assert graph.t["cursor"].tolist() == [graph.cursor()[0] - graph.cursor()[1], T]
+    # and the env keeps working eagerly afterwards
+    graph.step_bangbang()
+    eager.step_bangbang()
+    assert torch.equal(graph.t["Ta"], eager.t["Ta"])
+
+
+def test_graph_mode_guards():
+    import mdr_amd
+    env = mdr_amd.BatchedDemandResponseEnv(_cfg(64), nb_envs=2, device="cuda:0", seed=1, table_steps=4, graph_mode=True)
+    env.reset(episode=0)
+    assert env.graph_room() == 4
+    with pytest.raises(ValueError):
+        env.graph_replayed(5)                       # more than the tables cover
+    env.graph_replayed(4)                           # (pretend) - refills the tables
+    assert env.graph_room() == 4 and env.steps_taken == 4
+    plain = mdr_amd.BatchedDemandResponseEnv(_cfg(64), nb_envs=2, device="cuda:0", seed=1)
+    plain.reset(episode=0)
+    with pytest.raises(ValueError):
+        plain.graph_replayed(1)
+    with pytest.raises(RuntimeError):
+        plain.device_time_index
+
+
+def test_graph_mode_with_interpolated_base_power():
+    """The interpolatePower update every ceil(300 / dt) steps is host work: graph_room stops the replays there."""
+    import mdr_amd
+    from tests import golden_util as gu
+    grid = gu.Golden("s12_interp_default_like").interp_grid()
+    cfg = _cfg(40, **{"default_env_prop.power_grid_prop.base_power_mode": "interpolation", "default_env_prop.time_step": 60})
+    a = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=4, device="cuda:0", seed=2, interp_grid=grid, graph_mode=True)
+    b = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=4, device="cuda:0", seed=2, interp_grid=grid)
+    a.reset(episode=0)
+    b.reset(episode=0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        a.step_bangbang()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        a.step_bangbang()
+    done, T = 1, 23
+    rooms = []
+    while done < T:
+        n = min(a.graph_room(), T - done)
+        rooms.append(n)
+        for _ in range(n):
+            g.replay()
+        a.graph_replayed(n)
+        done += n
+    b.rollout(T)
+    assert max(rooms) <= 5                          # never across an update (every 5 steps)
+    for k in ("Ta", "sso", "reward", "P", "base_power", "obs"):
+        assert torch.equal(a.t[k], b.t[k]), k
