@@ -39,7 +39,8 @@ typedef struct mdr_actor {
   int32_t num_state;   /* F: floats per observation row */
   int32_t hidden1;     /* units of hidden layer 1 (<= MDR_ACTOR_MAX_HIDDEN) */
   int32_t hidden2;     /* units of hidden layer 2 (<= MDR_ACTOR_MAX_HIDDEN) */
-  int32_t reserved0;
+  int32_t greedy;      /* 0: action ~ Categorical(softmax) (PPOAgent.act, agents/rl_controllers.py:28-36); 1: action = argmax of the two
+                          outputs (DQNAgent.act, rl_controllers.py:53-60: the same Linear/ReLU stack read as Q-values), no draw */
   /* device, MFMA fragment order.  W1z / W2z / W3z: the weight matrices zero-padded to 128 rows / columns.
    * MDR_ACTOR_FRAG32 (S1 = ceil((F + 1) / 2), S2 = mdr_actor_steps2, r = lane & 31, h = lane >> 5) carries the biases as a
    * constant-1 input feature / hidden unit:  W1e = [[W1 b1] [0 1]],  W2e = [[W2 b2] [0 1]],  W3e = [W3 b3]:

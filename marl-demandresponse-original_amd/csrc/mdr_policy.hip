@@ -48,6 +48,7 @@ struct ActorArgs {
   int F, S1, S2;
   uint32_t k0, k1, step_lo, step_hi;
   const int32_t* step_dev;   // optional: added to the step counter on the device (graph replays: the env's time index)
+  int greedy;                // action = argmax instead of a draw (DQNAgent.act)
 };
 
 // max(x, 0) in one instruction (v_med3_f32; fmaxf costs a canonicalising v_max_f32 x, x before the v_max_f32 x, 0)
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_actor_sample(ActorArgs a) {
     if (h == 0 && valid) {
       const u32x4 rnd = philox4x32_10((uint32_t)agent, (uint32_t)((uint64_t)agent >> 32), a.step_lo + (a.step_dev ? (uint32_t)*a.step_dev : 0u), TAG_ACTION ^ a.step_hi, a.k0, a.k1);
       const float u = ((float)(rnd.x >> 8) + 0.5f) * (1.0f / 16777216.0f);
-      const int act = u < p0 ? 0 : 1;
+      const int act = a.greedy ? (d >= 0.0f ? 0 : 1) : (u < p0 ? 0 : 1);   // argmax keeps the first maximum, as torch.argmax
       a.action[agent] = (uint8_t)act;
       if (a.a_prob) a.a_prob[agent] = act ? p1 : p0;
       if (a.probs) {
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
     const uint32_t draw = (uint32_t)__shfl((int)rnd, r + 16 * (it & 3));   // the group that drew for this tile
     if (g == 0 && valid) {
       const float u = ((float)(draw >> 8) + 0.5f) * (1.0f / 16777216.0f);
-      const int act = u < p0 ? 0 : 1;
+      const int act = a.greedy ? (d >= 0.0f ? 0 : 1) : (u < p0 ? 0 : 1);   // argmax keeps the first maximum, as torch.argmax
       a.action[agent] = (uint8_t)act;
       if (a.a_prob) a.a_prob[agent] = act ? p1 : p0;
       if (a.probs) {
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) 
     const uint32_t draw = (uint32_t)__shfl((int)rnd, r + 16 * (it & 3));   // the group that drew for this tile
     if (g == 0 && valid) {
       const float u = ((float)(draw >> 8) + 0.5f) * (1.0f / 16777216.0f);
-      const int act = u < p0 ? 0 : 1;
+      const int act = a.greedy ? (d >= 0.0f ? 0 : 1) : (u < p0 ? 0 : 1);   // argmax keeps the first maximum, as torch.argmax
       a.action[agent] = (uint8_t)act;
       if (a.a_prob) a.a_prob[agent] = act ? p1 : p0;
       if (a.probs) {
@@ -503,6 +504,7 @@ int mdr_actor_sample(const mdr_actor_t* actor, const float* obs, int64_t obs_pla
   a.k0 = (uint32_t)(seed & 0xFFFFFFFFull); a.k1 = (uint32_t)(seed >> 32);
   a.step_lo = (uint32_t)(step & 0xFFFFFFFFull); a.step_hi = (uint32_t)(step >> 32);
   a.step_dev = step_dev;
+  a.greedy = actor->greedy != 0;
   const size_t lds_bytes = ((size_t)(a.S1 + a.S2) * floats_per_step(layout) + 512) * sizeof(float);   // + head weights (and biases)
   if (lds_bytes > 160 * 1024) return MDR_ERR_UNSUPPORTED;   // num_state beyond ~190 with 100-unit layers
   int dev = 0, cus = 256;

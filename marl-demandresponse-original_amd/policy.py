@@ -22,7 +22,7 @@ FRAG32, FRAG16, BF16X3 = 0, 1, 2
 
 class MdrActor(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("layout", C.c_int32), ("num_state", C.c_int32), ("hidden1", C.c_int32),
-                ("hidden2", C.c_int32), ("reserved0", C.c_int32),
+                ("hidden2", C.c_int32), ("greedy", C.c_int32),
                 ("frag1", C.c_void_p), ("frag2", C.c_void_p), ("wdiff", C.c_void_p)]
 
 
@@ -31,7 +31,7 @@ def _acc_row(reg: np.ndarray, half: np.ndarray) -> np.ndarray:
 
 
 class FusedActor:
-    def __init__(self, w1, b1, w2, b2, w3, b3, device="cuda:0", layout: Optional[int] = None):
+    def __init__(self, w1, b1, w2, b2, w3, b3, device="cuda:0", layout: Optional[int] = None, greedy: bool = False):
         """w1 [H1, F], b1 [H1], w2 [H2, H1], b2 [H2], w3 [2, H2], b3 [2] (torch.nn.Linear layout).
         ``layout``: FRAG16 (v_mfma_f32_16x16x4_f32, exact fp32, the default whenever F <= 63), FRAG32
         (v_mfma_f32_32x32x2_f32, exact fp32, any F) or BF16X3 (bf16 MFMA on head + tail halves of every operand:
@@ -47,6 +47,7 @@ class FusedActor:
         if layout is None:
             layout = FRAG16 if F <= 64 else FRAG32
         self.layout = int(layout)
+        self.greedy = bool(greedy)      # argmax instead of a draw: the reference's DQNAgent.act on a DQN_network
         self.num_state, self.hidden1, self.hidden2 = int(F), int(H1), int(H2)
         self.device = torch.device(device)
         S1 = int(self._lib.mdr_actor_steps1(self.layout, F))
@@ -93,7 +94,7 @@ class FusedActor:
         assert self._wdiff.numel() == (128 if self.layout == FRAG32 else 388)
         assert self._frag1.numel() == self._lib.mdr_actor_frag1_floats(self.layout, F)
         assert self._frag2.numel() == self._lib.mdr_actor_frag2_floats(self.layout, H1)
-        self._desc = MdrActor(C.sizeof(MdrActor), self.layout, F, H1, H2, 0, self._frag1.data_ptr(), self._frag2.data_ptr(),
+        self._desc = MdrActor(C.sizeof(MdrActor), self.layout, F, H1, H2, int(self.greedy), self._frag1.data_ptr(), self._frag2.data_ptr(),
                               self._wdiff.data_ptr())
 
     def _bias_block(self, b1, b2, b3) -> torch.Tensor:
@@ -139,17 +140,18 @@ class FusedActor:
         assert self._wdiff.numel() == 388
         assert self._frag1.numel() * 2 == 4 * self._lib.mdr_actor_frag1_floats(self.layout, F)
         assert self._frag2.numel() * 2 == 4 * self._lib.mdr_actor_frag2_floats(self.layout, H1)
-        self._desc = MdrActor(C.sizeof(MdrActor), self.layout, F, H1, H2, 0, self._frag1.data_ptr(), self._frag2.data_ptr(),
+        self._desc = MdrActor(C.sizeof(MdrActor), self.layout, F, H1, H2, int(self.greedy), self._frag1.data_ptr(), self._frag2.data_ptr(),
                               self._wdiff.data_ptr())
 
     @classmethod
-    def from_module(cls, actor, device=None, layout: Optional[int] = None) -> "FusedActor":
-        """From an ``ActorMLP`` / the reference's ``Actor`` (``fc`` ModuleList of three Linear layers)."""
+    def from_module(cls, actor, device=None, layout: Optional[int] = None, greedy: bool = False) -> "FusedActor":
+        """From an ``ActorMLP`` / the reference's ``Actor`` - or, with ``greedy=True``, its ``DQN_network`` (the same ``fc``
+        ModuleList of three Linear layers, agents/network.py:58-77, whose two outputs are Q-values: action = argmax)."""
         fc = list(actor.fc)
         if len(fc) != 3:
             raise ValueError("the fused kernel covers two hidden layers (config.py: layers = [100, 100])")
         dev = device if device is not None else fc[0].weight.device
-        return cls(fc[0].weight, fc[0].bias, fc[1].weight, fc[1].bias, fc[2].weight, fc[2].bias, device=dev, layout=layout)
+        return cls(fc[0].weight, fc[0].bias, fc[1].weight, fc[1].bias, fc[2].weight, fc[2].bias, device=dev, layout=layout, greedy=greedy)
 
     def sample(self, obs: torch.Tensor, seed: int, step: int, want_probs: bool = False,
                action: Optional[torch.Tensor] = None, a_prob: Optional[torch.Tensor] = None,

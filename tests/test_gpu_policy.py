@@ -136,3 +136,23 @@ def test_feature_plane_input_gives_the_same_bits_as_rows(A, F, layout):
     env_like = planes.view(F, 1, A)                                  # [F, E, N] as obs_vector("planes") returns it
     a4, _ = fused.sample(env_like, 3, 4)
     assert torch.equal(a0, a4)
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_greedy_mode_is_the_argmax_of_a_dqn_network(layout):
+    """DQNAgent.act (agents/rl_controllers.py:53-60): the same Linear/ReLU stack, action = argmax of its two outputs."""
+    from mdr_amd.policy import FusedActor
+    net = _actor(51, (100, 100), seed=8, scale=2.0)              # ActorMLP's fc stack == DQN_network's
+    fused = FusedActor.from_module(net, layout=layout, greedy=True)
+    obs = torch.randn((20000, 51), device="cuda:0")
+    with torch.no_grad():
+        x = obs
+        for lin in net.fc[:-1]:
+            x = torch.relu(lin(x))
+        q = net.fc[-1](x)
+    a, _ = fused.sample(obs, 1, 1)
+    a2, _ = fused.sample(obs, 99, 7)
+    assert torch.equal(a, a2)                                     # no randomness involved
+    clear = (q[:, 0] - q[:, 1]).abs() > (1e-3 if layout == 2 else 1e-5)
+    assert clear.float().mean() > 0.99
+    assert torch.equal(a[clear].long(), q.argmax(1)[clear])
