@@ -591,6 +591,10 @@ class BatchedDemandResponseEnv:
         return self.t["tab_od"][self._row()].double() + self.spec.temp_ref
 
     def reg_signal(self) -> torch.Tensor:
+        if self.graph_mode:      # row from the device cursor: stays right when the call is captured and replayed
+            if not torch.cuda.is_current_stream_capturing():
+                self.graph_replayed(0)      # the device cursor is synced lazily (e.g. after reset): make it current
+            return torch.index_select(self.t["tab_signal"], 0, self.t["cursor"][:1].long())[0]
         return self.t["tab_signal"][self._row()]
 
     def solar_gain(self) -> torch.Tensor:

@@ -155,3 +155,61 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
     if store_states:
         out["state"] = states
     return out
+
+
+@torch.no_grad()
+def deploy_policy(env, policy, nb_steps: int, seed: int = 0, use_graph: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+    """The evaluation loop of main-deploy.py:99-152 with a learned agent (PPOAgent / DQNAgent, agents/rl_controllers.py) for all
+    envs at once: every step observation -> ``policy`` (a ``FusedActor``; ``greedy=True`` for a DQN network) -> ``env.step``,
+    with the metrics the script accumulates: ``reward_sum`` [E, N], ``sq_temp_error_sum`` [E] (sum over steps and houses of
+    (house_temp - target)^2), ``sq_signal_error_sum`` [E] (sum over steps of (reg_signal - cluster_hvac_power)^2).
+
+    ``use_graph`` (default: when the env was built with ``graph_mode=True``): the step is captured once in a
+    ``torch.cuda.CUDAGraph`` and replayed - the launch-bound regime of small batches."""
+    E, N = env.nb_envs, env.nb_houses
+    dev = env.device
+    F_len = env.obs_vector_length()
+    obs = torch.empty((E, N, F_len), dtype=torch.float32, device=dev)
+    act = torch.empty(E * N, dtype=torch.uint8, device=dev)
+    out = {"reward_sum": torch.zeros((E, N), dtype=torch.float32, device=dev),
+           "sq_temp_error_sum": torch.zeros(E, dtype=torch.float64, device=dev),
+           "sq_signal_error_sum": torch.zeros(E, dtype=torch.float64, device=dev)}
+    graph_mode = bool(getattr(env, "graph_mode", False))
+    if use_graph is None:
+        use_graph = graph_mode
+    if use_graph and not graph_mode:
+        raise ValueError("use_graph needs an env built with graph_mode=True")
+    step0 = 0 if graph_mode else env.steps_taken
+    step_dev = env.device_time_index if graph_mode else None
+
+    def one_step(t):
+        env.obs_vector("rows", out=obs)
+        policy.sample(obs.view(E * N, F_len), seed, step0 + t, action=act, step_dev=step_dev)
+        _, r, _, info = env.step(act.view(E, N))
+        out["reward_sum"] += r
+        d = (env.t["Ta"] - env.t["target"]).double()
+        out["sq_temp_error_sum"] += (d * d).sum(dim=1)
+        out["sq_signal_error_sum"] += (env.reg_signal() - info["cluster_hvac_power"]) ** 2
+
+    if not use_graph or nb_steps < 3:
+        for t in range(nb_steps):
+            one_step(0 if graph_mode else t)
+        return out
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):          # one eager step on the capture stream: warms up and syncs the device cursor
+        one_step(0)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    done = 1
+    if env.graph_room() < 1:
+        env.graph_replayed(0)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        one_step(0)
+    while done < nb_steps:
+        n = min(env.graph_room(), nb_steps - done)
+        for _ in range(n):
+            g.replay()
+        env.graph_replayed(n)
+        done += n
+    return out

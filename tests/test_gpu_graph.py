@@ -135,3 +135,45 @@ def test_graph_mode_with_interpolated_base_power():
     assert max(rooms) <= 5                          # never across an update (every 5 steps)
     for k in ("Ta", "sso", "reward", "P", "base_power", "obs"):
         assert torch.equal(a.t[k], b.t[k]), k
+
+
+@pytest.mark.parametrize("greedy", [False, True])
+def test_deploy_policy_graph_equals_eager(greedy):
+    """rollout.deploy_policy: the main-deploy.py loop with a learned agent, eager vs captured-and-replayed."""
+    import mdr_amd
+    from mdr_amd.policy import FusedActor
+    from mdr_amd.rollout import ActorMLP, deploy_policy
+    E, N, T = 8, 50, 70
+    cfg = _cfg(N)
+    torch.manual_seed(2)
+    envs = [mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=6, table_steps=16, graph_mode=gm) for gm in (True, True, False)]
+    for e in envs:
+        e.reset(episode=0)
+    fused = FusedActor.from_module(ActorMLP(envs[0].obs_vector_length()).cuda(), greedy=greedy)
+    res = [deploy_policy(envs[0], fused, T, seed=4, use_graph=True), deploy_policy(envs[1], fused, T, seed=4, use_graph=False),
+           deploy_policy(envs[2], fused, T, seed=4)]
+    for e in envs:
+        assert e.steps_taken == T
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]) and torch.equal(res[0][k], res[2][k]), k
+    for k in ("Ta", "sso", "reward"):
+        assert torch.equal(envs[0].t[k], envs[1].t[k]) and torch.equal(envs[0].t[k], envs[2].t[k]), k
+    assert float(res[0]["sq_temp_error_sum"].min()) > 0
+
+
+def test_reg_signal_in_graph_mode_follows_resets_and_steps():
+    import mdr_amd
+    cfg = _cfg(20)
+    a = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=3, device="cuda:0", seed=5, table_steps=8, graph_mode=True)
+    b = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=3, device="cuda:0", seed=5, table_steps=8)
+    for episode in (0, 1):
+        a.reset(episode=episode)
+        b.reset(episode=episode)
+        assert torch.equal(a.reg_signal(), b.reg_signal())
+        for _ in range(11):
+            a.step_bangbang()
+            b.step_bangbang()
+            assert torch.equal(a.reg_signal(), b.reg_signal())
+        a.rollout_fused(5)
+        b.rollout_fused(5)
+        assert torch.equal(a.reg_signal(), b.reg_signal()) and torch.equal(a.obs_vector("rows"), b.obs_vector("rows"))
