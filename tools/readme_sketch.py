@@ -23,3 +23,11 @@ o, r, d, i = single.step({k: True for k in o})
 torch.cuda.synchronize()
 print("ok", tuple(obs7.shape), tuple(state.shape), tuple(reward.shape), tuple(info["cluster_hvac_power"].shape),
       sorted(metrics), len(o), round(r[0], 4), float(env.t["base_power"][0]))
+
+from mdr_amd.rollout import ActorMLP, collect_ppo_rollout, deploy_policy  # noqa: E402
+from mdr_amd.policy import FusedActor  # noqa: E402
+actor = ActorMLP(env.obs_vector_length()).cuda()
+batch = collect_ppo_rollout(env, actor, nb_steps=8, store_states=False)
+dm = deploy_policy(env, FusedActor.from_module(actor), nb_steps=10)
+torch.cuda.synchronize()
+print("policy ok", sorted(batch), tuple(batch["action"].shape), sorted(dm), float(dm["reward_sum"].mean()))
