@@ -76,6 +76,13 @@ int64_t mdr_actor_frag2_floats(int32_t layout, int32_t hidden1);    /* size of f
 int mdr_actor_sample(const mdr_actor_t *actor, const float *obs, int64_t obs_plane_stride, int64_t nb_agents, uint64_t seed,
                      uint64_t step, const int32_t *step_dev, uint8_t *action, float *a_prob, float *probs, void *stream);
 
+/* The Monte-Carlo return scan of PPO.update (agents/ppo.py:123-134) for every agent at once: backwards over t,
+ * R <- reward[t] + gamma * (done[t] ? bootstrap[t] : R).  `reward`, `out` float [nb_steps][nb_agents]; `done` uint8 of that
+ * shape or NULL (no restarts); `bootstrap` float of that shape (the critic's value of the next state where done) or NULL
+ * (restart from 0: zero_eoepisode_return). */
+int mdr_discounted_returns(const float *reward, const uint8_t *done, const float *bootstrap, float gamma, int32_t nb_steps,
+                           int64_t nb_agents, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -441,6 +441,22 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) 
   }
 }
 
+// PPO.update's Monte-Carlo return scan (agents/ppo.py:123-134), backwards over the T steps of every agent:
+// R <- reward[t] + gamma * (done[t] ? bootstrap[t] (or 0) : R).  One thread per agent, steps coalesced across agents.
+__global__ __launch_bounds__(256) void k_discounted_returns(const float* reward, const uint8_t* done, const float* bootstrap, float gamma,
+                                                            int T, int64_t A, float* out) {
+  const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (a >= A) return;
+  float run = 0.0f;
+  for (int t = T - 1; t >= 0; --t) {
+    const int64_t i = (int64_t)t * A + a;
+    if (done != nullptr && done[i]) run = bootstrap != nullptr ? bootstrap[i] : 0.0f;
+    const float scaled = gamma * run;   // two roundings, as torch's reward[t] + gamma * running (separate statements: no contraction)
+    run = reward[i] + scaled;
+    out[i] = run;
+  }
+}
+
 int acc_row_half0(int q) { return 32 * (q >> 4) + (q & 3) + 8 * ((q >> 2) & 3); }
 
 // layout MDR_ACTOR_FRAG32: ceil((F + 1) / 2) k-steps of 2; MDR_ACTOR_FRAG16: ceil((F + 1) / 4) k-steps of 4
@@ -523,6 +539,15 @@ int mdr_actor_sample(const mdr_actor_t* actor, const float* obs, int64_t obs_pla
   if (a.S1 <= 32 && a.S2 == 52) return launch(k_actor_sample<32, 52>);   // the reference's shape: num_state <= 62, layers [100, 100]
   if (a.S1 <= 32) return launch(k_actor_sample<32, 0>);
   return launch(k_actor_sample<0, 0>);
+}
+
+int mdr_discounted_returns(const float* reward, const uint8_t* done, const float* bootstrap, float gamma, int32_t nb_steps, int64_t nb_agents,
+                           float* out, void* stream) {
+  if (!reward || !out || nb_steps < 0 || nb_agents < 0) return MDR_ERR_INVALID;
+  if (nb_steps == 0 || nb_agents == 0) return MDR_OK;
+  hipLaunchKernelGGL(k_discounted_returns, dim3((unsigned)((nb_agents + 255) / 256)), dim3(256), 0, (hipStream_t)stream, reward, done, bootstrap,
+                     gamma, nb_steps, nb_agents, out);
+  return hipGetLastError() == hipSuccess ? MDR_OK : MDR_ERR_HIP;
 }
 
 }  // extern "C"

@@ -52,6 +52,24 @@ class CriticMLP(nn.Module):
         return self.fc[-1](x)
 
 
+def _discounted_returns_hip(reward, done, gamma, bootstrap):
+    import ctypes as C
+    from . import _native as nat
+    lib = nat.load()
+    out = torch.empty_like(reward)
+    d8 = done.contiguous().view(torch.uint8) if done.dtype == torch.bool else done.to(torch.uint8).contiguous()
+    boot = bootstrap.to(torch.float32).contiguous() if bootstrap is not None else None
+    T = reward.shape[0]
+    A = reward[0].numel()
+    with torch.cuda.device(reward.device):
+        rc = lib.mdr_discounted_returns(C.c_void_p(reward.data_ptr()), C.c_void_p(d8.data_ptr()),
+                                        C.c_void_p(boot.data_ptr()) if boot is not None else None, C.c_float(gamma), T, A,
+                                        C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(reward.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError("mdr_discounted_returns failed: %s" % lib.mdr_status_string(rc).decode())
+    return out
+
+
 def _fused_policy(actor, dev, precision: str = "fp32"):
     """FusedActor of `actor`, re-packed only when a parameter changed (torch bumps `_version` on in-place updates)."""
     from .policy import BF16X3, FusedActor
@@ -79,6 +97,8 @@ def discounted_returns(reward: torch.Tensor, done: torch.Tensor, gamma: float,
     R_t = r_t + gamma * R_{t+1}; where ``done[t]`` the running return restarts from ``bootstrap[t]`` (the critic's value
     of the next state, or 0 with zero_eoepisode_return) before adding r_t."""
     T = reward.shape[0]
+    if reward.is_cuda and reward.dtype == torch.float32 and reward.is_contiguous() and done.shape == reward.shape and T > 0:
+        return _discounted_returns_hip(reward, done, float(gamma), bootstrap)     # one launch instead of 4 T
     out = torch.empty_like(reward)
     running = torch.zeros_like(reward[0])
     for t in range(T - 1, -1, -1):

@@ -121,3 +121,27 @@ def test_collect_rollout_bf16x3_policy_stays_close_to_the_fp32_actor():
         assert float((ro["a_prob"][t] - p).abs().mean()) < 5e-6
     with pytest.raises(ValueError):
         collect_ppo_rollout(_env(E, N), actor, 2, policy_precision="fp8")
+
+
+@pytest.mark.parametrize("with_bootstrap", [False, True])
+def test_discounted_returns_kernel_equals_the_torch_scan(with_bootstrap):
+    from mdr_amd import rollout
+    T, A = 37, 10007
+    g = torch.Generator(device="cuda").manual_seed(0)
+    reward = torch.randn((T, A), device="cuda", generator=g)
+    done = torch.rand((T, A), device="cuda", generator=g) < 0.1
+    done[T - 1] = True
+    boot = torch.randn((T, A), device="cuda", generator=g) if with_bootstrap else None
+    got = rollout.discounted_returns(reward, done, 0.97, boot)
+    ref = rollout.discounted_returns(reward.cpu(), done.cpu(), 0.97, boot.cpu() if boot is not None else None)     # the torch loop
+    assert torch.equal(got.cpu(), ref)
+    # 3-D shapes ([T, E, N]) and the reference's backward loop in double precision
+    got3 = rollout.discounted_returns(reward.view(T, 1, A), done.view(T, 1, A), 0.97, boot.view(T, 1, A) if boot is not None else None)
+    assert torch.equal(got3.view(T, A), got)
+    r64, R, exp = reward[:, 5].double().cpu().numpy(), 0.0, []
+    for t in reversed(range(T)):
+        if bool(done[t, 5]):
+            R = float(boot[t, 5]) if with_bootstrap else 0.0
+        R = r64[t] + 0.97 * R
+        exp.insert(0, R)
+    np.testing.assert_allclose(got[:, 5].cpu().numpy(), exp, rtol=1e-5, atol=1e-5)
