@@ -309,7 +309,9 @@ __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
   lo = uint4{l[0], l[1], l[2], l[3]};
 }
 
-constexpr int WAVESB = 12;   // 3 per SIMD: ~170 registers per lane (16 waves leave 128, which spills)
+constexpr int WAVESB = 8;    // 2 per SIMD: two column blocks of accumulators (~200 registers per lane)
+constexpr int NCB = 2;       // 16-agent column blocks per wavefront: every weight fragment read from LDS feeds NCB MFMAs (with one block
+                             // the fragment reads, 84 KB per 16 agents, kept the LDS busier than the matrix pipe)
 
 template <int MB>
 __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) {
@@ -333,13 +335,12 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) 
   const int64_t fstride = a.plane ? a.plane : 1;
   // Biases start the accumulators (the C operand) instead of riding as a constant-1 feature: no per-feature selects -
   // features past F are read at the clamped index F - 1 and meet zero weights.
-  // (re-read from LDS every tile: 56 more live registers would not fit the 128 a 16-wave workgroup leaves per lane)
   const f32x4* bias1 = reinterpret_cast<const f32x4*>(wd + 128) + g;   // [mb] at stride 4 vectors
   const f32x4* bias2 = reinterpret_cast<const f32x4*>(wd + 256) + g;
   const float bias3 = wd[384];
-  float xr[16];                           // S1 <= 2 k-steps (F <= 64): 8 features per step
-  auto row_of = [&](int64_t t) {
-    const int64_t agent = t * 16 + r;
+  float xr[NCB][16];                      // S1 <= 2 k-steps (F <= 64): 8 features per step and column block
+  auto row_of = [&](int64_t t, int c) {   // a tile = NCB * 16 consecutive agents
+    const int64_t agent = (t * NCB + c) * 16 + r;
     return a.obs + (agent < a.A ? agent : a.A - 1) * (a.plane ? 1 : (int64_t)a.F);
   };
   auto feature = [&](const float* x, int i) {   // i = 8 s + j
@@ -347,95 +348,131 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) 
     return x[min(k, a.F - 1) * fstride];
   };
   if (wave < a.ntiles) {
-    const float* x = row_of(wave);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) xr[i] = feature(x, i < 8 * a.S1 ? i : 0);
+    for (int c = 0; c < NCB; ++c) {
+      const float* x = row_of(wave, c);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) xr[c][i] = feature(x, i < 8 * a.S1 ? i : 0);
+    }
   }
-  // One Philox call serves four tiles: lane group g draws for the tile this wave reaches g iterations from now (the
-  // counter is that tile's agent index, so the draw stays a function of (seed, step, agent) alone).
-  uint32_t rnd = 0;
+  // One Philox call per agent serves four tiles: lane group g draws for the tile this wave reaches g iterations from now
+  // (the counter is that agent's index, so the draw stays a function of (seed, step, agent) alone).
+  uint32_t rnd[NCB] = {};
   int it = 0;
   for (int64_t t = wave; t < a.ntiles; t += nwaves, ++it) {
-    const int64_t agent = t * 16 + r;
-    const bool valid = agent < a.A;
     if ((it & 3) == 0) {
-      const int64_t ag = (t + g * nwaves) * 16 + r;
-      rnd = philox4x32_10((uint32_t)ag, (uint32_t)((uint64_t)ag >> 32), a.step_lo + (a.step_dev ? (uint32_t)*a.step_dev : 0u), TAG_ACTION ^ a.step_hi, a.k0, a.k1).x;
-    }
-    f32x4 acc[MB];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) acc[mb] = bias1[mb * 4];
+      for (int c = 0; c < NCB; ++c) {
+        const int64_t ag = ((t + g * nwaves) * NCB + c) * 16 + r;
+        rnd[c] = philox4x32_10((uint32_t)ag, (uint32_t)((uint64_t)ag >> 32), a.step_lo + (a.step_dev ? (uint32_t)*a.step_dev : 0u),
+                               TAG_ACTION ^ a.step_hi, a.k0, a.k1).x;
+      }
+    }
+    f32x4 acc[NCB][MB];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) acc[c][mb] = bias1[mb * 4];
     // ---- layer 1
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       if (s < a.S1) {
-        uint4 bh, bl;
-        split8(xr + 8 * s, bh, bl);
-        const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bl = __builtin_bit_cast(bf16x8, bl);
+        bf16x8 Bh[NCB], Bl[NCB];
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+          uint4 bh, bl;
+          split8(xr[c] + 8 * s, bh, bl);
+          Bh[c] = __builtin_bit_cast(bf16x8, bh);
+          Bl[c] = __builtin_bit_cast(bf16x8, bl);
+        }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
           const bf16x8 Ah = __builtin_bit_cast(bf16x8, f1[((s * 8 + mb) * 2 + 0) * 64 + lane]);
           const bf16x8 Al = __builtin_bit_cast(bf16x8, f1[((s * 8 + mb) * 2 + 1) * 64 + lane]);
-          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, acc[mb], 0, 0, 0);
+#pragma unroll
+          for (int c = 0; c < NCB; ++c) {
+            acc[c][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh[c], acc[c][mb], 0, 0, 0);
+            acc[c][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh[c], acc[c][mb], 0, 0, 0);
+            acc[c][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl[c], acc[c][mb], 0, 0, 0);
+          }
         }
       }
     }
     // ---- layer 2 (the next tile's features are loaded between its k-steps)
     const bool more = t + nwaves < a.ntiles;
-    const float* xn = row_of(more ? t + nwaves : t);
-    f32x4 out[MB];
+    const float* xn[NCB];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) out[mb] = bias2[mb * 4];
+    for (int c = 0; c < NCB; ++c) xn[c] = row_of(more ? t + nwaves : t, c);
+    f32x4 out[NCB][MB];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) out[c][mb] = bias2[mb * 4];
 #pragma unroll
     for (int s = 0; s < S2B; ++s) {
       if (more) {
 #pragma unroll
-        for (int i = 4 * s; i < 4 * s + 4 && i < 16; ++i)
-          if (i < 8 * a.S1) xr[i] = feature(xn, i);
-      }
-      float v[8];
+        for (int c = 0; c < NCB; ++c)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (2 * s + (j >> 2) < MB) ? relu(acc[2 * s + (j >> 2) < MB ? 2 * s + (j >> 2) : 0][j & 3]) : 0.0f;
-      uint4 bh, bl;
-      split8(v, bh, bl);
-      const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bl = __builtin_bit_cast(bf16x8, bl);
+          for (int i = 4 * s; i < 4 * s + 4 && i < 16; ++i)
+            if (i < 8 * a.S1) xr[c][i] = feature(xn[c], i);
+      }
+      bf16x8 Bh[NCB], Bl[NCB];
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (2 * s + (j >> 2) < MB) ? relu(acc[c][2 * s + (j >> 2) < MB ? 2 * s + (j >> 2) : 0][j & 3]) : 0.0f;
+        uint4 bh, bl;
+        split8(v, bh, bl);
+        Bh[c] = __builtin_bit_cast(bf16x8, bh);
+        Bl[c] = __builtin_bit_cast(bf16x8, bl);
+      }
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
         const bf16x8 Ah = __builtin_bit_cast(bf16x8, f2[((s * 8 + mb) * 2 + 0) * 64 + lane]);
         const bf16x8 Al = __builtin_bit_cast(bf16x8, f2[((s * 8 + mb) * 2 + 1) * 64 + lane]);
-        out[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, out[mb], 0, 0, 0);
-        out[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, out[mb], 0, 0, 0);
-        out[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, out[mb], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+          out[c][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh[c], out[c][mb], 0, 0, 0);
+          out[c][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh[c], out[c][mb], 0, 0, 0);
+          out[c][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl[c], out[c][mb], 0, 0, 0);
+        }
       }
     }
     if (more && S2B * 4 < 16) {
 #pragma unroll
-      for (int i = S2B * 4; i < 16; ++i)
-        if (i < 8 * a.S1) xr[i] = feature(xn, i);
+      for (int c = 0; c < NCB; ++c)
+#pragma unroll
+        for (int i = S2B * 4; i < 16; ++i)
+          if (i < 8 * a.S1) xr[c][i] = feature(xn[c], i);
     }
     // ---- head: this lane's 4 MB rows, then the other three lane groups'
-    float d = 0.0f;
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+    for (int c = 0; c < NCB; ++c) {
+      const int64_t agent = (t * NCB + c) * 16 + r;
+      const bool valid = agent < a.A;
+      float d = 0.0f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) d = fmaf(wd[(mb * 4 + i) * 4 + g], relu(out[mb][i]), d);
-    d += __shfl_xor(d, 16);
-    d += __shfl_xor(d, 32);
-    d += bias3;
-    const float e = expf(-d);                          // exp(l1 - l0); inf for d < -88: p0 = 0, p1 = 1
-    const float p0 = 1.0f / (1.0f + e);
-    const float p1 = e > 1e30f ? 1.0f : e * p0;
-    const uint32_t draw = (uint32_t)__shfl((int)rnd, r + 16 * (it & 3));   // the group that drew for this tile
-    if (g == 0 && valid) {
-      const float u = ((float)(draw >> 8) + 0.5f) * (1.0f / 16777216.0f);
-      const int act = a.greedy ? (d >= 0.0f ? 0 : 1) : (u < p0 ? 0 : 1);   // argmax keeps the first maximum, as torch.argmax
-      a.action[agent] = (uint8_t)act;
-      if (a.a_prob) a.a_prob[agent] = act ? p1 : p0;
-      if (a.probs) {
-        a.probs[agent * 2] = p0;
-        a.probs[agent * 2 + 1] = p1;
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d = fmaf(wd[(mb * 4 + i) * 4 + g], relu(out[c][mb][i]), d);
+      d += __shfl_xor(d, 16);
+      d += __shfl_xor(d, 32);
+      d += bias3;
+      const float e = expf(-d);                          // exp(l1 - l0); inf for d < -88: p0 = 0, p1 = 1
+      const float p0 = 1.0f / (1.0f + e);
+      const float p1 = e > 1e30f ? 1.0f : e * p0;
+      const uint32_t draw = (uint32_t)__shfl((int)rnd[c], r + 16 * (it & 3));   // the group that drew for this tile
+      if (g == 0 && valid) {
+        const float u = ((float)(draw >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const int act = a.greedy ? (d >= 0.0f ? 0 : 1) : (u < p0 ? 0 : 1);   // argmax keeps the first maximum, as torch.argmax
+        a.action[agent] = (uint8_t)act;
+        if (a.a_prob) a.a_prob[agent] = act ? p1 : p0;
+        if (a.probs) {
+          a.probs[agent * 2] = p0;
+          a.probs[agent * 2 + 1] = p1;
+        }
       }
     }
   }
@@ -514,7 +551,7 @@ int mdr_actor_sample(const mdr_actor_t* actor, const float* obs, int64_t obs_pla
   a.obs = obs; a.action = action; a.a_prob = a_prob; a.probs = probs;
   a.A = nb_agents;
   a.plane = obs_plane_stride;
-  const int tile = l16 ? 16 : 32, waves = lbf ? WAVESB : (l16 ? WAVES16 : WAVES);
+  const int tile = lbf ? 16 * NCB : (l16 ? 16 : 32), waves = lbf ? WAVESB : (l16 ? WAVES16 : WAVES);
   a.ntiles = (nb_agents + tile - 1) / tile;
   a.F = actor->num_state; a.S1 = steps1(layout, actor->num_state); a.S2 = steps2(layout, actor->hidden1);
   a.k0 = (uint32_t)(seed & 0xFFFFFFFFull); a.k1 = (uint32_t)(seed >> 32);
