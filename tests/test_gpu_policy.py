@@ -156,3 +156,26 @@ def test_greedy_mode_is_the_argmax_of_a_dqn_network(layout):
     clear = (q[:, 0] - q[:, 1]).abs() > (1e-3 if layout == 2 else 1e-5)
     assert clear.float().mean() > 0.99
     assert torch.equal(a[clear].long(), q.argmax(1)[clear])
+
+
+@pytest.mark.parametrize("idx", range(48))
+def test_fuzz_random_network_shapes(idx):
+    """Random (F, H1, H2, A) at every padding edge of the three layouts against the torch forward."""
+    from mdr_amd.policy import FusedActor
+    rng = np.random.default_rng(100 + idx)
+    layout = idx % 3
+    F = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 47, 50, 51, 52, 62, 63, 64] + ([65, 100, 133] if layout == 0 else [])))
+    H1 = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 95, 96, 97, 100, 111, 112, 113, 126, 127]))
+    H2 = int(rng.choice([1, 3, 16, 17, 32, 48, 64, 99, 100, 111, 112, 113, 127]))
+    A = int(rng.choice([1, 15, 16, 17, 31, 32, 33, 63, 64, 65, 1000, 4099]))
+    actor = _actor(F, (H1, H2), seed=idx, scale=2.0)
+    fused = FusedActor.from_module(actor, layout=layout)
+    obs = torch.randn((A, F), device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(idx))
+    with torch.no_grad():
+        ref = actor(obs)
+    action, a_prob, probs = fused.sample(obs, seed=idx, step=idx, want_probs=True)
+    if layout == 2:
+        torch.testing.assert_close(probs, ref, rtol=2e-3, atol=2e-5)
+    else:
+        torch.testing.assert_close(probs, ref, rtol=1e-5, atol=2e-6)
+    assert torch.equal(a_prob, probs.gather(1, action.long()[:, None]).squeeze(1))
