@@ -327,6 +327,13 @@ int mdr_env_obs_vector_ext(mdr_env_t *env, const mdr_obs_spec_t *spec, const flo
 int64_t mdr_env_graph_room(const mdr_env_t *env);
 int mdr_env_graph_replayed(mdr_env_t *env, int64_t n, void *stream);
 
+/* What the reference's dict surface shows of ONE env after reset / step (make_cluster_obs_dict env 904-1003, rewards 330-373),
+ * gathered into one fp64 vector on the device so that a host adapter needs a single copy:
+ * out[5 N + 6] = house_temp[N] | house_mass_temp[N] (deg C) | seconds_since_off[N] | flags[N] (bit 0 on, bit 1 lockout) |
+ *                reward[N] | OD_temp, reg_signal, solar gain of the current time index, cluster_hvac_power, max_power,
+ *                artificial_ratio. */
+int mdr_env_pack(mdr_env_t *env, int32_t env_index, double *out, void *stream);
+
 int mdr_env_cursor(const mdr_env_t *env, int64_t *k, int64_t *j0);
 /* Re-create a cursor on a new handle whose buffers were cloned from another env: copy.deepcopy(env) as
  * utils.test_*_agent use it (utils.py:890, 931, 970, 1008). */

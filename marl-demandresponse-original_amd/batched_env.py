@@ -402,6 +402,17 @@ class BatchedDemandResponseEnv:
             nat.check(self._lib, self._handle, rc, "mdr_env_rollout_fused")
         return res
 
+    def pack_env(self, env_index: int = 0) -> np.ndarray:
+        """Host copy of what the dict surface shows of one env (mdr_env_pack): float64 [5 N + 6], one launch + one copy."""
+        n = self.nb_houses
+        buf = self.__dict__.get("_pack_dev")
+        if buf is None:
+            buf = self._pack_dev = torch.empty(5 * n + 6, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self._lib.mdr_env_pack(self._handle, int(env_index), C.c_void_p(buf.data_ptr()), self._stream())
+            nat.check(self._lib, self._handle, rc, "mdr_env_pack")
+        return buf.cpu().numpy()
+
     # ------------------------------------------------------------------ graph mode (device-resident cursor)
     def graph_room(self) -> int:
         """Steps the time tables still cover: how often a captured step may be replayed before ``graph_replayed``."""

@@ -503,6 +503,24 @@ int mdr_env_step(mdr_env_t* env, uint8_t* actions, int action_source, void* stre
   return interp_boundary(env, (hipStream_t)stream, nullptr);
 }
 
+int mdr_env_pack(mdr_env_t* env, int32_t env_index, double* out, void* stream) {
+  if (!env || !out) return MDR_ERR_INVALID;
+  if (!env->bound || !env->has_tables) return fail(env, MDR_ERR_UNBOUND, "no episode: call reset/load_episode and begin_episode first");
+  if (env_index < 0 || env_index >= env->cfg.nb_envs) return fail(env, MDR_ERR_INVALID, "env_index out of range");
+  if (env->k - env->j0 > env->cfg.table_steps) return fail(env, MDR_ERR_INVALID, "cursor outside the tables");
+  const mdr_buffers_t& b = env->buf;
+  const int64_t row = env->k - env->j0;
+  mdr::StepArgs a{};
+  a.Ta = b.Ta; a.Tm = b.Tm; a.sso = b.sso; a.flags = b.flags; a.reward = b.reward; a.P = b.P;
+  a.N = env->cfg.nb_houses; a.E = env->cfg.nb_envs;
+  a.od_old = b.tab_od + row * env->cfg.nb_envs;          // rows of the current time index
+  a.solar_new = b.tab_solar + row * env->cfg.nb_envs;
+  a.sig_old = b.tab_signal + row * env->cfg.nb_envs;
+  hipError_t e = mdr::launch_pack_env(a, env_index, env->cfg.temp_ref, b.max_power, b.ratio, out, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(env, e, "pack_env");
+  return MDR_OK;
+}
+
 int64_t mdr_env_graph_room(const mdr_env_t* env) {
   if (!env || !env->bound || !env->has_tables) return 0;
   int64_t room = env->cfg.table_steps - (env->k - env->j0);

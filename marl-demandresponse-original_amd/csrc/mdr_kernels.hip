@@ -320,6 +320,35 @@ __global__ void k_cursor_set(int32_t* cursor, int32_t row, int32_t k) {
   cursor[1] = k;
 }
 
+// Everything the dict adapter shows of env e after a step, as one fp64 vector (ONE launch + ONE device->host copy):
+// Ta[N] | Tm[N] (deg C) | sso[N] | flags[N] | reward[N] | OD temp, reg signal, solar gain, cluster power, max power, ratio
+__global__ __launch_bounds__(256) void k_pack_env(StepArgs a, int e, double temp_ref, const double* max_power, const double* ratio,
+                                                  double* out) {
+  const int64_t base = (int64_t)e * a.N;
+  for (int h = threadIdx.x; h < a.N; h += 256) {
+    out[h] = (double)a.Ta[base + h] + temp_ref;
+    out[a.N + h] = (double)a.Tm[base + h] + temp_ref;
+    out[2 * a.N + h] = (double)a.sso[base + h];
+    out[3 * a.N + h] = (double)a.flags[base + h];
+    out[4 * a.N + h] = (double)a.reward[base + h];
+  }
+  if (threadIdx.x == 0) {
+    double* s = out + 5 * (int64_t)a.N;
+    s[0] = (double)a.od_old[e] + temp_ref;    // od_old / solar_new / sig_old: the rows of the CURRENT time index here
+    s[1] = a.sig_old[e];
+    s[2] = (double)a.solar_new[e];
+    s[3] = a.P[e];
+    s[4] = max_power[e];
+    s[5] = ratio[e];
+  }
+}
+
+hipError_t launch_pack_env(const StepArgs& a, int e, double temp_ref, const double* max_power, const double* ratio, double* out,
+                           hipStream_t s) {
+  hipLaunchKernelGGL(k_pack_env, dim3(1), dim3(256), 0, s, a, e, temp_ref, max_power, ratio, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_cursor_advance(int32_t* cursor, hipStream_t s) {
   hipLaunchKernelGGL(k_cursor_advance, dim3(1), dim3(1), 0, s, cursor);
   return hipGetLastError();

@@ -177,10 +177,9 @@ class MADemandResponseEnv:
         self.datetime += self.time_step
         self._batched.step(torch.from_numpy(cmd).to(self._batched.device))
         self._pull()
-        reward = self._batched.t["reward"][0].cpu().numpy()
         obs_dict = self._make_obs_dict()
-        rewards_dict = {i: float(reward[i]) for i in self.agent_ids}
-        dones_dict = {i: False for i in self.agent_ids}   # env 375-390
+        rewards_dict = dict(zip(self.agent_ids, self._host["reward"].tolist()))
+        dones_dict = dict.fromkeys(self.agent_ids, False)   # env 375-390
         info_dict = {"cluster_hvac_power": float(self._host["P"])}
         if "perlin" in self._batched.spec.signal_mode_name:
             self.power_grid.nb_steps += 1
@@ -188,15 +187,21 @@ class MADemandResponseEnv:
 
     # ------------------------------------------------------------------ device -> host
     def _pull(self):
+        """Everything the dicts need, packed on the device into one float64 vector and fetched with ONE copy + sync
+        (a dozen separate .cpu() / .item() calls cost ~20 us each and dominated the step at the reference's own sizes)."""
         b = self._batched
-        flags = b.t["flags"][0].cpu().numpy()
+        n = self.nb_agents
+        k = b.steps_taken
+        pack = b.pack_env(0)
+        flags = pack[3 * n:4 * n].astype(np.uint8)
+        od, S, solar, P, max_power, ratio = pack[5 * n:].tolist()
         self._host = {
-            "Ta": b.house_temp()[0].cpu().numpy(), "Tm": b.house_mass_temp()[0].cpu().numpy(),
-            "sso": b.t["sso"][0].cpu().numpy(), "on": (flags & 1).astype(bool), "lock": (flags & 2).astype(bool),
-            "od": b.od_temp()[0].item(), "S": b.reg_signal()[0].item(),
+            "Ta": pack[0:n], "Tm": pack[n:2 * n], "sso": pack[2 * n:3 * n].astype(np.int64),
+            "on": (flags & 1).astype(bool), "lock": (flags & 2).astype(bool), "reward": pack[4 * n:5 * n].astype(np.float32),
+            "od": od, "S": S,
             # SingleHouse.current_solar_gain is 0 until the first update_temperature (env 573)
-            "solar": b.solar_gain()[0].item() if b.steps_taken > 0 else 0,
-            "P": b.t["P"][0].item(), "max_power": b.t["max_power"][0].item(), "ratio": b.t["ratio"][0].item(),
+            "solar": solar if k > 0 else 0,
+            "P": P, "max_power": max_power, "ratio": ratio,
         }
 
     # ------------------------------------------------------------------ communication links (env 806-902)
@@ -210,57 +215,78 @@ class MADemandResponseEnv:
             return random.sample([j for j in self.agent_ids if j != i], k=nb_comm(cp))
         return self._links[i]
 
-    def _message(self, j, empty):
-        """SingleHouse.message (env 624-662)."""
+    _MSG_KEYS = ("current_temp_diff_to_target", "hvac_seconds_since_off", "hvac_curr_consumption",
+                 "hvac_max_consumption", "hvac_lockout_duration")
+
+    def _message_keys(self):
         mp = self.default_env_prop["message_properties"]
-        h, s = self._host, self._static
-        if empty:
-            vals = [0, 0, 0, 0, 0]
-        else:
-            pmax = float(s["capacity"][j]) / float(s["COP"][j])
-            vals = [float(h["Ta"][j]) - float(s["target"][j]), int(h["sso"][j]),
-                    pmax if h["on"][j] else 0, pmax, int(s["lockout"][j])]
-        m = dict(zip(("current_temp_diff_to_target", "hvac_seconds_since_off", "hvac_curr_consumption",
-                      "hvac_max_consumption", "hvac_lockout_duration"), vals))
+        keys = list(self._MSG_KEYS)
         if mp["thermal"]:
-            for k in ("Ua", "Cm", "Ca", "Hm"):
-                m["house_" + k] = 0 if empty else float(s[k][j])
+            keys += ["house_Ua", "house_Cm", "house_Ca", "house_Hm"]
         if mp["hvac"]:
-            m["hvac_COP"] = 0 if empty else float(s["COP"][j])
-            m["hvac_cooling_capacity"] = 0 if empty else float(s["capacity"][j])
-            m["hvac_latent_cooling_fraction"] = 0 if empty else float(s["latent"][j])
-        return m
+            keys += ["hvac_COP", "hvac_cooling_capacity", "hvac_latent_cooling_fraction"]
+        return keys
+
+    def _static_lists(self):
+        """Python-float copies of the per-episode constants (bulk .tolist() once per episode, not per step and element)."""
+        st = getattr(self, "_static_py", None)
+        if st is None or st[0] is not self._static:
+            s = self._static
+            py = {k: s[k].astype(np.float64).tolist() for k in ("target", "deadband", "Ua", "Cm", "Ca", "Hm", "COP", "capacity", "latent")}
+            py["lockout"] = [int(v) for v in s["lockout"].tolist()]
+            py["pmax"] = [c / p for c, p in zip(py["capacity"], py["COP"])]
+            st = self._static_py = (self._static, py)
+        return st[1]
 
     # ------------------------------------------------------------------ observation dict (env 904-1003, 212-232)
     def _make_obs_dict(self):
-        h, s = self._host, self._static
-        defect = self.default_env_prop["cluster_prop"]["comm_defect_prob"]
+        h, py = self._host, self._static_lists()
+        cp = self.default_env_prop["cluster_prop"]
+        mp = self.default_env_prop["message_properties"]
+        defect = cp["comm_defect_prob"]
+        Ta, Tm, sso = h["Ta"].tolist(), h["Tm"].tolist(), h["sso"].tolist()
+        on, lock = h["on"].tolist(), h["lock"].tolist()
+        mkeys = self._message_keys()
+        # SingleHouse.message (env 624-662) of every house once; the receivers get their own copy of it below
+        msg_vals = []
+        for j in self.agent_ids:
+            v = [Ta[j] - py["target"][j], sso[j], py["pmax"][j] if on[j] else 0, py["pmax"][j], py["lockout"][j]]
+            if mp["thermal"]:
+                v += [py["Ua"][j], py["Cm"][j], py["Ca"][j], py["Hm"][j]]
+            if mp["hvac"]:
+                v += [py["COP"][j], py["capacity"][j], py["latent"][j]]
+            msg_vals.append(v)
+        empty = dict.fromkeys(mkeys, 0)
+        random_links = cp["agents_comm_mode"] == "random_sample"
+        od, dtm, solar, S, P = h["od"], self.datetime, h["solar"], h["S"], h["P"]
         obs = {}
         for i in self.agent_ids:
-            d = {
-                "OD_temp": h["od"],
-                "datetime": self.datetime,
-                "house_temp": float(h["Ta"][i]),
-                "house_mass_temp": float(h["Tm"][i]),
-                "hvac_turned_on": bool(h["on"][i]),
-                "hvac_seconds_since_off": int(h["sso"][i]),
-                "hvac_lockout": bool(h["lock"][i]),
-                "house_target_temp": float(s["target"][i]),
-                "house_deadband": float(s["deadband"][i]),
-                "house_Ua": float(s["Ua"][i]),
-                "house_Cm": float(s["Cm"][i]),
-                "house_Ca": float(s["Ca"][i]),
-                "house_Hm": float(s["Hm"][i]),
-                "house_solar_gain": h["solar"],
-                "hvac_COP": float(s["COP"][i]),
-                "hvac_cooling_capacity": float(s["capacity"][i]),
-                "hvac_latent_cooling_fraction": float(s["latent"][i]),
-                "hvac_lockout_duration": int(s["lockout"][i]),
+            senders = self._neighbours(i) if random_links else self._links[i]
+            # one np.random.rand() per link, in link order (env 992): the same stream as the reference consumes
+            keep = np.random.rand(len(senders)) > defect if senders else ()
+            obs[i] = {
+                "OD_temp": od,
+                "datetime": dtm,
+                "house_temp": Ta[i],
+                "house_mass_temp": Tm[i],
+                "hvac_turned_on": on[i],
+                "hvac_seconds_since_off": sso[i],
+                "hvac_lockout": lock[i],
+                "house_target_temp": py["target"][i],
+                "house_deadband": py["deadband"][i],
+                "house_Ua": py["Ua"][i],
+                "house_Cm": py["Cm"][i],
+                "house_Ca": py["Ca"][i],
+                "house_Hm": py["Hm"][i],
+                "house_solar_gain": solar,
+                "hvac_COP": py["COP"][i],
+                "hvac_cooling_capacity": py["capacity"][i],
+                "hvac_latent_cooling_fraction": py["latent"][i],
+                "hvac_lockout_duration": py["lockout"][i],
+                "message": [dict(zip(mkeys, msg_vals[j])) if ok else dict(empty) for j, ok in zip(senders, keep)],
+                "reg_signal": S,
+                "cluster_hvac_power": P,
             }
-            d["message"] = [self._message(j, not (np.random.rand() > defect)) for j in self._neighbours(i)]
-            d["reg_signal"] = h["S"]
-            d["cluster_hvac_power"] = h["P"]
-            obs[i] = d
         return obs
 
     # ------------------------------------------------------------------ copy.deepcopy(env) (utils.py:890-1008)
