@@ -128,3 +128,20 @@ def test_deepcopy_snapshot_like_test_agents_use():
     assert before != [o_twin[i]["house_temp"] for i in range(g.N)]
     assert [o_env[i]["house_temp"] for i in range(g.N)] == [o_twin[i]["house_temp"] for i in range(g.N)]
     assert twin.datetime == env.datetime
+
+
+@pytest.mark.gpu
+def test_norm_states_equals_normStateDict_of_the_dicts():
+    """env.norm_states() (device) == the reference's normStateDict applied to the adapter's own dicts, agent by agent."""
+    import mdr_amd
+    cfg = mdr_amd.default_config()
+    cfg["default_env_prop"]["cluster_prop"]["nb_agents"] = 14
+    cfg["default_env_prop"]["power_grid_prop"]["base_power_mode"] = "constant"
+    env = mdr_amd.MADemandResponseEnv(cfg, seed=11)
+    obs = env.reset()
+    for t in range(6):
+        got = env.norm_states()
+        want = np.array([norm_state_vector(obs[i], cfg) for i in range(14)])
+        assert got.shape == want.shape == (14, 51)
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
+        obs, _, _, _ = env.step({i: (t + i) % 3 == 0 for i in obs})
