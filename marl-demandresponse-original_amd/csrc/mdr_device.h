@@ -246,55 +246,67 @@ __device__ __forceinline__ double dpp_f64(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// `pen` (wave-uniform): the penalty sum / max are wanted too.  The multi-step kernels pass false in the individual_L2 mode,
+// where only the cluster power is reduced - a third of their per-step vector instructions were these exchanges.
 template <int CTRL, int ROW_MASK = 0xF>
-__device__ __forceinline__ void red3_dpp(Red3& v) {
+__device__ __forceinline__ void red3_dpp(Red3& v, bool pen = true) {
   v.sum_p += dpp_f64<CTRL, ROW_MASK>(v.sum_p);
-  v.sum_pen += dpp_f64<CTRL, ROW_MASK>(v.sum_pen);
-  v.max_pen = fmaxf(v.max_pen, dpp_f32<CTRL, ROW_MASK>(v.max_pen));   // penalties are >= 0: 0 is the identity
+  if (pen) {
+    v.sum_pen += dpp_f64<CTRL, ROW_MASK>(v.sum_pen);
+    v.max_pen = fmaxf(v.max_pen, dpp_f32<CTRL, ROW_MASK>(v.max_pen));   // penalties are >= 0: 0 is the identity
+  }
 }
 
 // Reduction over groups of WIDTH consecutive lanes (WIDTH a power of two <= 64); every lane of a group ends with the
 // group's totals.  Distances 1..8 by DPP; 16 by one bpermute butterfly (WIDTH == 32) or, for the full wavefront, the
 // row broadcasts + a scalar read of lane 63.
 template <int WIDTH>
-__device__ __forceinline__ Red3 lanes_reduce(Red3 v) {
-  if constexpr (WIDTH >= 2) red3_dpp<DPP_QUAD_SWAP1>(v);
-  if constexpr (WIDTH >= 4) red3_dpp<DPP_QUAD_SWAP2>(v);
-  if constexpr (WIDTH >= 8) red3_dpp<DPP_ROW_HALF_MIRROR>(v);
-  if constexpr (WIDTH >= 16) red3_dpp<DPP_ROW_MIRROR>(v);
+__device__ __forceinline__ Red3 lanes_reduce(Red3 v, bool pen = true) {
+  if constexpr (WIDTH >= 2) red3_dpp<DPP_QUAD_SWAP1>(v, pen);
+  if constexpr (WIDTH >= 4) red3_dpp<DPP_QUAD_SWAP2>(v, pen);
+  if constexpr (WIDTH >= 8) red3_dpp<DPP_ROW_HALF_MIRROR>(v, pen);
+  if constexpr (WIDTH >= 16) red3_dpp<DPP_ROW_MIRROR>(v, pen);
   if constexpr (WIDTH == 32) {
     v.sum_p += __shfl_xor(v.sum_p, 16, 64);
-    v.sum_pen += __shfl_xor(v.sum_pen, 16, 64);
-    v.max_pen = fmaxf(v.max_pen, __shfl_xor(v.max_pen, 16, 64));
+    if (pen) {
+      v.sum_pen += __shfl_xor(v.sum_pen, 16, 64);
+      v.max_pen = fmaxf(v.max_pen, __shfl_xor(v.max_pen, 16, 64));
+    }
   }
   if constexpr (WIDTH == 64) {
-    red3_dpp<DPP_ROW_BCAST15, 0xA>(v);   // rows 1 and 3 += row 0 / row 2 totals
-    red3_dpp<DPP_ROW_BCAST31, 0xC>(v);   // rows 2 and 3 += the total of rows 0-1: lane 63 holds everything
+    red3_dpp<DPP_ROW_BCAST15, 0xA>(v, pen);   // rows 1 and 3 += row 0 / row 2 totals
+    red3_dpp<DPP_ROW_BCAST31, 0xC>(v, pen);   // rows 2 and 3 += the total of rows 0-1: lane 63 holds everything
     v.sum_p = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v.sum_p), 63), __builtin_amdgcn_readlane(__double2loint(v.sum_p), 63));
-    v.sum_pen = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v.sum_pen), 63), __builtin_amdgcn_readlane(__double2loint(v.sum_pen), 63));
-    v.max_pen = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.max_pen), 63));
+    if (pen) {
+      v.sum_pen = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v.sum_pen), 63), __builtin_amdgcn_readlane(__double2loint(v.sum_pen), 63));
+      v.max_pen = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.max_pen), 63));
+    }
   }
   return v;
 }
 
 template <int THREADS>
-__device__ __forceinline__ Red3 block_reduce(Red3 v, double* lds /* [3][THREADS/64] */) {
+__device__ __forceinline__ Red3 block_reduce(Red3 v, double* lds /* [3][THREADS/64] */, bool pen = true) {
   constexpr int WAVES = THREADS / 64;
-  v = lanes_reduce<64>(v);
+  v = lanes_reduce<64>(v, pen);
   if constexpr (WAVES == 1) return v;
   const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
     lds[wave] = v.sum_p;
-    lds[WAVES + wave] = v.sum_pen;
-    lds[2 * WAVES + wave] = (double)v.max_pen;
+    if (pen) {
+      lds[WAVES + wave] = v.sum_pen;
+      lds[2 * WAVES + wave] = (double)v.max_pen;
+    }
   }
   __syncthreads();
   Red3 t{0.0, 0.0, 0.0f};
 #pragma unroll
   for (int w = 0; w < WAVES; ++w) {  // same order in every thread: identical totals, no second barrier
     t.sum_p += lds[w];
-    t.sum_pen += lds[WAVES + w];
-    t.max_pen = fmaxf(t.max_pen, (float)lds[2 * WAVES + w]);
+    if (pen) {
+      t.sum_pen += lds[WAVES + w];
+      t.max_pen = fmaxf(t.max_pen, (float)lds[2 * WAVES + w]);
+    }
   }
   return t;
 }

@@ -647,6 +647,7 @@ __device__ __forceinline__ EnvRow window_get(const EnvRow& w, int src_lane) {
 template <int VEC, int TILES, int THREADS, bool WINDOW>
 __global__ __launch_bounds__(THREADS) void k_rollout_fused(StepArgs a, RolloutArgs ro) {
   __shared__ double lds[2][3 * (THREADS / 64)];
+  const bool need_pen = a.penalty_mode != MDR_PENALTY_INDIVIDUAL_L2;   // common penalty modes need the env's penalty sum / max
   const int e = blockIdx.x;
   const int64_t base = (int64_t)e * a.N;
   HouseIn hs[TILES][VEC];
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(THREADS) void k_rollout_fused(StepArgs a, RolloutAr
         terr += (double)te;
       }
     }
-    tot = block_reduce<THREADS>(acc, lds[s & 1]);
+    tot = block_reduce<THREADS>(acc, lds[s & 1], need_pen);
     sig_term = signal_term(a, tot.sum_p, er.sig_old);
 #pragma unroll
     for (int t = 0; t < TILES; ++t)
@@ -891,6 +892,7 @@ __global__ __launch_bounds__(256) void k_step_single_house(StepArgs a) {
 // same reduction tree as k_step_group, so both end bit for bit in the same state), no LDS, no barrier
 template <int GROUP, int VEC, bool WINDOW>
 __global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs ro) {
+  const bool need_pen = a.penalty_mode != MDR_PENALTY_INDIVIDUAL_L2;
   const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / GROUP;
   const int lane = threadIdx.x % GROUP;
   const bool env_ok = gid < a.E;
@@ -975,7 +977,7 @@ __global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs r
       acc.sum_pen = (double)ps;
       terr += (double)te;
     }
-    tot = lanes_reduce<GROUP>(acc);
+    tot = lanes_reduce<GROUP>(acc, need_pen);
     sig_term = signal_term(a, tot.sum_p, er.sig_old);
     if (active) {
 #pragma unroll
