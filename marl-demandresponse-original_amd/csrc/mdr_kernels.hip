@@ -648,6 +648,7 @@ template <int VEC, int TILES, int THREADS, bool WINDOW>
 __global__ __launch_bounds__(THREADS) void k_rollout_fused(StepArgs a, RolloutArgs ro) {
   __shared__ double lds[2][3 * (THREADS / 64)];
   const bool need_pen = a.penalty_mode != MDR_PENALTY_INDIVIDUAL_L2;   // common penalty modes need the env's penalty sum / max
+  const bool want_rsum = ro.reward_sum != nullptr, want_terr = ro.sq_temp_error_sum != nullptr;   // accumulators nobody asked for are not computed
   const int e = blockIdx.x;
   const int64_t base = (int64_t)e * a.N;
   HouseIn hs[TILES][VEC];
@@ -727,8 +728,10 @@ __global__ __launch_bounds__(THREADS) void k_rollout_fused(StepArgs a, RolloutAr
           p += o[t][v].power;
           ps += o[t][v].pen;
           acc.max_pen = fmaxf(acc.max_pen, o[t][v].pen);
-          const float d = o[t][v].Ta - hs[t][v].target;
-          te = fmaf(d, d, te);
+          if (want_terr) {
+            const float d = o[t][v].Ta - hs[t][v].target;
+            te = fmaf(d, d, te);
+          }
         }
         acc.sum_p += (double)p;
         acc.sum_pen += (double)ps;
@@ -737,13 +740,15 @@ __global__ __launch_bounds__(THREADS) void k_rollout_fused(StepArgs a, RolloutAr
     }
     tot = block_reduce<THREADS>(acc, lds[s & 1], need_pen);
     sig_term = signal_term(a, tot.sum_p, er.sig_old);
+    if (want_rsum) {   // (the last step's reward is written by the epilogue either way)
 #pragma unroll
-    for (int t = 0; t < TILES; ++t)
-      if (live[t]) {
+      for (int t = 0; t < TILES; ++t)
+        if (live[t]) {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v)
-          rsum[t][v] = __fadd_rn(rsum[t][v], reward_value(a, o[t][v].pen, tot.sum_pen, tot.max_pen, sig_term));
-      }
+          for (int v = 0; v < VEC; ++v)
+            rsum[t][v] = __fadd_rn(rsum[t][v], reward_value(a, o[t][v].pen, tot.sum_pen, tot.max_pen, sig_term));
+        }
+    }
     if (threadIdx.x == 0) {
       if (ro.power_trace) ro.power_trace[row] = tot.sum_p;
       const double d = er.sig_new - tot.sum_p;
@@ -893,6 +898,7 @@ __global__ __launch_bounds__(256) void k_step_single_house(StepArgs a) {
 template <int GROUP, int VEC, bool WINDOW>
 __global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs ro) {
   const bool need_pen = a.penalty_mode != MDR_PENALTY_INDIVIDUAL_L2;
+  const bool want_rsum = ro.reward_sum != nullptr;
   const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / GROUP;
   const int lane = threadIdx.x % GROUP;
   const bool env_ok = gid < a.E;
@@ -980,8 +986,10 @@ __global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs r
     tot = lanes_reduce<GROUP>(acc, need_pen);
     sig_term = signal_term(a, tot.sum_p, er.sig_old);
     if (active) {
+      if (want_rsum) {
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) rsum[v] = __fadd_rn(rsum[v], reward_value(a, o[v].pen, tot.sum_pen, tot.max_pen, sig_term));
+        for (int v = 0; v < VEC; ++v) rsum[v] = __fadd_rn(rsum[v], reward_value(a, o[v].pen, tot.sum_pen, tot.max_pen, sig_term));
+      }
       if (lane == 0) {
         if (ro.power_trace) ro.power_trace[row] = tot.sum_p;
         const double d = er.sig_new - tot.sum_p;
