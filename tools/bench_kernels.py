@@ -62,8 +62,8 @@ def main():
         env.reset()
         env.rollout(10)
         F = env.obs_vector_length()
-        report("C3 obs_vector planes F=%d" % F, timeit(lambda: env.obs_vector("planes"), 20), 4096 * 1024, 4 * F + 25)
-        report("C3 obs_vector rows F=%d" % F, timeit(lambda: env.obs_vector("rows"), 20), 4096 * 1024, 4 * F + 25)
+        report("C3 obs_vector planes F=%d" % F, timeit(lambda: env.obs_vector("planes"), 200), 4096 * 1024, 4 * F + 25)
+        report("C3 obs_vector rows F=%d" % F, timeit(lambda: env.obs_vector("rows"), 200), 4096 * 1024, 4 * F + 25)
         del env
     if "obs_small" in what:
         for (E, N) in ((209715, 20), (83886, 50), (32768, 128)):
