@@ -1,8 +1,13 @@
 """Differential fuzzing: random (shape, config) combinations, device vs oracle for a short episode.  Deterministic
 (seeded) so that a failure is reproducible by its case number."""
+import os
+
 import numpy as np
 import pytest
 import torch
+
+# MDR_FUZZ_SCALE=k runs k times as many seeded cases (a one-off campaign; the default suite stays at a few seconds)
+SCALE = max(1, int(os.environ.get("MDR_FUZZ_SCALE", "1")))
 
 pytestmark = pytest.mark.gpu
 
@@ -44,7 +49,7 @@ def _case(idx):
     return cfg, E, N, int(rng.integers(0, 2 ** 40)), int(rng.integers(0, 5)), float(rng.uniform(0.2, 0.8)), int(rng.choice([3, 8, 64]))
 
 
-@pytest.mark.parametrize("idx", range(120))
+@pytest.mark.parametrize("idx", range(120 * SCALE))
 def test_fuzz_device_vs_oracle(idx):
     import mdr_amd
     from oracle import mdr_oracle as mo
@@ -103,7 +108,7 @@ def _obs_case(idx):
     return cfg, E, N, int(rng.integers(0, 2 ** 40))
 
 
-@pytest.mark.parametrize("idx", range(80))
+@pytest.mark.parametrize("idx", range(80 * SCALE))
 def test_fuzz_obs_vector_vs_oracle(idx):
     import random
     import mdr_amd
@@ -137,7 +142,7 @@ def test_fuzz_obs_vector_vs_oracle(idx):
     np.testing.assert_allclose(env.obs_vector("planes").cpu().numpy(), np.moveaxis(ref, -1, 0), rtol=3e-5, atol=3e-6, err_msg="planes, case %d" % idx)
 
 
-@pytest.mark.parametrize("idx", range(60))
+@pytest.mark.parametrize("idx", range(60 * SCALE))
 def test_fuzz_fused_rollout_equals_stepwise(idx):
     """mdr_env_rollout_fused ends in the stepwise path's state bit for bit, for any shape / table length / step count."""
     import mdr_amd
@@ -204,7 +209,7 @@ def _interp_case(idx):
     return cfg, E, N, int(rng.integers(0, 2 ** 40)), values, axes
 
 
-@pytest.mark.parametrize("idx", range(50))
+@pytest.mark.parametrize("idx", range(50 * SCALE))
 def test_fuzz_interpolation_mode_vs_oracle(idx):
     """Random base-power grids (axis lengths, values, queries outside the axes), update periods ceil(300 / dt) from 1 to 75
     steps, N below / at / above the 100-house sampling limit."""
