@@ -77,6 +77,21 @@ def cpu_baseline(cfg_full, seconds):
     except Exception as exc:   # no compiler on the box: the Python port above still stands
         out["c_port_value"] = None
         out["c_port_sample"] = "unavailable: %s" % exc
+    try:   # the vectorised NumPy oracle (fp64, [E, N] arrays): SURVEY 8d's third CPU form
+        import time
+        import numpy as np
+        from oracle import mdr_oracle as mo
+        ora = mo.OracleEnv(cfg, nb_envs=4).reset(seed=2024, episode=0)
+        nsteps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < min(3.0, seconds):
+            ora.step(ora.bangbang_actions().astype(np.uint8))
+            nsteps += 1
+        el = time.perf_counter() - t0
+        out["numpy_value"] = 4 * N_HOUSES * nsteps / el
+        out["numpy_sample"] = "oracle/mdr_oracle.py (vectorised NumPy fp64), 4 envs x %d houses x %d steps, %.1f s, 1 process" % (N_HOUSES, nsteps, el)
+    except Exception as exc:
+        out["numpy_value"] = None
+        out["numpy_sample"] = "unavailable: %s" % exc
     return out
 
 
