@@ -53,9 +53,11 @@ class BatchedDemandResponseEnv:
         self.test = test
         self.spec: EnvSpec = flatten_config(config, test=test)
         self.device = torch.device(device if device is not None else "cuda:0")
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.nb_envs = int(nb_envs)
         self.nb_agents = self.spec.nb_houses_total
         self.house_offset, self.nb_houses = (0, self.nb_agents) if house_shard is None else map(int, house_shard)
+        self._act_shape = torch.Size((self.nb_envs, self.nb_houses))
         self.sharded = house_shard is not None and self.nb_houses != self.nb_agents
         self.process_group = process_group
         self.env_offset = int(env_offset)
@@ -319,15 +321,23 @@ class BatchedDemandResponseEnv:
             return self.t["actions"].data_ptr()
         if actions.dtype == torch.bool:
             actions = actions.view(torch.uint8)
+        ptr = actions.data_ptr()
         if (actions.dtype != torch.uint8 or actions.device != self.device or not actions.is_contiguous()
-                or tuple(actions.shape) != (self.nb_envs, self.nb_houses) or actions.data_ptr() % 4 != 0):
+                or actions.shape != self._act_shape or ptr % 4 != 0):
             self.t["actions"].copy_(actions.reshape(self.nb_envs, self.nb_houses).to(self.device) != 0)
             return self.t["actions"].data_ptr()
         self._keep_actions = actions
-        return actions.data_ptr()
+        return ptr
 
     def _step(self, ptr, source):
         if not self.sharded:
+            # the launch-bound regime is host-bound from Python: skip the device context manager when the device is
+            # already current (the common case) - it costs more than the ctypes call itself
+            if torch.cuda.current_device() == self._dev_index:
+                rc = self._lib.mdr_env_step(self._handle, ptr, source, torch.cuda.current_stream().cuda_stream)
+                if rc != 0:
+                    nat.check(self._lib, self._handle, rc, "mdr_env_step")
+                return
             with torch.cuda.device(self.device):
                 rc = self._lib.mdr_env_step(self._handle, C.c_void_p(ptr), source, self._stream())
                 nat.check(self._lib, self._handle, rc, "mdr_env_step")
