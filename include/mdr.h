@@ -308,7 +308,9 @@ int mdr_env_obs_vector(mdr_env_t *env, const mdr_obs_spec_t *spec, float *out, v
  *   mdr_env_obs_vector_ext  - as mdr_env_obs_vector, but message slot m of house h is the record
  *                             messages[e][spec->links[h * nb_comm + m]] (links = record slots, not house ids).
  * Own columns, comm defects (drawn per global house index) and layouts are those of mdr_env_obs_vector; an unsharded
- * handle may use the pair too (entries_per_env = nb_houses, links = house ids).  random_links is not available here. */
+ * handle may use the pair too (entries_per_env = nb_houses, links = house ids).  With random_links the senders are drawn
+ * among ALL houses of the env, so `messages` must hold every house's record at slot = global house id
+ * (entries_per_env >= nb_houses_total; mdr_env_obs_messages then gets `messages + house_offset * fields`). */
 int32_t mdr_obs_message_fields(const mdr_obs_spec_t *spec);
 int mdr_env_obs_messages(mdr_env_t *env, const mdr_obs_spec_t *spec, float *messages, int64_t entries_per_env, void *stream);
 int mdr_env_obs_vector_ext(mdr_env_t *env, const mdr_obs_spec_t *spec, const float *messages, int64_t entries_per_env,

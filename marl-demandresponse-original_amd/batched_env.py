@@ -535,21 +535,26 @@ class BatchedDemandResponseEnv:
 
     # sharded houses: SURVEY 8e "halo exchange" of the neighbour messages
     def _halo_plan(self):
-        from .comm import links_array
+        from .comm import links_array, nb_comm
         from .sharding import HaloPlan
         plan = getattr(self, "_halo", None)
         if plan is None:
             cluster = self.config["default_env_prop"]["cluster_prop"]
-            if cluster["agents_comm_mode"] == "random_sample" and not getattr(self, "_links_forced", False):
-                raise NotImplementedError("agents_comm_mode 'random_sample' is not available over sharded houses "
-                                          "(every house would need every other house's message each step)")
-            links = self._links_global if getattr(self, "_links_forced", False) else links_array(cluster)
             ranges, rank = self._exchange().ranges(self)
-            plan = self._halo = HaloPlan(links, ranges, rank).to(self.device)
+            if cluster["agents_comm_mode"] == "random_sample" and not getattr(self, "_links_forced", False):
+                # senders are re-drawn among ALL houses every step: every shard exports all its records (16-44 B per
+                # house and env) and the record slots are global house ids
+                plan = self._halo = HaloPlan.everything(ranges, rank, nb_comm(cluster)).to(self.device)
+            else:
+                links = self._links_global if getattr(self, "_links_forced", False) else links_array(cluster)
+                plan = self._halo = HaloPlan(links, ranges, rank).to(self.device)
         return plan
 
     def _obs_spec_sharded(self, layout, plan):
         spec = self._obs_spec(layout, with_links=False)
+        if plan.all_records:             # random_sample: slots are global house ids, drawn in the kernel
+            spec.random_links = 1
+            return spec
         spec.random_links = 0
         spec.nb_comm = int(plan.slots.shape[1])
         spec.links = plan.slots_dev.data_ptr() if spec.nb_comm > 0 else None
@@ -566,16 +571,22 @@ class BatchedDemandResponseEnv:
         if msg is None or tuple(msg.shape) != (E, plan.entries, mf):
             msg = self._msg = torch.zeros((E, plan.entries, mf), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            rc = self._lib.mdr_env_obs_messages(self._handle, C.byref(spec), C.c_void_p(msg.data_ptr()), plan.entries, self._stream())
+            # local records at slots [local_base, local_base + n_local): 0, or the shard's house offset when slots are global ids
+            ptr = msg.data_ptr() + plan.local_base * mf * 4
+            rc = self._lib.mdr_env_obs_messages(self._handle, C.byref(spec), C.c_void_p(ptr), plan.entries, self._stream())
             nat.check(self._lib, self._handle, rc, "mdr_env_obs_messages")
         padded = torch.zeros((E, plan.export_max, mf), dtype=torch.float32, device=self.device)
         if len(plan.export_idx):
-            padded[:, :len(plan.export_idx)] = msg[:, plan.export_dev]
+            padded[:, :len(plan.export_idx)] = msg[:, plan.export_dev + plan.local_base]
         return padded
 
     def _obs_from_gathered(self, layout, gathered) -> torch.Tensor:
         plan = self._halo_plan()
-        if plan.halo:
+        if plan.all_records:
+            for (off, cnt), block in zip(plan.ranges, gathered):      # every shard's records to their global slots
+                if off != plan.local_base:
+                    self._msg[:, off:off + cnt] = block[:, :cnt]
+        elif plan.halo:
             self._msg[:, plan.n_local:] = plan.pick(gathered)
         return self._obs_launch(layout, self._obs_spec_sharded(layout, plan), None, self._msg)
 

@@ -712,6 +712,7 @@ static int obs_args(mdr_env_t* env, const mdr_obs_spec_t* spec, bool need_layout
   if (a.out_plane < a.plane) return fail(env, MDR_ERR_INVALID, "out_plane_stride smaller than nb_envs * nb_houses");
   a.k = env->k;
   a.E = c.nb_envs; a.N = c.nb_houses; a.c = spec->nb_comm; a.F = mdr::obs_vector_length(*spec); a.dt = c.time_step;
+  a.n_total = c.nb_houses_total;
   a.f_hour = spec->state_hour; a.f_day = spec->state_day; a.f_solar = spec->state_solar_gain;
   a.f_thermal = spec->state_thermal; a.f_hvac = spec->state_hvac;
   a.m_thermal = spec->message_thermal; a.m_hvac = spec->message_hvac;
@@ -769,8 +770,10 @@ int mdr_env_obs_vector_ext(mdr_env_t* env, const mdr_obs_spec_t* spec, const flo
   int rc = obs_args(env, spec, true, &a);
   if (rc == MDR_OK) rc = sync_cursor(env, (hipStream_t)stream);
   if (rc != MDR_OK) return rc;
-  if (spec->random_links) return fail(env, MDR_ERR_UNSUPPORTED, "random_sample links need every house's message: not available through record slots");
-  if (spec->nb_comm > 0 && (!messages || !spec->links)) return fail(env, MDR_ERR_INVALID, "messages and a link table of record slots are required");
+  if (spec->random_links && entries_per_env < env->cfg.nb_houses_total)
+    return fail(env, MDR_ERR_INVALID, "random_sample links draw among all houses of the env: messages must hold every house's record, slot = house id");
+  if (spec->nb_comm > 0 && (!messages || (!spec->links && !spec->random_links)))
+    return fail(env, MDR_ERR_INVALID, "messages and a link table of record slots are required");
   if (entries_per_env < 0) return fail(env, MDR_ERR_INVALID, "entries_per_env must be >= 0");
   a.out = out;
   a.msg_ext_in = messages;

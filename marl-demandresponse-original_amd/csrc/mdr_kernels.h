@@ -117,6 +117,7 @@ struct ObsArgs {
   const int32_t* cursor;    // graph mode: {table row, time index} on the device (sig_now / od_now / solar_now address row 0, k unused)
   int32_t cursor_max;
   int E, N, c, F, dt;
+  int n_total;              // houses of the whole env (== N unless the houses are sharded): random_sample draws among them
   int f_hour, f_day, f_solar, f_thermal, f_hvac, m_thermal, m_hvac;
   int64_t env_offset, house_offset;
   uint32_t k0, k1, episode;

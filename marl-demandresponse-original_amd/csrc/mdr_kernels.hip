@@ -1166,7 +1166,8 @@ struct LinkSampler {
   u32x4 buf{0, 0, 0, 0};
 
   __device__ __forceinline__ int next(const ObsArgs& a, int e, int h) {
-    const uint32_t D = (uint32_t)(a.N - 1);   // >= nb_comm >= 1
+    const uint32_t D = (uint32_t)(a.n_total - 1);   // >= nb_comm >= 1; the whole env's other houses
+    const int hg = h + (int)a.house_offset;         // global id of the receiving house
     int pick;
     bool taken;
     do {
@@ -1184,7 +1185,7 @@ struct LinkSampler {
     for (int t = 0; t < MAX_RANDOM_LINKS; ++t)
       if (t == count) prev[t] = pick;
     ++count;
-    return pick < h ? pick : pick + 1;   // index among the OTHER houses -> house id
+    return pick < hg ? pick : pick + 1;   // index among the OTHER houses -> (global) house id
   }
 };
 
@@ -1427,7 +1428,7 @@ __global__ __launch_bounds__(256) void k_obs_vector(ObsArgs a) {
                     ++f;
                   },
                   [&](int m, int) {
-                    if (EXT) return sender_from_ext(a, e, a.links[(int64_t)h * a.c + m]);
+                    if (EXT) return sender_from_ext(a, e, RANDOM ? smp.next(a, e, h) : a.links[(int64_t)h * a.c + m]);
                     return sender_from_global(a, base + (RANDOM ? smp.next(a, e, h) : sender_id(a, h, m)));
                   });
 }
@@ -1813,8 +1814,14 @@ hipError_t launch_obs_messages(const ObsArgs& a, hipStream_t s) {
 
 hipError_t launch_obs_vector_ext(const ObsArgs& a, int layout, hipStream_t s) {
   const dim3 g((unsigned)((a.plane + 255) / 256)), b(256);
-  if (layout == MDR_OBS_PLANES) hipLaunchKernelGGL((k_obs_vector<MDR_OBS_PLANES, false, true>), g, b, 0, s, a);
-  else hipLaunchKernelGGL((k_obs_vector<MDR_OBS_ROWS, false, true>), g, b, 0, s, a);
+  if (a.random_links) {   // record slots are global house ids (the caller gathered every house's record)
+    if (layout == MDR_OBS_PLANES) hipLaunchKernelGGL((k_obs_vector<MDR_OBS_PLANES, true, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_obs_vector<MDR_OBS_ROWS, true, true>), g, b, 0, s, a);
+  } else if (layout == MDR_OBS_PLANES) {
+    hipLaunchKernelGGL((k_obs_vector<MDR_OBS_PLANES, false, true>), g, b, 0, s, a);
+  } else {
+    hipLaunchKernelGGL((k_obs_vector<MDR_OBS_ROWS, false, true>), g, b, 0, s, a);
+  }
   return hipGetLastError();
 }
 

@@ -48,6 +48,26 @@ class HaloPlan:
     export_idx int64 [X_r]         local indices of the houses this rank exports
     src_rank, src_pos int64 [H]    where each halo record sits in the gathered [world, E, export_max, mf] block"""
 
+    all_records = False      # True: every shard exports everything, record slots are global house ids (random_sample)
+    local_base = 0           # slot of this rank's first record
+
+    @classmethod
+    def everything(cls, ranges: Sequence[Tuple[int, int]], rank: int, nb_comm: int) -> "HaloPlan":
+        """agents_comm_mode 'random_sample': the senders are re-drawn among all houses every step, so every record is
+        needed everywhere; slots are global house ids, the local records sit at their global position."""
+        import numpy as np
+        plan = cls.__new__(cls)
+        off, cnt = ranges[rank]
+        plan.all_records, plan.local_base, plan.ranges = True, int(off), [(int(o), int(c)) for o, c in ranges]
+        plan.n_local = int(cnt)
+        plan.entries = int(sum(c for _, c in ranges))
+        plan.halo = plan.entries - plan.n_local
+        plan.export_idx = np.arange(cnt, dtype=np.int64)
+        plan.export_max = int(max(c for _, c in ranges))
+        plan.src_rank = plan.src_pos = np.zeros(0, dtype=np.int64)
+        plan.slots = np.zeros((cnt, nb_comm), dtype=np.int32)        # unused: the kernel draws the senders
+        return plan
+
     def __init__(self, links, ranges: Sequence[Tuple[int, int]], rank: int):
         import numpy as np
         links = np.asarray(links, dtype=np.int64)

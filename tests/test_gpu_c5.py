@@ -217,11 +217,21 @@ def test_c5_sharded_obs_vector_at_full_size():
     assert ref.shape == (1, N_C5, 51) and torch.equal(got, ref)
 
 
-def test_sharded_obs_vector_refuses_random_sample():
+@pytest.mark.parametrize("N,shards,nb_comm", [(400, 2, 5), (1001, 4, 10), (64, 3, 16)])
+def test_sharded_obs_vector_random_sample_links(N, shards, nb_comm):
+    """agents_comm_mode 'random_sample' over sharded houses: every shard gathers every record (slot = global house id) and
+    draws the same senders the unsharded kernel draws (Philox of the global house index) - bit-identical rows / planes."""
     import mdr_amd
     from mdr_amd.sharding import LocalShardGroup
-    cfg = _obs_cfg(400, "random_sample", 5, False)
-    group = LocalShardGroup(cfg, nb_envs=1, nb_shards=2, devices=("cuda:0",), seed=2)
+    cfg = _obs_cfg(N, "random_sample", nb_comm, True, defect=0.1)
+    whole = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=2, device="cuda:0", seed=2)
+    group = LocalShardGroup(cfg, nb_envs=2, nb_shards=shards, devices=("cuda:0",), seed=2)
+    whole.reset(episode=0)
     group.reset(episode=0)
-    with pytest.raises(NotImplementedError):
-        group.obs_vector("rows")
+    for t in range(3):
+        for layout in ("rows", "planes"):
+            ref = whole.obs_vector(layout)
+            got = torch.cat(group.obs_vector(layout), dim=1 if layout == "rows" else 2)
+            assert torch.equal(got, ref), "%s step %d" % (layout, t)
+        whole.step_bangbang()
+        group.step_bangbang()
