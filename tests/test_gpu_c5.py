@@ -235,3 +235,59 @@ def test_sharded_obs_vector_random_sample_links(N, shards, nb_comm):
             assert torch.equal(got, ref), "%s step %d" % (layout, t)
         whole.step_bangbang()
         group.step_bangbang()
+
+
+@pytest.mark.parametrize("idx", range(30))
+def test_fuzz_sharded_group_vs_unsharded(idx):
+    """Random shard counts / shapes / penalty modes / comm topologies / base-power modes: the in-process shard group against
+    the unsharded env (state, power, signal bit for bit; rewards to fp32 rounding; the flat observation bit for bit)."""
+    import random
+    import mdr_amd
+    from mdr_amd.comm import links_array
+    from mdr_amd.sharding import LocalShardGroup
+    from tests import golden_util as gu
+    rng = np.random.default_rng(4200 + idx)
+    shards = int(rng.integers(2, 7))
+    N = int(rng.choice([4 * shards, 64, 100, 257, 1000, 4100, 9000]))
+    N = max(N, 4 * shards)
+    E = int(rng.integers(1, 5))
+    mode = str(rng.choice(["neighbours", "closed_groups", "random_fixed", "random_sample", "no_message"]))
+    nb_comm = int(rng.integers(1, 11))
+    if mode == "closed_groups" and N % (nb_comm + 1) == nb_comm:
+        mode = "neighbours"
+    nb_comm = min(nb_comm, N - 1)
+    cfg = _obs_cfg(N, mode, nb_comm, bool(rng.integers(0, 2)), defect=float(rng.choice([0.0, 0.2])))
+    env = cfg["default_env_prop"]
+    env["reward_prop"]["temp_penalty_mode"] = str(rng.choice(["individual_L2", "common_L2", "common_max", "mixture"]))
+    env["time_step"] = int(rng.choice([4, 30, 60]))
+    interp = bool(rng.integers(0, 2))
+    kw = {}
+    if interp:
+        env["power_grid_prop"]["base_power_mode"] = "interpolation"
+        kw["interp_grid"] = gu.Golden("s12_interp_default_like").interp_grid()
+    seed = int(rng.integers(0, 2 ** 31))
+    whole = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=seed, **kw)
+    group = LocalShardGroup(cfg, nb_envs=E, nb_shards=shards, devices=("cuda:0",), seed=seed, **kw)
+    if mode == "random_fixed":
+        random.seed(idx)
+        table = links_array(env["cluster_prop"])
+        whole.set_comm_links(table)
+        for e in group.shards:
+            e.set_comm_links(table)
+    whole.reset(episode=1)
+    group.reset(episode=1)
+    bounds = np.cumsum([0] + [e.nb_houses for e in group.shards])
+    for t in range(12):
+        assert torch.equal(torch.cat(group.obs_vector("rows"), dim=1), whole.obs_vector("rows")), "obs step %d" % t
+        if t % 3 == 2:
+            whole.step_bangbang()
+            group.step_bangbang()
+        else:
+            act = (torch.rand((E, N), device="cuda:0") < 0.5).to(torch.uint8)
+            whole.step(act)
+            group.step([act[:, bounds[r]:bounds[r + 1]].contiguous() for r in range(shards)])
+        assert torch.equal(group.cluster_hvac_power(), whole.t["P"])
+        for name in ("Ta", "Tm", "sso", "flags"):
+            assert torch.equal(group.gather(name), whole.t[name]), name
+        torch.testing.assert_close(group.shards[0].reg_signal(), whole.reg_signal(), rtol=1e-12, atol=0)
+        torch.testing.assert_close(group.gather("reward"), whole.t["reward"], rtol=2e-6, atol=2e-6)
