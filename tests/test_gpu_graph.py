@@ -177,3 +177,59 @@ def test_reg_signal_in_graph_mode_follows_resets_and_steps():
         a.rollout_fused(5)
         b.rollout_fused(5)
         assert torch.equal(a.reg_signal(), b.reg_signal()) and torch.equal(a.obs_vector("rows"), b.obs_vector("rows"))
+
+
+@pytest.mark.parametrize("idx", range(24))
+def test_fuzz_graph_replay_vs_eager(idx):
+    """Random shapes / table lengths / time steps / signal and base-power modes: a captured bang-bang step + observation replayed
+    through an episode against the ordinary env."""
+    import numpy as np
+    import mdr_amd
+    from tests import golden_util as gu
+    rng = np.random.default_rng(900 + idx)
+    N = int(rng.choice([1, 3, 10, 50, 64, 257, 1000, 1024, 4100]))
+    E = int(rng.integers(1, max(2, 3000 // N)))
+    table_steps = int(rng.choice([3, 8, 64]))
+    patches = {"default_env_prop.time_step": int(rng.choice([4, 60, 150])),
+               "default_env_prop.power_grid_prop.signal_mode": str(rng.choice(["flat", "sinusoidals", "regular_steps", "perlin"])),
+               "default_env_prop.reward_prop.temp_penalty_mode": str(rng.choice(["individual_L2", "mixture"]))}
+    kw = {}
+    if rng.integers(0, 2):
+        patches["default_env_prop.power_grid_prop.base_power_mode"] = "interpolation"
+        kw["interp_grid"] = gu.Golden("s12_interp_default_like").interp_grid()
+    cfg = _cfg(N, **patches)
+    seed = int(rng.integers(0, 2 ** 31))
+    a = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=seed, table_steps=table_steps, graph_mode=True, **kw)
+    b = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=seed, table_steps=table_steps, **kw)
+    a.reset(episode=0)
+    b.reset(episode=0)
+    F = a.obs_vector_length()
+    obs = torch.empty((E, N, F), device="cuda:0")
+
+    def one():
+        a.step_bangbang()
+        a.obs_vector("rows", out=obs)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        one()
+    torch.cuda.current_stream().wait_stream(side)
+    if a.graph_room() < 1:
+        a.graph_replayed(0)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        one()
+    T = int(rng.integers(5, 40))
+    done = 1
+    while done < T:
+        n = min(a.graph_room(), T - done)
+        assert n >= 1
+        for _ in range(n):
+            g.replay()
+        a.graph_replayed(n)
+        done += n
+    b.rollout(T)
+    for k in ("Ta", "Tm", "sso", "flags", "reward", "obs", "P"):
+        assert torch.equal(a.t[k], b.t[k]), "%s (case %d: E=%d N=%d K=%d T=%d)" % (k, idx, E, N, table_steps, T)
+    assert torch.equal(obs, b.obs_vector("rows"))
