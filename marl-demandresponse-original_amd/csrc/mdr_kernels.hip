@@ -1592,7 +1592,7 @@ __global__ __launch_bounds__(TILE) void k_obs_tiled(ObsArgs a) {
         }
       }
       if (vec && o + 3 < total) {
-        *reinterpret_cast<float4*>(dst + o) = make_float4(v[0], v[1], v[2], v[3]);
+        store_out<4>(dst, o, v);
       } else {
         for (int q = 0; q < 4 && o + q < total; ++q) dst[o + q] = v[q];
       }
