@@ -228,8 +228,10 @@ def test_fuzz_interpolation_mode_vs_oracle(idx):
         _, reward, _, _ = env.step(torch.from_numpy(act).cuda())
         r_ref = ora.step(act)
         np.testing.assert_array_equal(env.t["P"].cpu().numpy(), ora.P, err_msg="case %d step %d" % (idx, t))
-        np.testing.assert_allclose(env.t["base_power"].cpu().numpy(), ora.base_power, rtol=1e-5, atol=1e-3, err_msg="case %d step %d" % (idx, t))
-        np.testing.assert_allclose(env.reg_signal().cpu().numpy(), ora.S, rtol=1e-5, atol=1e-3)
+        # the random grids are steep (thousands of W per axis step) and the query is built from fp32 temperatures: a 2e-5 degC
+        # difference after 60 steps moves the interpolated power by 1e-5 of its value (seen once in an 11,000-case campaign)
+        np.testing.assert_allclose(env.t["base_power"].cpu().numpy(), ora.base_power, rtol=5e-5, atol=1e-3, err_msg="case %d step %d" % (idx, t))
+        np.testing.assert_allclose(env.reg_signal().cpu().numpy(), ora.S, rtol=5e-5, atol=1e-3)
         np.testing.assert_allclose(reward.cpu().numpy(), r_ref, rtol=3e-5, atol=3e-5)
     # big_noise start temperatures reach 0 degC, where a bound relative to the Celsius value is ill-posed: 1e-5 degC floor
     np.testing.assert_allclose(env.house_temp().cpu().numpy(), ora.Ta, rtol=1e-5, atol=1e-5)
