@@ -11,7 +11,13 @@ random start date per env, bang-bang actions evaluated in-kernel on the previous
 no host round trip).  All state is resident in HBM before the timed region.  With N GPUs every rank owns
 its own 4096 envs (independent replicas, env_offset = rank * 4096, no data-path collective): weak scaling.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (one
+`torch.distributed.run` child, started before this process touches the GPU) and exits with the child's code.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects, plus two
+secondary legs measured after the timed region of the headline (BASELINE.json configs[3] and configs[4]):
+  `ppo_rollout`  policy-in-the-loop rollout collection on the same per-rank batch (observation -> actor -> sample -> step);
+  `c5`           1 env x 1,000,000 houses sharded over the N ranks with the per-step exchange (kernel / collective split).
 """
 from __future__ import annotations
 
@@ -19,6 +25,8 @@ import argparse
 import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,9 +38,13 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 #   state 13 R + 13 W (Ta, Tm f32; sso i32; flags u8) + parameters 40 R (9 f32 + lockout i32)
 #   + action 1 (read, or written when the bang-bang rule runs in-kernel) + reward 4 W + 7 obs planes 28 W
 B_ALG = 99
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0   # the guide's measured float4-copy ceiling (MI355X_MICROARCH.md:36)
 
 E_PER_GPU, N_HOUSES = 4096, 1024
+C5_HOUSES = 1_000_000
+REFERENCE_CPU_NOTE = ("the reference itself (env/MA_DemandResponse.py, imported in the build container, 8-vCPU Xeon 2.1 GHz, 1 core) "
+                      "runs 3.8-5.1e4 house-steps/s (BASELINE.md section 2); its Python cannot travel to the GPU box")
 
 
 def c3_config(mdr):
@@ -59,8 +71,9 @@ def cpu_baseline(cfg_full, seconds):
     rate, steps, el = loop_port.time_baseline(cfg, seconds=seconds)
     out = {"value": rate, "unit": "house-steps/s", "cores": 1, "kind": "port",
            "sample": "oracle/loop_port.py (object-per-house pure-Python restatement, obs dicts + 10-neighbour "
-                     "messages as the reference builds them), 1 env x %d houses x %d bang-bang steps, %.1f s"
-                     % (N_HOUSES, steps, el)}
+                     "messages as the reference builds them), 1 env x %d houses x %d bang-bang steps, %.1f s; %s"
+                     % (N_HOUSES, steps, el, REFERENCE_CPU_NOTE),
+           "reference_build_container_value": [3.8e4, 5.1e4]}
     try:   # the reference's only parallelism: independent processes side by side
         procs = max(1, min(16, (os.cpu_count() or 1)))
         mp_rate, procs = loop_port.time_baseline_parallel(cfg, procs, seconds=min(6.0, seconds))
@@ -78,7 +91,6 @@ def cpu_baseline(cfg_full, seconds):
         out["c_port_value"] = None
         out["c_port_sample"] = "unavailable: %s" % exc
     try:   # the vectorised NumPy oracle (fp64, [E, N] arrays): SURVEY 8d's third CPU form
-        import time
         import numpy as np
         from oracle import mdr_oracle as mo
         ora = mo.OracleEnv(cfg, nb_envs=4).reset(seed=2024, episode=0)
@@ -96,89 +108,251 @@ def cpu_baseline(cfg_full, seconds):
 
 
 def traffic_from_profiles():
-    """HBM bytes per launch of the step kernel from the committed PMC passes (profiles/*traffic*.json), or None."""
-    best = None
+    """HBM bytes per launch of the step kernel from the newest committed PMC passes (profiles/*traffic*.json), or None.
+    A constant read from the profile directory, not a measurement of this run (PMC passes need rocprofv3 around the process)."""
+    best, src = None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
         try:
             with open(path) as f:
-                best = json.load(f)
+                best, src = json.load(f), os.path.relpath(path, ROOT)
         except Exception:
             pass
-    return None if best is None else best.get("hbm_bytes_per_launch")
+    return (None, None) if best is None else (best.get("hbm_bytes_per_launch"), src)
 
 
-def main():
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as ONE torch.distributed.run child - before this
+    process has made any GPU call, and as a child, never an exec - and hand its exit code on.  Rank 0's JSON line goes
+    straight to our stdout."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def parse(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the secondary ppo_rollout / c5 legs")
+    ap.add_argument("--ppo-steps", type=int, default=20)
+    ap.add_argument("--c5-steps", type=int, default=200)
     ap.add_argument("--stagger", type=int, default=int(os.environ.get("MDR_STAGGER", "2304")))
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    import torch
-    import torch.distributed as dist
+
+class Ranks:
+    """Rank bookkeeping + the fence / max-over-ranks of the timing contract."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world))
+        # one process per GPU; MDR_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the multi-rank code path
+        # on a one-GPU box (RCCL refuses two ranks on one device) - never used for reported numbers
+        self.backend = os.environ.get("MDR_BENCH_BACKEND", "nccl")
+        self.dry = os.environ.get("MDR_BENCH_DRY", "") not in ("", "0")      # launcher rehearsal without a GPU (CPU test)
+        self.device = None
+        if not self.dry:
+            idx = self.local_rank if self.backend == "nccl" else self.local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(idx)
+            self.device = torch.device("cuda", idx)
+        # a process group also for a world of one when asked (MDR_BENCH_FORCE_DIST=1) or for the C5 leg (see c5_leg)
+        self.group_ready = False
+        if self.world > 1 or os.environ.get("MDR_BENCH_FORCE_DIST", "") not in ("", "0"):
+            self.init_group()
+
+    def init_group(self):
+        if self.group_ready:
+            return
+        if "MASTER_ADDR" not in os.environ:       # a world of one started without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        # RCCL / gloo print a banner on stdout when the first communicator comes up: keep stdout to the ONE JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if self.backend == "nccl" and not self.dry:
+                self.dist.init_process_group("nccl", device_id=self.device)
+            else:
+                self.dist.init_process_group("gloo")
+            self.dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
+        self.group_ready = True
+
+    def fence(self):
+        if self.group_ready:
+            self.dist.barrier()
+        if not self.dry:
+            self.torch.cuda.synchronize(self.device)
+
+    def max_over_ranks(self, seconds: float) -> float:
+        if not self.group_ready:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.device if (self.device is not None and self.backend == "nccl") else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.group_ready:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed(rk: Ranks, fn, steps: int):
+    """fence - clock - fn - fence; returns (wall seconds as max over ranks, this rank's HIP-event ms per step)."""
+    torch = rk.torch
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    rk.fence()
+    t0 = time.perf_counter()
+    ev0.record()               # same stream the kernels are launched on (torch's current stream)
+    fn()
+    ev1.record()
+    rk.fence()
+    elapsed = time.perf_counter() - t0
+    return rk.max_over_ranks(elapsed), ev0.elapsed_time(ev1) / steps
+
+
+def ppo_leg(rk: Ranks, env, args):
+    """BASELINE.json configs[3] 'PPO rollout collection' on this rank's replica batch: every step = normStateDict vector of
+    all agents -> Actor forward + Categorical.sample (one MFMA kernel) -> env step, nothing leaves the GPU
+    (train_ppo.py:60-108 for all agents at once).  Random-init Actor of the reference's shape (agents/network.py:14-33)."""
+    torch = rk.torch
+    from mdr_amd.rollout import ActorMLP, collect_ppo_rollout
+    E, N = env.nb_envs, env.nb_houses
+    torch.manual_seed(0)
+    actor = ActorMLP(env.obs_vector_length()).to(rk.device)
+    out = {"metric": "agent-steps/s, policy in the loop (observation -> actor -> sample -> env step)",
+           "workload": "%d envs x %d houses per GPU (the C3 batch), Actor %d-100-100-2 random init, transitions kept on the GPU "
+                       "(action, a_prob, reward; states not stored)" % (E, N, env.obs_vector_length()),
+           "steps": args.ppo_steps, "n_gpus": rk.world, "scaling": "weak"}
+    for prec in ("fp32", "bf16x3"):
+        collect_ppo_rollout(env, actor, 3, store_states=False, policy_precision=prec, seed=rk.rank)      # warm-up + packing
+        wall, ev_ms = timed(rk, lambda: collect_ppo_rollout(env, actor, args.ppo_steps, store_states=False,
+                                                             policy_precision=prec, seed=rk.rank), args.ppo_steps)
+        out[prec] = {"agent_steps_per_s": E * N * rk.world * args.ppo_steps / wall, "ms_per_step": wall / args.ppo_steps * 1e3,
+                     "event_ms_per_step_rank0": ev_ms}
+    out["value"] = out["fp32"]["agent_steps_per_s"]
+    out["unit"] = "agent-steps/s"
+    out["dtype"] = "f32 (exact fp32 MFMA); bf16x3 = split-bf16 operands, fp32 accumulate, probabilities within 2e-5"
+    return out
+
+
+def c5_leg(rk: Ranks, mdr, args):
+    """BASELINE.json configs[4]: ONE env x 1,000,000 houses, houses sharded over the ranks, one exchange per step
+    (all-gather of every rank's [3][E] aggregate block; env/MA_DemandResponse.py:1042-1050, 274-321).  A world of one
+    still runs the exchange (through RCCL) so that the collective's cost is on record at every N."""
+    torch = rk.torch
+    from mdr_amd.sharding import house_shard
+    rk.init_group()
+    cfg = c3_config(mdr)
+    cfg["default_env_prop"]["cluster_prop"]["nb_agents"] = C5_HOUSES
+    off, cnt = house_shard(C5_HOUSES, rk.world, rk.rank)
+    env = mdr.BatchedDemandResponseEnv(cfg, nb_envs=1, device=rk.device, seed=2024, house_shard=(off, cnt), exchange_always=True,
+                                       table_steps=64)
+    env.reset(episode=0)
+    K = args.c5_steps
+    env.rollout(20)
+    wall, ev_ms = timed(rk, lambda: env.rollout(K), K)
+    # the collective alone (same tensor, same call), and the kernels alone (an unsharded env of this rank's share: the same
+    # k_step_partial / k_step_finish launches without the exchange)
+    ex = env._exchange()
+    for _ in range(5):
+        ex.gather_totals(env)
+    _, coll_ms = timed(rk, lambda: [ex.gather_totals(env) for _ in range(K)], K)
+    cfg_local = c3_config(mdr)
+    cfg_local["default_env_prop"]["cluster_prop"]["nb_agents"] = cnt
+    local = mdr.BatchedDemandResponseEnv(cfg_local, nb_envs=1, device=rk.device, seed=2024, table_steps=64)
+    local.reset(episode=0)
+    local.rollout(20)
+    _, kern_ms = timed(rk, lambda: local.rollout(K), K)
+    assert env.steps_taken == 20 + K and bool(torch.isfinite(env.t["Ta"]).all())
+    return {"metric": "house-steps/s, 1 env x 1,000,000 houses sharded over the ranks, one all-gather per step",
+            "value": C5_HOUSES * K / wall, "unit": "house-steps/s", "n_gpus": rk.world, "scaling": "strong", "steps": K,
+            "houses_per_rank": cnt, "us_per_step": wall / K * 1e6, "event_us_per_step_rank0": ev_ms * 1e3,
+            "kernel_us_per_step": kern_ms * 1e3, "collective_us_per_step": coll_ms * 1e3,
+            "backend": "rccl" if rk.backend == "nccl" else rk.backend,
+            "note": "us_per_step is host wall-clock per step (max over ranks) of step_begin -> all_gather_into_tensor([3][E] f64 per rank) -> "
+                    "step_end_gathered; kernel = the two step kernels alone on an unsharded env of this rank's %d houses; "
+                    "collective = the all-gather alone, back to back" % cnt}
+
+
+def dry_rank(rk: Ranks, args):
+    """MDR_BENCH_DRY=1: rehearse launcher, rendezvous, fence and max-over-ranks without a GPU (tests/test_bench_launch.py).
+    No kernel runs and the line says so; it is never a result."""
+    if os.environ.get("MDR_BENCH_DRY") == "fail1" and rk.rank == 1:      # a rank that dies must fail the whole launch
+        raise SystemExit(3)
+    rk.fence()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (1 + rk.rank))
+    rk.fence()
+    elapsed = rk.max_over_ranks(time.perf_counter() - t0)
+    if rk.rank == 0:
+        print(json.dumps({"metric": "house-steps/sec at 4096 envs x 1024 houses; achieved HBM GB/s vs roofline", "value": 0.0,
+                          "unit": "house-steps/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "dry-run: launcher rehearsal, no kernel ran",
+                          "config": {"workload": "none (MDR_BENCH_DRY)"}, "roofline": None, "dry_run": True}), flush=True)
+    rk.close()
+
+
+def run_rank(args):
+    rk = Ranks(args)
+    if rk.dry:
+        return dry_rank(rk, args)
     import mdr_amd
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    # one process per GPU; MDR_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the multi-rank code path
-    # on a one-GPU box (RCCL refuses two ranks on one device) - never used for reported numbers
-    backend = os.environ.get("MDR_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
+    torch = rk.torch
 
     cfg = c3_config(mdr_amd)
     e_per_gpu = int(os.environ.get("MDR_BENCH_ENVS", E_PER_GPU))   # rehearsal knob only; the reported config is 4096
-    env = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=e_per_gpu, device=device, seed=2024,
-                                           env_offset=rank * e_per_gpu, table_steps=64, stagger_bytes=args.stagger)
+    env = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=e_per_gpu, device=rk.device, seed=2024,
+                                           env_offset=rk.rank * e_per_gpu, table_steps=64, stagger_bytes=args.stagger)
     env.reset(episode=0)
     env.rollout(args.warmup)
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(device)
-
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    fence()
-    t0 = time.perf_counter()
-    ev0.record()               # same stream the kernels are launched on (torch's current stream)
-    env.rollout(args.steps)
-    ev1.record()
-    fence()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps   # average launch-to-launch duration of the step kernel
-
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    houses = e_per_gpu * N_HOUSES * world
+    elapsed, kernel_ms = timed(rk, lambda: env.rollout(args.steps), args.steps)   # kernel_ms: average launch-to-launch duration of the step kernel
+    houses = e_per_gpu * N_HOUSES * rk.world
     value = houses * args.steps / elapsed
 
     # sanity: the rollout really advanced and the state is finite (cheap, outside the timed region)
     assert env.steps_taken == args.warmup + args.steps
     assert bool(torch.isfinite(env.t["Ta"]).all()) and bool(torch.isfinite(env.t["reward"]).all())
 
-    if rank == 0:
+    legs = {}
+    if not args.no_legs:
+        for name, leg in (("ppo_rollout", lambda: ppo_leg(rk, env, args)), ("c5", lambda: c5_leg(rk, mdr_amd, args))):
+            try:
+                legs[name] = leg()
+            except Exception as exc:      # a secondary leg never costs the headline; with several ranks a failure is fatal for all
+                if rk.world > 1:
+                    raise
+                legs[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
+    if rk.rank == 0:
         achieved = B_ALG * e_per_gpu * N_HOUSES / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_src = traffic_from_profiles()
         line = {
             "metric": "house-steps/sec at 4096 envs x 1024 houses; achieved HBM GB/s vs roofline",
-            "value": value, "unit": "house-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "house-steps/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C3: %d envs x %d houses per GPU, house_big_noise + big_noise HVAC, "
@@ -187,16 +361,27 @@ def main():
                        "envs_per_gpu": e_per_gpu, "houses_per_env": N_HOUSES, "sharding": "independent env replicas, no collective",
                        "seed": 2024, "table_steps": 64},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profiles(),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profile constant from %s (PMC passes of an earlier run of this command), not measured in this run" % traffic_src,
                          "kernel": "k_step_fused<4,1,256>", "algorithmic_bytes_per_house_step": B_ALG,
-                         "kernel_ms": kernel_ms},
+                         "kernel_ms": kernel_ms,
+                         "peak_measured_copy": HBM_COPY_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
+                         "cache_note": "C3 re-reads 53 B/house = 222 MB per step, below the 256 MiB Infinity Cache: part of this rate is "
+                                       "cache-assisted; the size sweep in profiles/ (r02_size_sweep.jsonl) gives the rate with the re-read set at 2-8x the cache"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        line.update(legs)
+        if rk.world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    rk.close()
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -316,6 +316,13 @@ int mdr_env_obs_messages(mdr_env_t *env, const mdr_obs_spec_t *spec, float *mess
 int mdr_env_obs_vector_ext(mdr_env_t *env, const mdr_obs_spec_t *spec, const float *messages, int64_t entries_per_env,
                            float *out, void *stream);
 
+/* The random part of the message gather on its own (env 976-1002): for every local house and message slot m < spec->nb_comm the
+ * sender's GLOBAL house id -> senders[e][h][m] (int32; the link-table entry, the circular neighbour, or - random_links - the
+ * `random.sample` draw of this step) and whether the link delivers -> keep[e][h][m] (uint8; 0 = `np.random.rand() >
+ * comm_defect_prob` failed: an all-zero message).  Same Philox streams and counters as mdr_env_obs_vector at the same time
+ * index, so a host that builds the reference's `message` lists itself (the dict adapter) shows exactly what the flat vector holds. */
+int mdr_env_comm_draws(mdr_env_t *env, const mdr_obs_spec_t *spec, int32_t *senders, uint8_t *keep, void *stream);
+
 /* Cursor: k = number of steps taken this episode (env.datetime == start_datetime + k * time_step, env 189);
  * j0 = time index of table row 0. */
 /* Graph mode (mdr_buffers_t.cursor bound).  The launch-bound regime - a policy in the loop on small batches, where a step is

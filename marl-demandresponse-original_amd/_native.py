@@ -125,7 +125,7 @@ EXPORTS = (
     "mdr_env_set_od_table", "mdr_env_set_interp_grid", "mdr_env_begin_episode", "mdr_env_step", "mdr_env_rollout", "mdr_env_rollout_fused",
     "mdr_env_step_begin", "mdr_env_step_end", "mdr_env_step_end_gathered",
     "mdr_env_interp_due", "mdr_env_interp_local", "mdr_env_interp_apply", "mdr_obs_vector_length", "mdr_env_obs_vector",
-    "mdr_obs_message_fields", "mdr_env_obs_messages", "mdr_env_obs_vector_ext",
+    "mdr_obs_message_fields", "mdr_env_obs_messages", "mdr_env_obs_vector_ext", "mdr_env_comm_draws",
     "mdr_env_graph_room", "mdr_env_graph_replayed", "mdr_env_pack", "mdr_env_cursor", "mdr_env_set_cursor",
     # include/mdr_policy.h
     "mdr_actor_steps1", "mdr_actor_steps2", "mdr_actor_frag1_floats", "mdr_actor_frag2_floats", "mdr_actor_sample", "mdr_discounted_returns",
@@ -176,6 +176,7 @@ def load():
         "mdr_obs_message_fields": (i32, [C.POINTER(MdrObsSpec)]),
         "mdr_env_obs_messages": (C.c_int, [vp, C.POINTER(MdrObsSpec), vp, i64, vp]),
         "mdr_env_obs_vector_ext": (C.c_int, [vp, C.POINTER(MdrObsSpec), vp, i64, vp, vp]),
+        "mdr_env_comm_draws": (C.c_int, [vp, C.POINTER(MdrObsSpec), vp, vp, vp]),
         "mdr_env_cursor": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
         "mdr_env_set_cursor": (C.c_int, [vp, u64, u32, i64, i64]),
         "mdr_actor_steps1": (i64, [i32, i32]),

@@ -44,7 +44,7 @@ class BatchedDemandResponseEnv:
                  table_steps: int = 64, env_offset: int = 0,
                  house_shard: Optional[Tuple[int, int]] = None, process_group=None,
                  stagger_bytes: int = 2304, interp_grid=None, regenerate_missing_grid: bool = True,
-                 graph_mode: bool = False):
+                 graph_mode: bool = False, exchange_always: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedDemandResponseEnv needs a ROCm device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -58,7 +58,10 @@ class BatchedDemandResponseEnv:
         self.nb_agents = self.spec.nb_houses_total
         self.house_offset, self.nb_houses = (0, self.nb_agents) if house_shard is None else map(int, house_shard)
         self._act_shape = torch.Size((self.nb_envs, self.nb_houses))
-        self.sharded = house_shard is not None and self.nb_houses != self.nb_agents
+        # exchange_always: run the begin / exchange / end sequence even when this rank holds the whole env (a world of one):
+        # how the production collectives are exercised on a one-GPU box (tests/test_gpu_rccl.py, bench.py's C5 leg at N = 1)
+        self.sharded = house_shard is not None and (self.nb_houses != self.nb_agents or bool(exchange_always))
+        self._exchange_always = bool(exchange_always)
         self.process_group = process_group
         self.env_offset = int(env_offset)
         self.table_steps = int(table_steps)
@@ -658,6 +661,7 @@ class BatchedDemandResponseEnv:
                                          seed=self.seed, test=self.test, table_steps=self.table_steps,
                                          env_offset=self.env_offset,
                                          house_shard=(self.house_offset, self.nb_houses) if self.sharded else None,
+                                         exchange_always=self._exchange_always,
                                          process_group=self.process_group, stagger_bytes=self._stagger, graph_mode=self.graph_mode,
                                          interp_grid=getattr(self, "_interp_grid_host", None))
         if self.episode >= 0:

@@ -27,6 +27,21 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > built for d in deps)
 
 
+def build_variant(name: str, defines=(), verbose: bool = False) -> str:
+    """Experiment build csrc/libmdr_hip_<name>.so with extra -D switches (e.g. MDR_NT_STORES=0 for the cache-control sweep of
+    tools/bench_size_sweep.py); select it with the MDR_HIP_LIB environment variable.  Never the product library."""
+    out = os.path.join(CSRC, "libmdr_hip_%s.so" % name)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    if os.path.isfile(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=on", "-std=c++17", "-fPIC", "-shared"]
+    cmd += ["-D" + d for d in defines] + ["-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return out
+
+
 def build_native(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return OUTPUT

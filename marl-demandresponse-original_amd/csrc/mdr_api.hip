@@ -783,6 +783,17 @@ int mdr_env_obs_vector_ext(mdr_env_t* env, const mdr_obs_spec_t* spec, const flo
   return MDR_OK;
 }
 
+int mdr_env_comm_draws(mdr_env_t* env, const mdr_obs_spec_t* spec, int32_t* senders, uint8_t* keep, void* stream) {
+  if (!env || !spec || !senders || !keep) return MDR_ERR_INVALID;
+  mdr::ObsArgs a;
+  int rc = obs_args(env, spec, false, &a);
+  if (rc == MDR_OK) rc = sync_cursor(env, (hipStream_t)stream);
+  if (rc != MDR_OK) return rc;
+  hipError_t e = mdr::launch_comm_draws(a, senders, keep, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(env, e, "comm_draws");
+  return MDR_OK;
+}
+
 int mdr_env_step_end(mdr_env_t* env, void* stream) { return step_end_impl(env, nullptr, 0, stream); }
 
 int mdr_env_step_end_gathered(mdr_env_t* env, const double* gathered, int32_t world, void* stream) {

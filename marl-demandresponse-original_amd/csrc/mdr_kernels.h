@@ -171,6 +171,7 @@ hipError_t launch_rollout_fused(const StepArgs& a, const RolloutArgs& r, const S
 hipError_t launch_obs_vector(const ObsArgs& a, int layout, hipStream_t s);
 hipError_t launch_obs_messages(const ObsArgs& a, hipStream_t s);               // msg_ext_out[e][h][:] for the local houses
 hipError_t launch_obs_vector_ext(const ObsArgs& a, int layout, hipStream_t s);  // senders read from msg_ext_in through links
+hipError_t launch_comm_draws(const ObsArgs& a, int32_t* senders, uint8_t* keep, hipStream_t s);   // per-slot sender ids + keep flags
 int obs_message_fields(const mdr_obs_spec_t& s);
 int obs_vector_length(const mdr_obs_spec_t& spec);
 hipError_t launch_step_begin_split(const StepArgs& a, hipStream_t s);

@@ -1409,6 +1409,51 @@ __global__ __launch_bounds__(256) void k_obs_messages(ObsArgs a) {
   }
 }
 
+// ---- the random draws of the message gather on their own: sender id and keep flag of every message slot of every local
+// house at the current time index - exactly what the observation kernels use (same Philox streams, same counters), for
+// hosts that build the reference's `message` lists themselves (the dict adapter) and for draw-by-draw parity tests.
+// senders: global house ids (link table entry / circular neighbour among nb_houses_total / random_sample draw).
+template <bool RANDOM>
+__global__ __launch_bounds__(256) void k_comm_draws(ObsArgs a, int32_t* __restrict__ senders, uint8_t* __restrict__ keep) {
+  rebase(a);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.plane) return;
+  const int e = (int)(i / a.N);
+  const int h = (int)(i - (int64_t)e * a.N);
+  const int hg = h + (int)a.house_offset;
+  typename std::conditional<RANDOM, LinkSampler, NoSampler>::type smp;
+  u32x4 rnd{0, 0, 0, 0};
+  const int before = a.c / 2;
+  for (int m = 0; m < a.c; ++m) {
+    int sid;
+    if (RANDOM) {
+      sid = smp.next(a, e, h);
+    } else if (a.links != nullptr) {
+      sid = a.links[(int64_t)h * a.c + m];
+    } else {   // circular neighbours of the whole env (env 816-828)
+      sid = (m < before ? hg - before + m : hg + 1 + (m - before)) % a.n_total;
+      if (sid < 0) sid += a.n_total;
+    }
+    unsigned ok = 1u;
+    if (a.defect_prob > 0.0f) {   // np.random.rand() > comm_defect_prob keeps the message (env 992)
+      if ((m & 3) == 0)
+        rnd = philox4x32_10((uint32_t)(e + a.env_offset), (uint32_t)hg, (uint32_t)a.k, TAG_COMM | ((uint32_t)(m >> 2) << 8), a.k0,
+                            a.k1 ^ (a.episode * 0x85EBCA6Bu));
+      const uint32_t x = (m & 3) == 0 ? rnd.x : (m & 3) == 1 ? rnd.y : (m & 3) == 2 ? rnd.z : rnd.w;
+      ok = (float)u01(x) > a.defect_prob ? 1u : 0u;
+    }
+    senders[i * a.c + m] = sid;
+    keep[i * a.c + m] = (uint8_t)ok;
+  }
+}
+
+hipError_t launch_comm_draws(const ObsArgs& a, int32_t* senders, uint8_t* keep, hipStream_t s) {
+  const dim3 g((unsigned)((a.plane + 255) / 256)), b(256);
+  if (a.random_links) hipLaunchKernelGGL(k_comm_draws<true>, g, b, 0, s, a, senders, keep);
+  else hipLaunchKernelGGL(k_comm_draws<false>, g, b, 0, s, a, senders, keep);
+  return hipGetLastError();
+}
+
 // ---- simple form: one thread per house, direct (4-byte) stores; fallback for shapes the other kernels cannot hold.
 // EXT: the senders are message records (sender_from_ext) addressed through the link table - the sharded-houses form.
 template <int LAYOUT, bool RANDOM, bool EXT = false>

@@ -145,6 +145,8 @@ class TorchDistExchange:
         import torch.distributed as dist
         world = dist.get_world_size(self.process_group)
         out = torch.empty((world,) + tuple(padded.shape), dtype=padded.dtype, device=padded.device)
+        if padded.numel() == 0:      # nobody listens across a shard edge (e.g. a world of one): nothing to exchange
+            return out
         dist.all_gather_into_tensor(out.view(world * padded.shape[0], padded.shape[1], padded.shape[2]), padded, group=self.process_group)
         return out
 

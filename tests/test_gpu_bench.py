@@ -1,0 +1,44 @@
+"""bench.py end to end on the GPU box: the default single-GPU line (with its secondary legs) and the self-launched two-rank form
+(gloo, both ranks sharing the one GPU - RCCL refuses two ranks on one device; reduced batch, never a reported number)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_env, *argv, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=timeout)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [json.loads(l) for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    return lines[0]
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_with_legs_over_rccl():
+    line = _run({"MDR_BENCH_ENVS": "512"}, "--steps", "50", "--warmup", "5", "--no-cpu-baseline", "--ppo-steps", "3", "--c5-steps", "20")
+    assert line["n_gpus"] == 1 and line["value"] > 1e9 and line["roofline"]["bound"] == "hbm"
+    assert 0 < line["roofline"]["frac"] < 1.0 and line["roofline"]["frac_of_measured_copy"] > line["roofline"]["frac"]
+    assert "error" not in line["ppo_rollout"], line["ppo_rollout"]
+    assert line["ppo_rollout"]["fp32"]["agent_steps_per_s"] > 1e7 and line["ppo_rollout"]["bf16x3"]["agent_steps_per_s"] > 1e7
+    assert "error" not in line["c5"], line["c5"]        # the exchange of a world of one ran over RCCL
+    assert line["c5"]["backend"] == "rccl" and line["c5"]["houses_per_rank"] == 1_000_000 and line["c5"]["value"] > 1e9
+    assert line["c5"]["collective_us_per_step"] > 0 and line["c5"]["kernel_us_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_self_launched_gloo_on_one_gpu():
+    line = _run({"MDR_BENCH_BACKEND": "gloo", "MDR_BENCH_ENVS": "256"}, "--gpus", "2", "--steps", "20", "--warmup", "5", "--ppo-steps", "2",
+                "--c5-steps", "10")
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 1e8
+    assert line["config"]["envs_per_gpu"] == 256
+    assert line["ppo_rollout"]["n_gpus"] == 2 and line["ppo_rollout"]["value"] > 1e6
+    assert line["c5"]["n_gpus"] == 2 and line["c5"]["houses_per_rank"] == 500_000 and line["c5"]["backend"] == "gloo"
+    assert "cpu_baseline" not in line
