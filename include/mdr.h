@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MDR_ABI_VERSION 2
+#define MDR_ABI_VERSION 3
 #define MDR_MAX_SINUSOIDS 8
 #define MDR_MAX_CAPACITIES 16
 #define MDR_OBS_COLUMNS 7
@@ -155,6 +155,9 @@ typedef struct mdr_buffers {
    * launch that advances it - so a captured mdr_env_step / mdr_env_obs_vector (hipGraph, torch.cuda.CUDAGraph) keeps walking
    * through the episode when it is replayed.  See mdr_env_graph_room / mdr_env_graph_replayed. */
   int32_t *cursor;
+  /* Optional (NULL = off): [(table_steps+1)][E] what PowerGrid.step adds to cumulated_abs_noise at that time index,
+   * |base_power * amplitude * perlin| (env 1301); 0 for the signal families without noise. */
+  double *tab_abs_noise;
 } mdr_buffers_t;
 
 /* Raw episode parameters for mdr_env_load_episode (replay of an episode sampled elsewhere).
@@ -218,7 +221,8 @@ int mdr_env_reset(mdr_env_t *env, uint64_t seed, uint32_t episode, void *stream)
 int mdr_env_load_episode(mdr_env_t *env, const mdr_episode_t *episode, uint64_t seed, uint32_t episode_index,
                          void *stream);
 /* Optional: replace ClusterHouses.compute_OD_temp (env 1057-1081, incl. its random.gauss draw 1079) by a table, double [rows][E] deg C (row = time index);
- * NULL restores the model.  Takes effect at the next mdr_env_begin_episode / table refill. */
+ * NULL restores the model.  Takes effect at the next mdr_env_begin_episode / table refill; mdr_env_reset (a freshly sampled
+ * episode) drops it. */
 int mdr_env_set_od_table(mdr_env_t *env, const double *od_table, int64_t rows);
 /* The 10-D bang-bang average-power grid of monteCarlo/ (PowerInterpolator, monteCarlo/interpolation.py:21-47).
  * Axis order is the reference's interp_dict_keys.csv: Ua_ratio, Cm_ratio, Ca_ratio, Hm_ratio, air_temp, mass_temp,
@@ -328,8 +332,10 @@ int mdr_env_comm_draws(mdr_env_t *env, const mdr_obs_spec_t *spec, int32_t *send
 /* Graph mode (mdr_buffers_t.cursor bound).  The launch-bound regime - a policy in the loop on small batches, where a step is
  * six short kernels - is served by capturing ONE step (observation, policy, mdr_env_step) into a graph and replaying it.
  * The host does not run during a replay, so it is told afterwards:
- *   mdr_env_graph_room      how many steps the time tables still cover (replays allowed before the next host-side refill /
- *                           interpolatePower update); capture needs room >= 1;
+ *   mdr_env_graph_room      how many replays are allowed now: the steps the time tables still cover, and - interpolation mode -
+ *                           only up to the step BEFORE the next interpolatePower update: the step that lands on an update
+ *                           must be an ordinary (un-captured) mdr_env_step, which runs the update before anything enqueued
+ *                           behind it reads the signal.  0 = take one ordinary step now; capture needs room >= 1;
  *   mdr_env_graph_replayed  `n` steps were replayed: the host cursor catches up, refills the tables and runs a due
  *                           interpolation update (launches on `stream`, outside any capture).
  * Ordinary (non-captured) calls keep working in graph mode; each step then costs one extra one-thread launch. */
@@ -338,9 +344,9 @@ int mdr_env_graph_replayed(mdr_env_t *env, int64_t n, void *stream);
 
 /* What the reference's dict surface shows of ONE env after reset / step (make_cluster_obs_dict env 904-1003, rewards 330-373),
  * gathered into one fp64 vector on the device so that a host adapter needs a single copy:
- * out[5 N + 6] = house_temp[N] | house_mass_temp[N] (deg C) | seconds_since_off[N] | flags[N] (bit 0 on, bit 1 lockout) |
+ * out[5 N + 7] = house_temp[N] | house_mass_temp[N] (deg C) | seconds_since_off[N] | flags[N] (bit 0 on, bit 1 lockout) |
  *                reward[N] | OD_temp, reg_signal, solar gain of the current time index, cluster_hvac_power, max_power,
- *                artificial_ratio. */
+ *                artificial_ratio, |base_power * amplitude * perlin| of the current time index (0 without tab_abs_noise). */
 int mdr_env_pack(mdr_env_t *env, int32_t env_index, double *out, void *stream);
 
 int mdr_env_cursor(const mdr_env_t *env, int64_t *k, int64_t *j0);

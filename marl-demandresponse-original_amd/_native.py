@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDR_HIP_LIB") or os.path.join(HERE, "csrc", "libmdr_hip.so")   # MDR_HIP_LIB: experiment builds
 
-MDR_ABI_VERSION = 2
+MDR_ABI_VERSION = 3
 MDR_MAX_SINUSOIDS = 8
 MDR_MAX_CAPACITIES = 16
 MDR_OBS_COLUMNS = 7
@@ -68,7 +68,7 @@ class MdrBuffers(C.Structure):
         ("t0", _i64p), ("phase", _f64p), ("ratio", _f64p), ("max_power", _f64p),
         ("P", _f64p), ("tot_sum", _f64p), ("tot_max", _f64p),
         ("tab_od", _f32p), ("tab_solar", _f32p), ("tab_signal", _f64p),
-        ("partials", _f64p), ("base_power", _f64p), ("cursor", C.c_void_p),
+        ("partials", _f64p), ("base_power", _f64p), ("cursor", C.c_void_p), ("tab_abs_noise", _f64p),
     ]
 
 

@@ -131,7 +131,8 @@ class BatchedDemandResponseEnv:
         items += [("obs", torch.float32, (nat.MDR_OBS_COLUMNS, E, N))]
         items += [("t0", torch.int64, (E,))] + [(n, torch.float64, (E,)) for n in ("phase", "ratio", "max_power", "P", "base_power")]
         items += [("tot", torch.float64, (3, E))]     # local aggregates as ONE block: tot_sum = tot[0:2], tot_max = tot[2]
-        items += [("tab_od", torch.float32, (K1, E)), ("tab_solar", torch.float32, (K1, E)), ("tab_signal", torch.float64, (K1, E))]
+        items += [("tab_od", torch.float32, (K1, E)), ("tab_solar", torch.float32, (K1, E)), ("tab_signal", torch.float64, (K1, E)),
+                  ("tab_abs_noise", torch.float64, (K1, E))]
         items += [("partials", torch.float64, (E, nblk, 3))]
         items += [("cursor", torch.int32, (2,))]      # graph mode: {table row, time index} kept on the device
         return items
@@ -255,6 +256,7 @@ class BatchedDemandResponseEnv:
         if seed is not None:
             self.seed = int(seed)
         self.episode = self.episode + 1 if episode is None else int(episode)
+        self._od_table = None        # mdr_env_reset drops a recorded outdoor-temperature sequence: it belonged to a loaded episode
         with torch.cuda.device(self.device):
             rc = self._lib.mdr_env_reset(self._handle, C.c_uint64(self.seed & 0xFFFFFFFFFFFFFFFF),
                                          C.c_uint32(self.episode & 0xFFFFFFFF), self._stream())
@@ -416,11 +418,11 @@ class BatchedDemandResponseEnv:
         return res
 
     def pack_env(self, env_index: int = 0) -> np.ndarray:
-        """Host copy of what the dict surface shows of one env (mdr_env_pack): float64 [5 N + 6], one launch + one copy."""
+        """Host copy of what the dict surface shows of one env (mdr_env_pack): float64 [5 N + 7], one launch + one copy."""
         n = self.nb_houses
         buf = self.__dict__.get("_pack_dev")
         if buf is None:
-            buf = self._pack_dev = torch.empty(5 * n + 6, dtype=torch.float64, device=self.device)
+            buf = self._pack_dev = torch.empty(5 * n + 7, dtype=torch.float64, device=self.device)
         with torch.cuda.device(self.device):
             rc = self._lib.mdr_env_pack(self._handle, int(env_index), C.c_void_p(buf.data_ptr()), self._stream())
             nat.check(self._lib, self._handle, rc, "mdr_env_pack")
@@ -445,7 +447,7 @@ class BatchedDemandResponseEnv:
 
     # ------------------------------------------------------------------ full normStateDict vector
     def _obs_spec(self, layout: str, with_links: bool = True) -> nat.MdrObsSpec:
-        from .comm import build_comm_links, nb_comm
+        from .comm import nb_comm
         env = self.config["default_env_prop"]
         cluster, sp, mp = env["cluster_prop"], env["state_properties"], env["message_properties"]
         spec = nat.MdrObsSpec()
@@ -460,15 +462,10 @@ class BatchedDemandResponseEnv:
             spec.random_links = 1
         if mode == "no_message":
             spec.nb_comm = 0
-        if not with_links:
-            pass
-        elif getattr(self, "_links_dev", None) is None and mode not in ("neighbours", "no_message", "random_sample"):
-            links = build_comm_links(cluster)
-            table = np.array([links[i] for i in range(self.nb_agents)], dtype=np.int32).reshape(self.nb_agents, -1)
-            self._links_dev = torch.from_numpy(table).to(self.device)
         if with_links and (mode not in ("neighbours", "no_message", "random_sample") or getattr(self, "_links_forced", False)):
-            spec.nb_comm = int(self._links_dev.shape[1])
-            spec.links = self._links_dev.data_ptr() if spec.nb_comm > 0 else None
+            links_dev = self._links_device()
+            spec.nb_comm = int(links_dev.shape[1])
+            spec.links = links_dev.data_ptr() if spec.nb_comm > 0 else None
         spec.comm_defect_prob = float(cluster["comm_defect_prob"])
         house, hvac = self.config["default_house_prop"], self.config["default_hvac_prop"]
         spec.def_Ua, spec.def_Cm, spec.def_Ca, spec.def_Hm = house["Ua"], house["Cm"], house["Ca"], house["Hm"]
@@ -476,17 +473,68 @@ class BatchedDemandResponseEnv:
         spec.norm_reg_sig = self.spec.norm_reg_sig
         return spec
 
+    def comm_links_array(self):
+        """ClusterHouses.agent_communicators (env 806-902) of the current episode as int32 [nb_agents, c] global sender ids
+        (None for 'random_sample', whose senders are re-drawn every step): the table installed with `set_comm_links`, or the
+        one the mode implies.  'random_fixed' is re-drawn at every reset (the reference re-draws it in build_environment) as
+        a pure function of (seed, episode), so every rank of a sharded run and every view of the env sees the same table."""
+        from .comm import links_array
+        if getattr(self, "_links_forced", False):
+            return self._links_global
+        cluster = self.config["default_env_prop"]["cluster_prop"]
+        key = (self.seed, self.episode) if cluster["agents_comm_mode"] == "random_fixed" else None
+        cached = getattr(self, "_links_cache", None)
+        if cached is None or cached[0] != key:
+            cached = self._links_cache = (key, links_array(cluster, seed_episode=(self.seed, max(self.episode, 0))))
+            self._links_dev_cache = None
+            self._halo = None
+        return cached[1]
+
+    def _links_device(self) -> torch.Tensor:
+        table = self.comm_links_array()
+        dev = getattr(self, "_links_dev_cache", None)
+        if dev is None or dev[0] is not table:
+            dev = self._links_dev_cache = (table, torch.from_numpy(np.ascontiguousarray(table)).to(self.device))
+        return dev[1]
+
     def set_comm_links(self, table) -> None:
         """Install a static [N, c] sender table (ClusterHouses.agent_communicators) instead of the one derived from
-        cluster_prop - e.g. the links a 'random_fixed' episode drew elsewhere."""
+        cluster_prop - e.g. the links a 'random_fixed' episode of the reference drew; it stays until replaced (resets keep it)."""
         table = np.ascontiguousarray(np.asarray(table, dtype=np.int32)).reshape(self.nb_agents, -1)
         if table.size and (table.min() < 0 or table.max() >= self.nb_agents):
             raise ValueError("sender ids must be in [0, nb_agents)")
         self._links_global = table
         self._halo = None
-        if not self.sharded:
-            self._links_dev = torch.from_numpy(table).to(self.device)
+        self._links_dev_cache = None
         self._links_forced = True
+
+    def comm_draws(self):
+        """The random part of the message gather at the current time index (env 976-1002; mdr_env_comm_draws): for every local
+        house and message slot the sender's global house id - int32 [E, N, c] - and whether the link delivers - bool [E, N, c];
+        exactly the draws `obs_vector` uses at this step."""
+        cluster = self.config["default_env_prop"]["cluster_prop"]
+        mode = cluster["agents_comm_mode"]
+        spec = self._obs_spec("rows", with_links=False)
+        keep_alive = None
+        if mode == "random_sample" and not getattr(self, "_links_forced", False):
+            spec.random_links = 1
+        elif mode != "no_message" and (mode != "neighbours" or getattr(self, "_links_forced", False)):
+            spec.random_links = 0
+            rows = self.comm_links_array()[self.house_offset:self.house_offset + self.nb_houses]
+            keep_alive = torch.from_numpy(np.ascontiguousarray(rows)).to(self.device)
+            spec.nb_comm = int(keep_alive.shape[1])
+            spec.links = keep_alive.data_ptr() if spec.nb_comm > 0 else None
+        c = int(spec.nb_comm)
+        senders = torch.empty((self.nb_envs, self.nb_houses, c), dtype=torch.int32, device=self.device)
+        keep = torch.empty((self.nb_envs, self.nb_houses, c), dtype=torch.uint8, device=self.device)
+        if c > 0:
+            with torch.cuda.device(self.device):
+                rc = self._lib.mdr_env_comm_draws(self._handle, C.byref(spec), C.c_void_p(senders.data_ptr()), C.c_void_p(keep.data_ptr()),
+                                                  self._stream())
+                nat.check(self._lib, self._handle, rc, "mdr_env_comm_draws")
+                if keep_alive is not None:
+                    torch.cuda.current_stream(self.device).synchronize()
+        return senders, keep.bool()
 
     def obs_vector_length(self) -> int:
         spec = self._obs_spec("planes")
@@ -538,8 +586,9 @@ class BatchedDemandResponseEnv:
 
     # sharded houses: SURVEY 8e "halo exchange" of the neighbour messages
     def _halo_plan(self):
-        from .comm import links_array, nb_comm
+        from .comm import nb_comm
         from .sharding import HaloPlan
+        self.comm_links_array()          # a new 'random_fixed' episode drops the cached plan
         plan = getattr(self, "_halo", None)
         if plan is None:
             cluster = self.config["default_env_prop"]["cluster_prop"]
@@ -549,8 +598,7 @@ class BatchedDemandResponseEnv:
                 # house and env) and the record slots are global house ids
                 plan = self._halo = HaloPlan.everything(ranges, rank, nb_comm(cluster)).to(self.device)
             else:
-                links = self._links_global if getattr(self, "_links_forced", False) else links_array(cluster)
-                plan = self._halo = HaloPlan(links, ranges, rank).to(self.device)
+                plan = self._halo = HaloPlan(self.comm_links_array(), ranges, rank).to(self.device)
         return plan
 
     def _obs_spec_sharded(self, layout, plan):
@@ -664,6 +712,9 @@ class BatchedDemandResponseEnv:
                                          exchange_always=self._exchange_always,
                                          process_group=self.process_group, stagger_bytes=self._stagger, graph_mode=self.graph_mode,
                                          interp_grid=getattr(self, "_interp_grid_host", None))
+        if getattr(self, "_links_forced", False):
+            other.set_comm_links(self._links_global)
+        other.episode = self.episode      # 'random_fixed' derives its link table from (seed, episode)
         if self.episode >= 0:
             other.load_state_dict(self.state_dict())
         return other

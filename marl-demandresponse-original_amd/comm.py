@@ -15,7 +15,32 @@ def nb_comm(cluster_prop: dict) -> int:
     return int(min(cluster_prop["nb_agents_comm"], cluster_prop["nb_agents"] - 1))   # env 808-810
 
 
-def build_comm_links(cluster_prop: dict) -> Optional[Dict[int, List[int]]]:
+def random_fixed_table(n: int, c: int, seed: int, episode: int):
+    """agents_comm_mode 'random_fixed' (env 849-854): every house keeps `c` distinct random senders among the others for the
+    whole episode.  The reference draws them from Python's global `random` stream at every build_environment; here the table
+    is a pure function of (seed, episode) - the same on every rank of a sharded run and in every view of one env (flat
+    vector, dict messages, halo plan), re-drawn at every reset because the episode index moves.  int32 [n, c]."""
+    import numpy as np
+    if c <= 0 or n <= 1:
+        return np.zeros((n, 0), dtype=np.int32)
+    rng = np.random.default_rng([int(seed) & 0xFFFFFFFFFFFFFFFF, int(episode) & 0xFFFFFFFF, 0x6C696E6B])
+    own = np.arange(n, dtype=np.int64)[:, None]
+    if n - 1 <= 64 or c * c * 8 > n:          # small envs / dense tables: a permutation of the others per house
+        picks = rng.permuted(np.broadcast_to(np.arange(n - 1, dtype=np.int64), (n, n - 1)), axis=1)[:, :c]
+    else:                                     # large envs: independent draws, rows with a repeated sender re-drawn
+        picks = rng.integers(0, n - 1, size=(n, c), dtype=np.int64)
+        while True:
+            srt = np.sort(picks, axis=1)
+            bad = np.nonzero((srt[:, 1:] == srt[:, :-1]).any(axis=1))[0]
+            if bad.size == 0:
+                break
+            picks[bad] = rng.integers(0, n - 1, size=(bad.size, c), dtype=np.int64)
+    return (picks + (picks >= own)).astype(np.int32)      # index among the OTHER houses -> house id
+
+
+def build_comm_links(cluster_prop: dict, seed_episode=None) -> Optional[Dict[int, List[int]]]:
+    """`seed_episode` = (seed, episode): where 'random_fixed' takes its table from (`random_fixed_table`); without it the table
+    is drawn from Python's global `random` stream as the reference does."""
     n = int(cluster_prop["nb_agents"])
     c = nb_comm(cluster_prop)
     mode = cluster_prop["agents_comm_mode"]
@@ -37,6 +62,9 @@ def build_comm_links(cluster_prop: dict) -> Optional[Dict[int, List[int]]]:
     if mode == "random_sample":
         return None
     if mode == "random_fixed":     # env 849-854
+        if seed_episode is not None:
+            table = random_fixed_table(n, c, *seed_episode)
+            return {i: [int(x) for x in table[i]] for i in ids}
         return {i: random.sample([j for j in ids if j != i], k=c) for i in ids}
     if mode == "neighbours_2D":    # env 856-890
         p2 = cluster_prop["agents_comm_parameters"]["neighbours_2D"]
@@ -55,7 +83,7 @@ def build_comm_links(cluster_prop: dict) -> Optional[Dict[int, List[int]]]:
     raise ValueError("Cluster property: unknown agents_comm_mode '{}'.".format(mode))
 
 
-def links_array(cluster_prop: dict):
+def links_array(cluster_prop: dict, seed_episode=None):
     """The static link table as int32 [nb_agents, c] (None for random_sample).  'neighbours' is built with array
     arithmetic so that a 1,000,000-house env does not go through a Python dict."""
     import numpy as np
@@ -64,6 +92,8 @@ def links_array(cluster_prop: dict):
     mode = cluster_prop["agents_comm_mode"]
     if mode == "random_sample":
         return None
+    if mode == "random_fixed" and seed_episode is not None:
+        return random_fixed_table(n, c, *seed_episode)
     if mode == "no_message" or c == 0 and mode == "neighbours":
         return np.zeros((n, 0), dtype=np.int32)
     if mode == "neighbours":

@@ -152,6 +152,7 @@ int fill_tables(mdr_env* env, int64_t j0, hipStream_t s) {
   t.tab_od = env->buf.tab_od;
   t.tab_solar = env->buf.tab_solar;
   t.tab_signal = env->buf.tab_signal;
+  t.tab_abs_noise = env->buf.tab_abs_noise;
   t.t0 = env->buf.t0;
   t.phase = env->buf.phase;
   t.ratio = env->buf.ratio;
@@ -396,6 +397,8 @@ int mdr_env_reset(mdr_env_t* env, uint64_t seed, uint32_t episode, void* stream)
   env->has_tables = false;
   env->split_pending = false;
   env->interp_due = false;
+  env->od_ext = nullptr;      // a recorded outdoor-temperature sequence belongs to the episode it was loaded with
+  env->od_ext_rows = 0;
   hipError_t e = mdr::launch_sample(episode_args(*env), (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "reset");
   env->has_episode = true;
@@ -490,6 +493,8 @@ int mdr_env_step(mdr_env_t* env, uint8_t* actions, int action_source, void* stre
     graph_rows(env, &a);
   }
   const bool recording = graph && capturing((hipStream_t)stream);   // launches are recorded, not run: the host state must not move
+  if (recording && mdr_env_graph_room(env) < 1)
+    return fail(env, MDR_ERR_INVALID, "graph mode: the next step lands on an interpolatePower update (mdr_env_graph_room() is 0): run it un-captured");
   hipError_t e = mdr::launch_step(a, env->plan, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "step");
   if (graph) {
@@ -516,7 +521,8 @@ int mdr_env_pack(mdr_env_t* env, int32_t env_index, double* out, void* stream) {
   a.od_old = b.tab_od + row * env->cfg.nb_envs;          // rows of the current time index
   a.solar_new = b.tab_solar + row * env->cfg.nb_envs;
   a.sig_old = b.tab_signal + row * env->cfg.nb_envs;
-  hipError_t e = mdr::launch_pack_env(a, env_index, env->cfg.temp_ref, b.max_power, b.ratio, out, (hipStream_t)stream);
+  hipError_t e = mdr::launch_pack_env(a, env_index, env->cfg.temp_ref, b.max_power, b.ratio,
+                                      b.tab_abs_noise ? b.tab_abs_noise + row * env->cfg.nb_envs : nullptr, out, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "pack_env");
   return MDR_OK;
 }
@@ -524,7 +530,9 @@ int mdr_env_pack(mdr_env_t* env, int32_t env_index, double* out, void* stream) {
 int64_t mdr_env_graph_room(const mdr_env_t* env) {
   if (!env || !env->bound || !env->has_tables) return 0;
   int64_t room = env->cfg.table_steps - (env->k - env->j0);
-  if (interp_mode(env)) room = std::min<int64_t>(room, env->interp_steps - (env->k % env->interp_steps));
+  // interpolation mode: the step that LANDS on an interpolatePower update is never replayed - the update is host work, and
+  // whatever a graph enqueues behind the step (observation, metrics) would still read the signal built from the old base power
+  if (interp_mode(env)) room = std::min<int64_t>(room, env->interp_steps - (env->k % env->interp_steps) - 1);
   return room < 0 ? 0 : room;
 }
 
@@ -816,6 +824,7 @@ int mdr_env_set_cursor(mdr_env_t* env, uint64_t seed, uint32_t episode, int64_t 
   env->episode = episode;
   env->k = k;
   env->j0 = j0;
+  env->dev_row = env->dev_k = -1;   // the caller replaced the buffers (incl. the device cursor): nothing is known about it
   env->has_episode = true;
   env->has_tables = true;
   env->split_pending = false;

@@ -30,6 +30,7 @@ struct TableArgs {
   float* tab_od;
   float* tab_solar;
   double* tab_signal;
+  double* tab_abs_noise;      // optional
   const int64_t* t0;
   const double* phase;
   const double* ratio;
@@ -159,7 +160,8 @@ hipError_t launch_load(const EpisodeArgs& a, const mdr_episode_t& ep, hipStream_
 hipError_t launch_tables(const TableArgs& a, hipStream_t s);
 hipError_t launch_interp_base(const InterpArgs& a, hipStream_t s);
 hipError_t launch_patch_signal_plane(const StepArgs& a, hipStream_t s);   // obs plane 5 <- sig_old row
-hipError_t launch_pack_env(const StepArgs& a, int e, double temp_ref, const double* max_power, const double* ratio, double* out, hipStream_t s);
+hipError_t launch_pack_env(const StepArgs& a, int e, double temp_ref, const double* max_power, const double* ratio,
+                           const double* abs_noise_row, double* out, hipStream_t s);
 hipError_t launch_cursor_advance(int32_t* cursor, hipStream_t s);                       // cursor[0] += 1, cursor[1] += 1
 hipError_t launch_cursor_set(int32_t* cursor, int32_t row, int32_t k, hipStream_t s);
 hipError_t launch_signal_error(const StepArgs& a, double* sq_signal_error_sum, hipStream_t s);   // += (sig_old - P)^2

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void k_fill_tables(TableArgs a) {
   // PowerGrid.step (env 1236-1316): constant base power (env 1249) or the last interpolated one (env 1250-1255)
   const double base = a.base_power ? a.base_power[e] : a.avg_power_per_hvac * (double)a.n_total;
   const double sod = (double)c.sod;
-  double sig;
+  double sig, abs_noise = 0.0;
   if (a.signal_mode == MDR_SIGNAL_FLAT) {
     sig = base;
   } else if (a.signal_mode == MDR_SIGNAL_SINUSOIDALS) {
@@ -283,7 +283,9 @@ __global__ __launch_bounds__(256) void k_fill_tables(TableArgs a) {
       n += w * lattice_noise_1d(x * f, eg, a.episode, a.k0, a.k1);
     }
     sig = fmax(0.0, base + base * a.perlin_amp * n);
+    abs_noise = fabs(base * a.perlin_amp * n);   // PowerGrid.cumulated_abs_noise += |signal * amplitude * perlin| (env 1301)
   }
+  if (a.tab_abs_noise != nullptr) a.tab_abs_noise[i] = abs_noise;
   sig *= a.ratio[e];                        // env 1312
   a.tab_signal[i] = fmin(sig, a.max_power[e]);  // env 1314
 }
@@ -321,9 +323,9 @@ __global__ void k_cursor_set(int32_t* cursor, int32_t row, int32_t k) {
 }
 
 // Everything the dict adapter shows of env e after a step, as one fp64 vector (ONE launch + ONE device->host copy):
-// Ta[N] | Tm[N] (deg C) | sso[N] | flags[N] | reward[N] | OD temp, reg signal, solar gain, cluster power, max power, ratio
+// Ta[N] | Tm[N] (deg C) | sso[N] | flags[N] | reward[N] | OD temp, reg signal, solar gain, cluster power, max power, ratio, |noise|
 __global__ __launch_bounds__(256) void k_pack_env(StepArgs a, int e, double temp_ref, const double* max_power, const double* ratio,
-                                                  double* out) {
+                                                  const double* abs_noise_row, double* out) {
   const int64_t base = (int64_t)e * a.N;
   for (int h = threadIdx.x; h < a.N; h += 256) {
     out[h] = (double)a.Ta[base + h] + temp_ref;
@@ -340,12 +342,13 @@ __global__ __launch_bounds__(256) void k_pack_env(StepArgs a, int e, double temp
     s[3] = a.P[e];
     s[4] = max_power[e];
     s[5] = ratio[e];
+    s[6] = abs_noise_row ? abs_noise_row[e] : 0.0;
   }
 }
 
-hipError_t launch_pack_env(const StepArgs& a, int e, double temp_ref, const double* max_power, const double* ratio, double* out,
-                           hipStream_t s) {
-  hipLaunchKernelGGL(k_pack_env, dim3(1), dim3(256), 0, s, a, e, temp_ref, max_power, ratio, out);
+hipError_t launch_pack_env(const StepArgs& a, int e, double temp_ref, const double* max_power, const double* ratio,
+                           const double* abs_noise_row, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_pack_env, dim3(1), dim3(256), 0, s, a, e, temp_ref, max_power, ratio, abs_noise_row, out);
   return hipGetLastError();
 }
 

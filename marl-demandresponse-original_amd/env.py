@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from .batched_env import BatchedDemandResponseEnv
-from .comm import build_comm_links, nb_comm
+from .comm import nb_comm
 from .config import from_epoch_seconds
 
 
@@ -100,8 +100,13 @@ class _ClusterView:
 class _GridView:
     def __init__(self, env):
         self._env = env
+        # PowerGrid.step of the episode's first time index already ran inside build_environment (env 133): in the perlin
+        # families it has added its |base * amplitude * perlin| and counted one step (env 1301-1302)
         self.cumulated_abs_noise = 0
         self.nb_steps = 0
+        if "perlin" in env._batched.spec.signal_mode_name:
+            self.cumulated_abs_noise = env._abs_noise_now()
+            self.nb_steps = 1
 
     current_signal = property(lambda self: float(self._env._host["S"]))
     max_power = property(lambda self: float(self._env._host["max_power"]))
@@ -181,16 +186,21 @@ class MADemandResponseEnv:
         rewards_dict = dict(zip(self.agent_ids, self._host["reward"].tolist()))
         dones_dict = dict.fromkeys(self.agent_ids, False)   # env 375-390
         info_dict = {"cluster_hvac_power": float(self._host["P"])}
-        if "perlin" in self._batched.spec.signal_mode_name:
+        if "perlin" in self._batched.spec.signal_mode_name:      # env 1301-1302
+            self.power_grid.cumulated_abs_noise += self._abs_noise_now()
             self.power_grid.nb_steps += 1
         return obs_dict, rewards_dict, dones_dict, info_dict
+
+    def _abs_noise_now(self) -> float:
+        """|base_power * amplitude * perlin| of the current time index (what PowerGrid.step adds to cumulated_abs_noise)."""
+        return float(self._host["abs_noise"])
 
     def norm_states(self) -> np.ndarray:
         """``utils.normStateDict(obs_dict[i], config)`` (utils.py:740-880) for every agent at once, float32 [nb_agents, F],
         computed on the device from the same state the last ``reset`` / ``step`` returned (``mdr_env_obs_vector``).  A trainer
         that calls ``normStateDict`` per agent and step (train_ppo.py:69-72, 87-98: ~30 us per call) can index this instead.
-        Comm defects / ``random_sample`` links are drawn from the device's Philox streams here, not from ``np.random`` /
-        ``random`` as the dict's ``message`` lists are; with the default topology and no defects both agree."""
+        Link defects and ``random_sample`` senders are the device's Philox draws of this step - the very draws the dict's
+        ``message`` lists are built from (``mdr_env_comm_draws``), so both views of a step agree in every mode."""
         return self._batched.obs_vector("rows")[0].cpu().numpy()
 
     # ------------------------------------------------------------------ device -> host
@@ -202,26 +212,25 @@ class MADemandResponseEnv:
         k = b.steps_taken
         pack = b.pack_env(0)
         flags = pack[3 * n:4 * n].astype(np.uint8)
-        od, S, solar, P, max_power, ratio = pack[5 * n:].tolist()
+        od, S, solar, P, max_power, ratio, abs_noise = pack[5 * n:].tolist()
         self._host = {
             "Ta": pack[0:n], "Tm": pack[n:2 * n], "sso": pack[2 * n:3 * n].astype(np.int64),
             "on": (flags & 1).astype(bool), "lock": (flags & 2).astype(bool), "reward": pack[4 * n:5 * n].astype(np.float32),
             "od": od, "S": S,
             # SingleHouse.current_solar_gain is 0 until the first update_temperature (env 573)
             "solar": solar if k > 0 else 0,
-            "P": P, "max_power": max_power, "ratio": ratio,
+            "P": P, "max_power": max_power, "ratio": ratio, "abs_noise": abs_noise,
         }
 
     # ------------------------------------------------------------------ communication links (env 806-902)
     def _build_agent_comm_links(self) -> Dict[int, List[int]]:
-        links = build_comm_links(self.default_env_prop["cluster_prop"])
-        return {} if links is None else links
-
-    def _neighbours(self, i):
-        cp = self.default_env_prop["cluster_prop"]
-        if cp["agents_comm_mode"] == "random_sample":
-            return random.sample([j for j in self.agent_ids if j != i], k=nb_comm(cp))
-        return self._links[i]
+        """ClusterHouses.agent_communicators: one table per episode, the one the batched env's flat vector gathers through
+        ('random_fixed' is re-drawn at every reset from (seed, episode); 'random_sample' has no table: env 846-847)."""
+        table = self._batched.comm_links_array()
+        if table is None:
+            return {}
+        rows = table.tolist()
+        return {i: rows[i] for i in self.agent_ids}
 
     _MSG_KEYS = ("current_temp_diff_to_target", "hvac_seconds_since_off", "hvac_curr_consumption",
                  "hvac_max_consumption", "hvac_lockout_duration")
@@ -267,11 +276,16 @@ class MADemandResponseEnv:
         empty = dict.fromkeys(mkeys, 0)
         random_links = cp["agents_comm_mode"] == "random_sample"
         od, dtm, solar, S, P = h["od"], self.datetime, h["solar"], h["S"], h["P"]
+        # the random part of the gather (env 976-1002) comes from the device: this step's `random.sample` senders and
+        # `np.random.rand() > comm_defect_prob` outcomes are the ones norm_states() / obs_vector use
+        drawn_senders = drawn_keep = None
+        if (random_links or defect > 0) and nb_comm(cp) > 0 and cp["agents_comm_mode"] != "no_message":
+            s_dev, k_dev = self._batched.comm_draws()
+            drawn_senders, drawn_keep = s_dev[0].cpu().tolist(), k_dev[0].cpu().tolist()
         obs = {}
         for i in self.agent_ids:
-            senders = self._neighbours(i) if random_links else self._links[i]
-            # one np.random.rand() per link, in link order (env 992): the same stream as the reference consumes
-            keep = np.random.rand(len(senders)) > defect if senders else ()
+            senders = drawn_senders[i] if random_links else self._links[i]
+            keep = drawn_keep[i] if drawn_keep is not None else (True,) * len(senders)
             obs[i] = {
                 "OD_temp": od,
                 "datetime": dtm,
@@ -307,4 +321,5 @@ class MADemandResponseEnv:
         other.cluster = _ClusterView(other)
         other.power_grid = _GridView(other)
         other.power_grid.nb_steps = self.power_grid.nb_steps
+        other.power_grid.cumulated_abs_noise = self.power_grid.cumulated_abs_noise
         return other

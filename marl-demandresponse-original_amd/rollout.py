@@ -221,13 +221,18 @@ def deploy_policy(env, policy, nb_steps: int, seed: int = 0, use_graph: Optional
         one_step(0)
     torch.cuda.current_stream(dev).wait_stream(side)
     done = 1
-    if env.graph_room() < 1:
-        env.graph_replayed(0)
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        one_step(0)
+    g = None
     while done < nb_steps:
+        env.graph_replayed(0)                  # tables refilled / device cursor current before the room is read
         n = min(env.graph_room(), nb_steps - done)
+        if n < 1:                              # the next step lands on an interpolatePower update: host work, never replayed
+            one_step(0)
+            done += 1
+            continue
+        if g is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                one_step(0)
         for _ in range(n):
             g.replay()
         env.graph_replayed(n)

@@ -64,7 +64,9 @@ TAG_HOUSE_THERMO = 3  # x0..x3 -> triangular factors for Ua, Cm, Ca, Hm
 TAG_ENV_START = 4     # x0 -> days ; x1 -> seconds ; x2 -> phase ; x3 -> artificial ratio
 TAG_OD_NOISE = 5      # counter word 1 = time index ; x0,x1 -> gauss
 TAG_PERLIN = 6        # counter word 1 = lattice index ; x0 -> gradient
-TAG_COMM = 7          # message-link defects (kernel k_obs_*): not restated in the oracle (statistical test only)
+TAG_COMM = 7          # counter word 1 = receiving house, word 2 = time index, tag | (slot >> 2) << 8 ; word (slot & 3) -> link defect
+TAG_LINKS = 9         # counter word 1 = receiving house, word 2 = time index, tag | (draw >> 2) << 8 ; word (draw & 3) -> sender draw
+COMM_KEY_MIX = 0x85EBCA6B   # streams 7 and 9 carry the time index where the others carry the episode: the episode is folded into key word 1
 TAG_INTERP = 8        # counter word 1 = draw index q, word 2 = time index ; x0 -> house sampled for the base power
 ENV_LEVEL = 0xFFFFFFFF
 
@@ -552,6 +554,8 @@ class OracleEnv:
         self.OD = self._od_temp(0)                        # env 793
         self.base_power = np.zeros(E)                     # env 1190
         self.tsli = self.interp_period + 1                # env 1155
+        self.cumulated_abs_noise = np.zeros(E)            # env 1117
+        self.grid_steps = 0                               # env 1118
         self.S = self._signal(0)                          # env 133
 
     # ---- per-env time functions ------------------------------------------- #
@@ -611,6 +615,8 @@ class OracleEnv:
             noise = perlin_octaves(x, lambda l: self.perlin_gradient(ids, l),
                                    s.signal_params["nb_octaves"], s.signal_params["octaves_step"])
             sig = np.maximum(0.0, base + base * amp * noise)
+            self.cumulated_abs_noise = self.cumulated_abs_noise + np.abs(base * amp * noise)   # env 1301
+            self.grid_steps += 1                                                               # env 1302
         sig = sig * self.ratio                               # env 1312
         return np.minimum(sig, self.max_power)               # env 1314
 
@@ -705,9 +711,61 @@ class OracleEnv:
         return np.concatenate([(i - before + np.arange(before)[None, :]) % n,
                                (i + 1 + np.arange(after)[None, :]) % n], axis=1).astype(np.int64)
 
-    def norm_state(self, config, links=None):
+    # ---- the random part of the message gather (env 976-1002), as the HIP kernels draw it ------------------------------------- #
+    def _comm_key(self):
+        k0, k1 = seed_key(self.seed)
+        return k0, k1 ^ ((self.episode * COMM_KEY_MIX) & 0xFFFFFFFF)
+
+    def link_keep(self, c: int, defect_prob: float) -> np.ndarray:
+        """`np.random.rand() > comm_defect_prob` per link, in link order (env 992), restated on Philox stream 7: one block of four
+        words serves message slots 4b..4b+3 of a (env, receiving house, time index).  The comparison is done in fp32, as the
+        kernels do it.  -> bool [E, N, c], True = the message is delivered."""
+        E, N = self.E, self.N
+        keep = np.ones((E, N, c), dtype=bool)
+        if not (np.float32(defect_prob) > np.float32(0.0)):
+            return keep
+        k0, k1 = self._comm_key()
+        e = self._env_ids()[:, None]
+        h = self._house_ids()[None, :]
+        for b in range((c + 3) // 4):
+            words = philox4x32_10(e, h, self.k, TAG_COMM | (b << 8), k0, k1)
+            for w in range(4):
+                m = 4 * b + w
+                if m < c:
+                    keep[:, :, m] = u01(words[w]).astype(np.float32) > np.float32(defect_prob)
+        return keep
+
+    def sampled_senders(self, c: int) -> np.ndarray:
+        """agents_comm_mode 'random_sample' (env 976-983): `random.sample(others, k=nb_comm)` per house and step - an ORDERED draw
+        without replacement - restated on Philox stream 9 by rejection: slot m takes uniform picks `(x * (N - 1)) >> 32` among the
+        N - 1 other houses (draw d of a house = word d & 3 of block d >> 2) until one is not among the m senders already chosen;
+        pick p maps to house id p (p < own id) or p + 1.  -> int64 [E, N, c] global house ids."""
+        E, N = self.E, self.N
+        D = self.N_total - 1
+        k0, k1 = self._comm_key()
+        e = np.broadcast_to(self._env_ids()[:, None], (E, N))
+        hg = np.broadcast_to(self._house_ids()[None, :], (E, N))
+        picks = np.full((E, N, c), -1, dtype=np.int64)
+        draws = np.zeros((E, N), dtype=np.int64)
+        for m in range(c):
+            pending = np.ones((E, N), dtype=bool)
+            while pending.any():
+                words = philox4x32_10(e, hg, self.k, TAG_LINKS | ((draws >> 2) << 8), k0, k1)
+                x = np.choose(draws & 3, words)
+                pick = mulhi_pick(x, D)
+                taken = (picks[:, :, :m] == pick[:, :, None]).any(axis=2)
+                accept = pending & ~taken
+                picks[:, :, m] = np.where(accept, pick, picks[:, :, m])
+                draws = draws + pending           # every pending house consumed one draw
+                pending = pending & taken
+        return np.where(picks < hg[:, :, None], picks, picks + 1)
+
+    def norm_state(self, config, links=None, keep=None):
         """utils.normStateDict (utils.py:740-880) for every house -> float64 [E, N, F], messages from
-        SingleHouse.message (env 624-662) gathered through `links` ([N, c] sender ids; None = 'neighbours')."""
+        SingleHouse.message (env 624-662) gathered through `links` ([N, c] sender ids shared by the envs, or [E, N, c];
+        None = the mode's own: circular 'neighbours', or the step's `sampled_senders` for 'random_sample').
+        `keep` (bool [E, N, c], default `link_keep` at the config's comm_defect_prob): links that deliver; the others
+        carry the all-zero message of SingleHouse.message(empty=True) (env 996-1001)."""
         env = config["default_env_prop"]
         sp, mp = env["state_properties"], env["message_properties"]
         house, hvac = config["default_house_prop"], config["default_hvac_prop"]
@@ -717,7 +775,13 @@ class OracleEnv:
         if s.comm_mode == "no_message":
             links = np.zeros((N, 0), dtype=np.int64)
         elif links is None:
-            links = self.circular_links(c)
+            links = self.sampled_senders(c) if s.comm_mode == "random_sample" else self.circular_links(c)
+        links = np.asarray(links, dtype=np.int64)
+        if links.ndim == 2:
+            links = np.broadcast_to(links[None, :, :], (E,) + links.shape)
+        if keep is None:
+            keep = self.link_keep(links.shape[2], float(env["cluster_prop"].get("comm_defect_prob", 0.0)))
+        rows = np.arange(E)[:, None]
         den = s.norm_reg_sig * s.cfg_nb_agents
         cal = self._time(self.k)
         ones = np.ones((E, N))
@@ -738,15 +802,18 @@ class OracleEnv:
             cols += [self.COP / hvac["COP"], self.latent / hvac["latent_cooling_fraction"]]
         cols += [self.on.astype(float), self.lock.astype(float), self.sso / self.lockout, self.lockout / self.lockout,
                  (self.S / den)[:, None] * ones, (self.P / den)[:, None] * ones]
-        for m in range(links.shape[1]):
-            j = links[:, m]
-            cols += [(self.Ta - self.target)[:, j] / 5, self.sso[:, j] / self.lockout,
-                     np.where(self.on, self.Pmax, 0.0)[:, j] / s.norm_reg_sig, self.Pmax[:, j] / s.norm_reg_sig]
+        for m in range(links.shape[2]):
+            j = links[:, :, m]
+            z = keep[:, :, m].astype(np.float64)
+            g = lambda a: a[rows, j]              # the sender's value for every (env, receiving house)
+            msg = [g(self.Ta - self.target) / 5, g(self.sso) / self.lockout,
+                   g(np.where(self.on, self.Pmax, 0.0)) / s.norm_reg_sig, g(self.Pmax) / s.norm_reg_sig]
             if mp["thermal"]:
-                cols += [self.Ua[:, j] / house["Ua"], self.Cm[:, j] / house["Cm"], self.Ca[:, j] / house["Ca"], self.Hm[:, j] / house["Hm"]]
+                msg += [g(self.Ua) / house["Ua"], g(self.Cm) / house["Cm"], g(self.Ca) / house["Ca"], g(self.Hm) / house["Hm"]]
             if mp["hvac"]:
-                cols += [self.COP[:, j] / hvac["COP"], self.latent[:, j] / hvac["latent_cooling_fraction"],
-                         self.capacity[:, j] / hvac["cooling_capacity"]]
+                msg += [g(self.COP) / hvac["COP"], g(self.latent) / hvac["latent_cooling_fraction"],
+                        g(self.capacity) / hvac["cooling_capacity"]]
+            cols += [z * v for v in msg]
         return np.stack([np.broadcast_to(cc, (E, N)) for cc in cols], axis=-1)
 
     def bangbang_actions(self):

@@ -126,18 +126,48 @@ def run_scenario(name, patches, seed, T, policy, perlin=False, norm_steps=(0, 1,
         ref_harness.set_perlin_gradient(None)
     random.seed(seed)
     np.random.seed(seed)
+    # the random part of the message gather (env 976-1002): which senders `random.sample` picked for each house
+    # ('random_sample' mode) and which links `np.random.rand() > comm_defect_prob` dropped, recorded at the norm steps so
+    # that the oracle's norm_state can be pinned on the reference's vectors with the reference's own draws
+    cl = cfg["default_env_prop"]["cluster_prop"]
+    record_comm = cl["agents_comm_mode"] == "random_sample" or cl["comm_defect_prob"] > 0
+    sampled = []
+    real_sample = random.sample
+    if cl["agents_comm_mode"] == "random_sample":
+        def recording_sample(population, k):
+            picked = real_sample(population, k=k)
+            sampled.append(list(picked))
+            return picked
+        random.sample = recording_sample
+    msg_keep, msg_senders = [], []
+
+    def capture_comm(obs):
+        if not record_comm:
+            return
+        c = len(obs[0]["message"])
+        msg_keep.append(np.array([[m["hvac_max_consumption"] != 0 for m in obs[i]["message"]] for i in range(N)], dtype=np.uint8).reshape(N, c))
+        if cl["agents_comm_mode"] == "random_sample":
+            assert len(sampled) == N, len(sampled)       # one random.sample call per house, in house order (env 976-983)
+            msg_senders.append(np.array(sampled, dtype=np.int32).reshape(N, c))
+        else:
+            comm_now = env.cluster.agent_communicators
+            msg_senders.append(np.array([comm_now[i] for i in range(N)], dtype=np.int32).reshape(N, c))
+
     env = ref["MADemandResponseEnv"](cfg)
+    del sampled[:]
     obs = env.reset()
     rec = capture_params(env)
     od = [env.cluster.current_OD_temp]
     S = [float(env.power_grid.current_signal)]
     base_power = [float(env.power_grid.base_power)]
+    abs_noise = [float(env.power_grid.cumulated_abs_noise)]
     act_rng = np.random.default_rng(seed + 1000)
     actors = {i: ref["BangBangController"]({"id": i}, cfg) for i in range(N)}
     norm = []
     want_norm = set(s if s >= 0 else T + 1 + s for s in norm_steps)
     if 0 in want_norm:
         norm.append(np.array([ref["utils"].normStateDict(obs[i], cfg) for i in range(N)]))
+        capture_comm(obs)
     keys = ("Ta", "Tm", "on", "lock", "sso")
     out = {k: [] for k in keys}
     out.update(P=[], reward=[], solar=[], actions=[])
@@ -161,6 +191,7 @@ def run_scenario(name, patches, seed, T, policy, perlin=False, norm_steps=(0, 1,
         else:
             raise ValueError(policy)
         out["actions"].append(np.array([bool(a[i]) for i in range(N)], dtype=np.uint8))
+        del sampled[:]
         obs, rew, done, info = env.step(a)
         st = capture_state(env)
         for k in keys:
@@ -171,9 +202,12 @@ def run_scenario(name, patches, seed, T, policy, perlin=False, norm_steps=(0, 1,
         od.append(env.cluster.current_OD_temp)
         S.append(float(env.power_grid.current_signal))
         base_power.append(float(env.power_grid.base_power))
+        abs_noise.append(float(env.power_grid.cumulated_abs_noise))
         assert not any(done.values())
         if (t + 1) in want_norm:
             norm.append(np.array([ref["utils"].normStateDict(obs[i], cfg) for i in range(N)]))
+            capture_comm(obs)
+    random.sample = real_sample
     meta = dict(name=name, seed=seed, T=T, N=N, policy=policy, perlin_standin=bool(perlin),
                 norm_steps=sorted(want_norm), config=jsonable(cfg),
                 generated_by="tests/golden/make_golden.py from /root/reference (snapshot 2025-03-14)")
@@ -185,6 +219,12 @@ def run_scenario(name, patches, seed, T, policy, perlin=False, norm_steps=(0, 1,
     comm = env.cluster.agent_communicators
     if comm and all(len(comm[i]) == len(comm[0]) for i in range(N)):
         arrays["links"] = np.array([comm[i] for i in range(N)], dtype=np.int32).reshape(N, -1)
+    if perlin:
+        arrays["cumulated_abs_noise"] = np.array(abs_noise, dtype=np.float64)   # PowerGrid.cumulated_abs_noise after reset and every step
+        arrays["grid_nb_steps"] = np.int64(env.power_grid.nb_steps)
+    if record_comm:
+        arrays["msg_keep"] = np.array(msg_keep, dtype=np.uint8)            # [norm step][N][c] 1 = delivered
+        arrays["msg_senders"] = np.array(msg_senders, dtype=np.int32)      # [norm step][N][c] sender house ids
     if extra:
         arrays.update(extra)
         arrays["base_power"] = np.array(base_power, dtype=np.float64)
@@ -338,6 +378,20 @@ def main():
                                            PG + "signal_mode": "flat"}, 83, 30, "mixed", norm_steps=(0, 5, -1))
     run_scenario("s11_comm_no_message", {CL + "nb_agents": 6, CL + "agents_comm_mode": "no_message",
                                          PG + "signal_mode": "flat"}, 84, 30, "mixed", norm_steps=(0, 5, -1))
+    # S13: the random part of the message gather (env 976-1002): link defects and per-step `random.sample` senders, with the
+    # reference's own draws recorded next to its normStateDict vectors
+    run_scenario("s13_comm_defects_neighbours", dict(allflags, **{
+        CL + "nb_agents": 14, CL + "comm_defect_prob": 0.3, "noise_house_prop.noise_mode": "big_noise",
+        "noise_hvac_prop.noise_mode": "big_noise", PG + "signal_mode": "flat"}), 85, 30, "mixed", norm_steps=(0, 1, 5, -1))
+    run_scenario("s13_comm_defects_closed_groups", {
+        CL + "nb_agents": 12, CL + "nb_agents_comm": 3, CL + "agents_comm_mode": "closed_groups", CL + "comm_defect_prob": 0.5,
+        PG + "signal_mode": "flat"}, 86, 20, "mixed", norm_steps=(0, 3, -1))
+    run_scenario("s13_comm_random_sample", {
+        CL + "nb_agents": 13, CL + "nb_agents_comm": 5, CL + "agents_comm_mode": "random_sample",
+        "noise_house_prop.noise_mode": "big_noise", MS + "hvac": True, PG + "signal_mode": "flat"}, 87, 20, "mixed", norm_steps=(0, 1, 4, -1))
+    run_scenario("s13_comm_random_sample_defects", {
+        CL + "nb_agents": 9, CL + "nb_agents_comm": 8, CL + "agents_comm_mode": "random_sample", CL + "comm_defect_prob": 0.1,
+        "noise_hvac_prop.noise_mode": "big_noise", PG + "signal_mode": "flat"}, 88, 20, "mixed", norm_steps=(0, 2, -1))
     # S12: base_power_mode "interpolation" (the reference's DEFAULT, env 1195-1255) on a small synthetic grid
     gp, gx = make_small_grid(5)
     run_scenario("s12_interp_default_like", dict(gp, **{

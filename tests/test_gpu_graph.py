@@ -23,6 +23,37 @@ def _cfg(N, **patches):
     return cfg
 
 
+def _replay_episode(env, one, T, done=0):
+    """Drive `one` (a step of the episode enqueued on the current stream) to step T: captured once - as soon as the env allows a
+    replay - and replayed graph_room() times between the host's turns; the step that lands on an interpolatePower update runs
+    eagerly (graph_room() == 0 there).  Returns the list of replay counts."""
+    g, rooms = None, []
+    if done == 0:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):             # warm-up on a side stream (also syncs the device cursor)
+            one()
+        torch.cuda.current_stream().wait_stream(side)
+        done = 1
+    while done < T:
+        env.graph_replayed(0)
+        n = min(env.graph_room(), T - done)
+        rooms.append(n)
+        if n < 1:
+            one()
+            done += 1
+            continue
+        if g is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                one()
+        for _ in range(n):
+            g.replay()
+        env.graph_replayed(n)
+        done += n
+    return rooms
+
+
 def _policy_step(env, fused, obs_buf, act, prob, step_dev):
     env.obs_vector("rows", out=obs_buf)
     fused.sample(obs_buf.view(-1, obs_buf.shape[-1]), 77, 0, action=act, a_prob=prob, step_dev=step_dev)
@@ -114,25 +145,10 @@ def test_graph_mode_with_interpolated_base_power():
     b = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=4, device="cuda:0", seed=2, interp_grid=grid)
     a.reset(episode=0)
     b.reset(episode=0)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        a.step_bangbang()
-    torch.cuda.current_stream().wait_stream(side)
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        a.step_bangbang()
-    done, T = 1, 23
-    rooms = []
-    while done < T:
-        n = min(a.graph_room(), T - done)
-        rooms.append(n)
-        for _ in range(n):
-            g.replay()
-        a.graph_replayed(n)
-        done += n
+    T = 23
+    rooms = _replay_episode(a, a.step_bangbang, T)
     b.rollout(T)
-    assert max(rooms) <= 5                          # never across an update (every 5 steps)
+    assert max(rooms) <= 4 and 0 in rooms           # never onto an update (every 5 steps): that step runs eagerly
     for k in ("Ta", "sso", "reward", "P", "base_power", "obs"):
         assert torch.equal(a.t[k], b.t[k]), k
 
@@ -210,26 +226,112 @@ def test_fuzz_graph_replay_vs_eager(idx):
         a.step_bangbang()
         a.obs_vector("rows", out=obs)
 
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        one()
-    torch.cuda.current_stream().wait_stream(side)
-    if a.graph_room() < 1:
-        a.graph_replayed(0)
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        one()
     T = int(rng.integers(5, 40))
-    done = 1
-    while done < T:
-        n = min(a.graph_room(), T - done)
-        assert n >= 1
-        for _ in range(n):
-            g.replay()
-        a.graph_replayed(n)
-        done += n
+    _replay_episode(a, one, T)
     b.rollout(T)
     for k in ("Ta", "Tm", "sso", "flags", "reward", "obs", "P"):
         assert torch.equal(a.t[k], b.t[k]), "%s (case %d: E=%d N=%d K=%d T=%d)" % (k, idx, E, N, table_steps, T)
     assert torch.equal(obs, b.obs_vector("rows"))
+    assert torch.equal(a.reg_signal(), b.reg_signal())
+
+
+def _interp_flat_cfg(N):
+    return _cfg(N, **{"default_env_prop.power_grid_prop.base_power_mode": "interpolation", "default_env_prop.time_step": 60,
+                      "default_env_prop.power_grid_prop.signal_mode": "flat"})      # signal == base power: moves at every update
+
+
+@pytest.mark.parametrize("T", [5, 10, 19, 20, 21])
+def test_graph_step_plus_observation_across_interpolation_updates(T):
+    """with interpolated base power the step that lands on an update is not replayed, so an observation captured
+    behind the step never reads the signal of the old base power - also when the episode ENDS on an update (T = 5, 10, 20)."""
+    import mdr_amd
+    from tests import golden_util as gu
+    grid = gu.Golden("s12_interp_default_like").interp_grid()
+    cfg = _interp_flat_cfg(40)
+    a = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=4, device="cuda:0", seed=8, interp_grid=grid, graph_mode=True)
+    b = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=4, device="cuda:0", seed=8, interp_grid=grid)
+    a.reset(episode=0)
+    b.reset(episode=0)
+    F = a.obs_vector_length()
+    obs = torch.empty((4, 40, F), device="cuda:0")
+    sig = torch.empty(4, dtype=torch.float64, device="cuda:0")
+
+    def one():
+        a.step_bangbang()
+        a.obs_vector("rows", out=obs)
+        sig.copy_(a.reg_signal())
+
+    rooms = _replay_episode(a, one, T)
+    assert max(rooms, default=0) <= 4
+    b.rollout(T)
+    assert len(set(b.t["base_power"].tolist())) > 1
+    assert torch.equal(sig, b.reg_signal()), "reg_signal captured behind the step is stale"
+    assert torch.equal(obs, b.obs_vector("rows"))
+    for k in ("Ta", "sso", "reward", "P", "base_power", "obs"):
+        assert torch.equal(a.t[k], b.t[k]), k
+
+
+def test_deploy_policy_graph_equals_eager_with_interpolated_base_power():
+    """deploy_policy's sq_signal_error_sum uses the signal of the step just taken: graph replay == eager also across updates."""
+    import mdr_amd
+    from mdr_amd.policy import FusedActor
+    from mdr_amd.rollout import ActorMLP, deploy_policy
+    from tests import golden_util as gu
+    grid = gu.Golden("s12_interp_default_like").interp_grid()
+    E, N, T = 6, 40, 20                                  # ends on an update
+    cfg = _interp_flat_cfg(N)
+    torch.manual_seed(2)
+    envs = [mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=6, interp_grid=grid, graph_mode=gm) for gm in (True, True, False)]
+    for e in envs:
+        e.reset(episode=0)
+    fused = FusedActor.from_module(ActorMLP(envs[0].obs_vector_length()).cuda())
+    res = [deploy_policy(envs[0], fused, T, seed=4, use_graph=True), deploy_policy(envs[1], fused, T, seed=4, use_graph=False),
+           deploy_policy(envs[2], fused, T, seed=4)]
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]) and torch.equal(res[0][k], res[2][k]), k
+    for k in ("Ta", "sso", "reward", "base_power"):
+        assert torch.equal(envs[0].t[k], envs[2].t[k]), k
+
+
+def test_capture_of_a_step_that_lands_on_an_update_is_refused():
+    import mdr_amd
+    from tests import golden_util as gu
+    grid = gu.Golden("s12_interp_default_like").interp_grid()
+    a = mdr_amd.BatchedDemandResponseEnv(_interp_flat_cfg(16), nb_envs=2, device="cuda:0", seed=1, interp_grid=grid, graph_mode=True)
+    a.reset(episode=0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(4):
+            a.step_bangbang()
+    torch.cuda.current_stream().wait_stream(side)
+    assert a.graph_room() == 0                             # step 5 lands on the update
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(ValueError, match="interpolatePower update"):
+        with torch.cuda.graph(g):
+            a.step_bangbang()
+
+
+def test_load_state_dict_resyncs_the_device_cursor():
+    """a snapshot taken while the device cursor was lazily stale, loaded into an env whose host-side picture of that
+    cursor happens to match the snapshot's (k - j0, k): the cursor in the loaded slab must not be trusted."""
+    import mdr_amd
+    cfg = _cfg(20)
+    a = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=3, device="cuda:0", seed=5, table_steps=8, graph_mode=True)
+    a.reset(episode=0)
+    for _ in range(5):
+        a.step_bangbang()                                  # device cursor = (5, 5)
+    a.reset(episode=1)                                     # host: k = 0; the device cursor is re-synced lazily, i.e. still (5, 5)
+    sd = a.state_dict()
+    b = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=3, device="cuda:0", seed=5, table_steps=8, graph_mode=True)
+    b.reset(episode=1)
+    b.graph_replayed(0)                                    # b's device cursor synced at (0, 0) - what the snapshot's host state says too
+    b.load_state_dict(sd)
+    plain = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=3, device="cuda:0", seed=5, table_steps=8)
+    plain.reset(episode=1)
+    for _ in range(3):
+        b.step_bangbang()
+        plain.step_bangbang()
+        assert torch.equal(b.reg_signal(), plain.reg_signal())
+    for k in ("Ta", "sso", "reward", "obs"):
+        assert torch.equal(b.t[k], plain.t[k]), k

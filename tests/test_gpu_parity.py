@@ -382,3 +382,64 @@ def test_single_house_envs_in_bulk_match_the_group_kernel_and_the_oracle():
     big.step_bangbang()
     small.step_bangbang()
     assert torch.equal(big.t["Ta"][E - 4096:], small.t["Ta"]) and torch.equal(big.t["actions"][E - 4096:], small.t["actions"])
+
+
+def test_c2_literal_1024_envs_x_50_houses_1000_steps():
+    """BASELINE.json configs[1] exactly as SURVEY.md 8(d) spells it out: E = 1024, N = 50, no house / HVAC noise (uniform
+    parameters), constant outdoor temperature (no weather noise), no solar gain, flat signal on constant base power, fixed start
+    date, initial Ta = Tm = 20 + |N(0, 5)| from seed 1234, recorded Bernoulli(0.5) actions from seed 1234, T = 1000 - the HIP
+    path against the oracle at EVERY step: integer state and cluster power exactly, temperatures and rewards to 1e-5."""
+    from oracle import mdr_oracle as mo
+    E, N, T = 1024, 50, 1000
+    cfg = _cfg(N, **{"noise_house_prop.noise_mode": "no_noise", "noise_hvac_prop.noise_mode": "no_noise",
+                     "default_env_prop.cluster_prop.temp_mode": "constant", "default_house_prop.solar_gain_bool": False,
+                     "default_env_prop.power_grid_prop.signal_mode": "flat",
+                     "default_env_prop.start_datetime_mode": "fixed", "default_env_prop.start_datetime": "2021-06-15 12:00:00"})
+    rng = np.random.default_rng(1234)
+    house, hvac = cfg["default_house_prop"], cfg["default_hvac_prop"]
+    start = 20.0 + np.abs(rng.normal(0.0, 5.0, size=(E, N)))
+    full = lambda v, dt=np.float64: np.full((E, N), v, dtype=dt)
+    params = dict(Ta=start, Tm=start.copy(), target=full(house["target_temp"]), deadband=full(house["deadband"]),
+                  Ua=full(house["Ua"]), Cm=full(house["Cm"]), Ca=full(house["Ca"]), Hm=full(house["Hm"]),
+                  capacity=full(hvac["cooling_capacity"]), COP=full(hvac["COP"]), latent=full(hvac["latent_cooling_fraction"]),
+                  lockout=full(hvac["lockout_duration"], np.int64),
+                  t0=np.full(E, mo.to_epoch_seconds(__import__("datetime").datetime(2021, 6, 15, 12, 0, 0)), dtype=np.int64),
+                  phase=np.zeros(E), ratio=np.ones(E))
+    actions = (rng.random((T, E, N)) < 0.5).astype(np.uint8)
+    env = _mdr().BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=1234)
+    env.load_episode(params, seed=1234, episode=0)
+    ora = mo.OracleEnv(cfg, nb_envs=E)
+    ora.seed, ora.episode = 1234, 0
+    ora.load_episode(params)
+    assert float(ora.OD.std()) == 0.0 and float(ora.S.std()) == 0.0          # fixed outdoor temperature, flat signal
+    acts = torch.from_numpy(actions).to("cuda:0")
+    worst_T = worst_r = 0.0
+    for t in range(T):
+        obs, reward, done, info = env.step(acts[t])
+        r_ref = ora.step(actions[t])
+        flags = env.t["flags"].cpu().numpy()
+        assert np.array_equal((flags & 1).astype(bool), ora.on) and np.array_equal((flags & 2).astype(bool), ora.lock), t
+        assert np.array_equal(env.t["sso"].cpu().numpy(), ora.sso), t
+        assert np.array_equal(info["cluster_hvac_power"].cpu().numpy(), ora.P), t
+        Ta = env.house_temp().cpu().numpy()
+        worst_T = max(worst_T, float(np.max(np.abs(Ta - ora.Ta) / np.abs(ora.Ta))),
+                      float(np.max(np.abs(env.house_mass_temp().cpu().numpy() - ora.Tm) / np.abs(ora.Tm))))
+        worst_r = max(worst_r, float(np.max(np.abs(reward.cpu().numpy() - r_ref) - R_RTOL * np.abs(r_ref))))
+        assert worst_T <= T_RTOL and worst_r <= R_ATOL, (t, worst_T, worst_r)
+    np.testing.assert_allclose(obs.cpu().numpy(), ora.dynamic_obs(), rtol=2e-5, atol=2e-6)
+    assert worst_T < 2e-6            # observed ~5e-7: the difference form holds fp32 an order below the bar over 1000 steps
+
+
+def test_reset_drops_a_loaded_outdoor_temperature_table():
+    """load_episode(od_table=...) followed by reset() must not keep replaying the recorded outdoor temperatures."""
+    g = gu.Golden("s1_c1_flat")
+    env = run_fixture(g)
+    env.step_bangbang()
+    env.reset(seed=77, episode=3)
+    fresh = _mdr().BatchedDemandResponseEnv(g.config, nb_envs=1, device="cuda:0", seed=77)
+    fresh.reset(episode=3)
+    assert torch.equal(env.t["tab_od"], fresh.t["tab_od"])
+    for _ in range(5):
+        env.step_bangbang()
+        fresh.step_bangbang()
+    assert torch.equal(env.t["Ta"], fresh.t["Ta"]) and torch.equal(env.od_temp(), fresh.od_temp())
