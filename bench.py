@@ -278,8 +278,8 @@ def c5_leg(rk: Ranks, mdr, args):
     # k_step_partial / k_step_finish launches without the exchange)
     ex = env._exchange()
     for _ in range(5):
-        ex.gather_totals(env)
-    _, coll_ms = timed(rk, lambda: [ex.gather_totals(env) for _ in range(K)], K)
+        ex.gather_partials(env)
+    _, coll_ms = timed(rk, lambda: [ex.gather_partials(env) for _ in range(K)], K)
     cfg_local = c3_config(mdr)
     cfg_local["default_env_prop"]["cluster_prop"]["nb_agents"] = cnt
     local = mdr.BatchedDemandResponseEnv(cfg_local, nb_envs=1, device=rk.device, seed=2024, table_steps=64)
@@ -292,8 +292,8 @@ def c5_leg(rk: Ranks, mdr, args):
             "houses_per_rank": cnt, "us_per_step": wall / K * 1e6, "event_us_per_step_rank0": ev_ms * 1e3,
             "kernel_us_per_step": kern_ms * 1e3, "collective_us_per_step": coll_ms * 1e3,
             "backend": "rccl" if rk.backend == "nccl" else rk.backend,
-            "note": "us_per_step is host wall-clock per step (max over ranks) of step_begin -> all_gather_into_tensor([3][E] f64 per rank) -> "
-                    "step_end_gathered; kernel = the two step kernels alone on an unsharded env of this rank's %d houses; "
+            "note": "us_per_step is host wall-clock per step (max over ranks) of step_begin_records -> all_gather_into_tensor(24 B per 1024-house workgroup) -> "
+                    "step_end_records; kernel = the two step kernels alone on an unsharded env of this rank's %d houses; "
                     "collective = the all-gather alone, back to back" % cnt}
 
 

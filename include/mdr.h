@@ -281,6 +281,16 @@ int mdr_env_step_end(mdr_env_t *env, void *stream);
  * the fly (sum, sum, max over ranks, in rank order) while writing rewards - the all-reduced values are never stored. */
 int mdr_env_step_end_gathered(mdr_env_t *env, const double *gathered, int32_t world, void *stream);
 
+/* The same split with one launch less: step_begin_records stops at the per-workgroup partial records - `partials`
+ * [E][records_per_env][3] (power sum, penalty sum, penalty max per 1024-house workgroup; records_per_env >=
+ * mdr_partials_per_env(nb_houses), the tail stays as the caller left it: zero) - the caller ALL-GATHERS the ranks' `partials`
+ * into `records` [world][E][records_per_env][3] (equal records_per_env on every rank: the largest shard's), and every workgroup
+ * of step_end_records re-sums its env's world * records_per_env records from L2 in one fixed order while it writes the rewards.
+ * Two launches around ONE collective; payload 24 B per 1024 houses instead of 24 B per rank - still latency-bound.
+ * records == NULL: this device's own `partials`, world = 1 (the unsharded split path of mdr_env_step for N > 4096). */
+int mdr_env_step_begin_records(mdr_env_t *env, uint8_t *actions, int action_source, int32_t records_per_env, void *stream);
+int mdr_env_step_end_records(mdr_env_t *env, const double *records, int32_t world, void *stream);
+
 /* Sharded houses with base_power_mode "interpolation": PowerGrid.interpolatePower (env 1195-1234) averages up to
  * interp_nb_agents houses drawn from the WHOLE env (env 1209-1215), so the update at episode start and every
  * ceil(interp_update_period / time_step) steps (env 1250-1255) needs one more exchange.  After mdr_env_begin_episode /

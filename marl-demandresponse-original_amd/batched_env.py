@@ -44,7 +44,7 @@ class BatchedDemandResponseEnv:
                  table_steps: int = 64, env_offset: int = 0,
                  house_shard: Optional[Tuple[int, int]] = None, process_group=None,
                  stagger_bytes: int = 2304, interp_grid=None, regenerate_missing_grid: bool = True,
-                 graph_mode: bool = False, exchange_always: bool = False):
+                 graph_mode: bool = False, exchange_always: bool = False, partial_records: Optional[int] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedDemandResponseEnv needs a ROCm device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -72,6 +72,9 @@ class BatchedDemandResponseEnv:
         self._od_table = None
         self._regenerate_missing_grid = bool(regenerate_missing_grid)
         self._stagger = int(stagger_bytes)
+        # sharded houses: records per env in `partials` (the largest shard's workgroup count: every rank all-gathers equal blocks);
+        # None = this shard's own count, raised to the group's maximum at the first episode (TorchDistExchange.agree_partial_records)
+        self._partial_records = None if partial_records is None else int(partial_records)
         self.graph_mode = bool(graph_mode)      # device-resident cursor: steps / observations can be captured in a graph
         self._handle = C.c_void_p()
         self._cfg = self._make_config()
@@ -125,6 +128,9 @@ class BatchedDemandResponseEnv:
     def _layout(self):
         E, N, K1 = self.nb_envs, self.nb_houses, self.table_steps + 1
         nblk = int(self._lib.mdr_partials_per_env(N))
+        if self._partial_records is not None and self._partial_records < nblk:
+            raise ValueError("partial_records smaller than the %d workgroups this shard needs" % nblk)
+        nblk = self._partial_records = max(nblk, self._partial_records or 0)
         items = [(n, torch.float32, (E, N)) for n in _HOUSE_F32]
         items += [(n, torch.int32, (E, N)) for n in _HOUSE_I32]
         items += [(n, torch.uint8, (E, N)) for n in _HOUSE_U8]
@@ -153,6 +159,14 @@ class BatchedDemandResponseEnv:
         for name, (o, nbytes, dtype, shape) in offsets.items():
             self.t[name] = self._slab[o:o + nbytes].view(dtype).view(*shape)
         self.t["tot_sum"], self.t["tot_max"] = self.t["tot"][0:2], self.t["tot"][2]
+
+    def _grow_partials(self, records: int) -> None:
+        """Raise the record stride of `partials` to the group's maximum (a fresh zero-filled scratch buffer, re-bound)."""
+        if records <= self._partial_records:
+            return
+        self._partial_records = int(records)
+        self.t["partials"] = torch.zeros((self.nb_envs, self._partial_records, 3), dtype=torch.float64, device=self.device)
+        self._bind()
 
     def _bind(self):
         b = nat.MdrBuffers()
@@ -226,6 +240,7 @@ class BatchedDemandResponseEnv:
 
     def _begin_episode(self):
         if self.sharded:  # ClusterHouses.max_power spans the whole env (env 798-802, 125)
+            self._exchange().agree_partial_records(self)
             self._exchange().sum_max_power(self)
         self._begin_episode_local()
         self._interp_exchange()
@@ -348,23 +363,26 @@ class BatchedDemandResponseEnv:
                 nat.check(self._lib, self._handle, rc, "mdr_env_step")
             return
         self._step_begin(ptr, source)
-        # ONE collective per step: all-gather every rank's [3][E] block (cluster power, penalty sum, penalty max);
-        # mdr_env_step_end_gathered reduces the blocks while it writes the rewards (payload 24 B per env and rank:
-        # the exchange is latency-bound, so the number of collectives is what counts)
-        gathered, world = self._exchange().gather_totals(self)
-        self._step_end(gathered, world)
+        # TWO launches around ONE collective: step_begin leaves one (power sum, penalty sum, penalty max) record per 1024-house
+        # workgroup, the ranks all-gather their record blocks, and every workgroup of step_end re-sums its env's records in one
+        # fixed order while it writes the rewards (payload 24 B per 1024 houses and env: latency-bound, so the number of
+        # collectives and launches is what counts)
+        records, world = self._exchange().gather_partials(self)
+        self._step_end(records, world)
         self._interp_exchange()       # every ceil(interp_update_period / time_step) steps: one more SUM all-reduce of [E]
 
     def _step_begin(self, ptr, source):
         with torch.cuda.device(self.device):
-            rc = self._lib.mdr_env_step_begin(self._handle, C.c_void_p(ptr), source, self._stream())
-            nat.check(self._lib, self._handle, rc, "mdr_env_step_begin")
+            rc = self._lib.mdr_env_step_begin_records(self._handle, C.c_void_p(ptr), source, self._partial_records, self._stream())
+            nat.check(self._lib, self._handle, rc, "mdr_env_step_begin_records")
 
-    def _step_end(self, gathered: torch.Tensor, world: int):
-        """`gathered`: float64 [world][3][E] on this device - every shard's `t['tot']` block."""
+    def _step_end(self, records: torch.Tensor, world: int):
+        """`records`: float64 [world][E][partial_records][3] on this device - every shard's `t['partials']`."""
+        if tuple(records.shape) != (world, self.nb_envs, self._partial_records, 3) or not records.is_contiguous():
+            raise ValueError("records must be a contiguous [world, E, %d, 3] tensor" % self._partial_records)
         with torch.cuda.device(self.device):
-            rc = self._lib.mdr_env_step_end_gathered(self._handle, C.c_void_p(gathered.data_ptr()), int(world), self._stream())
-            nat.check(self._lib, self._handle, rc, "mdr_env_step_end_gathered")
+            rc = self._lib.mdr_env_step_end_records(self._handle, C.c_void_p(records.data_ptr()), int(world), self._stream())
+            nat.check(self._lib, self._handle, rc, "mdr_env_step_end_records")
 
     def step(self, actions: torch.Tensor):
         """MADemandResponseEnv.step (env 174-210).  Returns (obs [7,E,N], reward [E,N], done [E,N], info)."""
@@ -709,7 +727,7 @@ class BatchedDemandResponseEnv:
                                          seed=self.seed, test=self.test, table_steps=self.table_steps,
                                          env_offset=self.env_offset,
                                          house_shard=(self.house_offset, self.nb_houses) if self.sharded else None,
-                                         exchange_always=self._exchange_always,
+                                         exchange_always=self._exchange_always, partial_records=self._partial_records,
                                          process_group=self.process_group, stagger_bytes=self._stagger, graph_mode=self.graph_mode,
                                          interp_grid=getattr(self, "_interp_grid_host", None))
         if getattr(self, "_links_forced", False):

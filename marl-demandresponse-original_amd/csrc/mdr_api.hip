@@ -27,6 +27,7 @@ struct mdr_env {
   mdr::StepPlan plan;
   mdr::StepPlan rollout_plan;
   int64_t nblk = 1;
+  int64_t records_stride = 0;   // > 0 between mdr_env_step_begin_records and mdr_env_step_end_records: record stride of `partials`
   mdr_interp_grid_t interp{};   // base_power_mode == 1
   bool has_interp = false;
   int64_t interp_steps = 0;     // U: env steps between two interpolatePower calls = ceil(update_period / time_step)
@@ -396,6 +397,7 @@ int mdr_env_reset(mdr_env_t* env, uint64_t seed, uint32_t episode, void* stream)
   env->episode = episode;
   env->has_tables = false;
   env->split_pending = false;
+  env->records_stride = 0;
   env->interp_due = false;
   env->od_ext = nullptr;      // a recorded outdoor-temperature sequence belongs to the episode it was loaded with
   env->od_ext_rows = 0;
@@ -417,6 +419,7 @@ int mdr_env_load_episode(mdr_env_t* env, const mdr_episode_t* ep, uint64_t seed,
   env->episode = episode_index;
   env->has_tables = false;
   env->split_pending = false;
+  env->records_stride = 0;
   env->interp_due = false;
   hipError_t e = mdr::launch_load(episode_args(*env), *ep, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "load_episode");
@@ -627,20 +630,43 @@ int mdr_env_step_begin(mdr_env_t* env, uint8_t* actions, int action_source, void
   mdr::StepArgs a;
   int rc = step_args(env, actions, action_source, (hipStream_t)stream, &a);
   if (rc != MDR_OK) return rc;
-  hipError_t e = mdr::launch_step_begin_split(a, (hipStream_t)stream);
+  hipError_t e = mdr::launch_step_begin_split(a, true, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "step_begin");
   env->split_pending = true;
   return MDR_OK;
 }
 
-static int step_end_impl(mdr_env_t* env, const double* gathered, int32_t world, void* stream) {
+int mdr_env_step_begin_records(mdr_env_t* env, uint8_t* actions, int action_source, int32_t records_per_env, void* stream) {
+  if (!env) return MDR_ERR_INVALID;
+  if (env->split_pending) return fail(env, MDR_ERR_INVALID, "step_begin called twice");
+  if (env->interp_due)
+    return fail(env, MDR_ERR_INVALID, "base power update pending: mdr_env_interp_local, SUM all-reduce of base_power, mdr_env_interp_apply");
+  if (env->bound && !env->buf.partials) return fail(env, MDR_ERR_UNBOUND, "buffer 'partials' is NULL");
+  if (records_per_env < env->nblk) return fail(env, MDR_ERR_INVALID, "records_per_env smaller than mdr_partials_per_env(nb_houses)");
+  mdr::StepArgs a;
+  int rc = step_args(env, actions, action_source, (hipStream_t)stream, &a);
+  if (rc != MDR_OK) return rc;
+  a.nblk = records_per_env;
+  hipError_t e = mdr::launch_step_begin_split(a, false, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(env, e, "step_begin_records");
+  env->split_pending = true;
+  env->records_stride = records_per_env;
+  return MDR_OK;
+}
+
+static int step_end_impl(mdr_env_t* env, const double* gathered, const double* records, int32_t world, void* stream) {
   if (!env) return MDR_ERR_INVALID;
   if (!env->split_pending) return fail(env, MDR_ERR_INVALID, "step_end without step_begin");
-  if (gathered && world < 1) return fail(env, MDR_ERR_INVALID, "world must be >= 1");
+  if ((gathered || records) && world < 1) return fail(env, MDR_ERR_INVALID, "world must be >= 1");
+  if ((records != nullptr) != (env->records_stride > 0))
+    return fail(env, MDR_ERR_INVALID, "mdr_env_step_begin pairs with mdr_env_step_end / _gathered, mdr_env_step_begin_records with mdr_env_step_end_records");
   mdr::StepArgs a;
   int rc = step_args(env, nullptr, MDR_ACTIONS_BANGBANG, (hipStream_t)stream, &a);  // actions unused here
   if (rc != MDR_OK) return rc;
   a.gathered = gathered;
+  a.records = records;
+  if (records) a.nblk = (int)env->records_stride;
+  env->records_stride = 0;
   a.world = world;
   hipError_t e = mdr::launch_step_end_split(a, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "step_end");
@@ -802,11 +828,21 @@ int mdr_env_comm_draws(mdr_env_t* env, const mdr_obs_spec_t* spec, int32_t* send
   return MDR_OK;
 }
 
-int mdr_env_step_end(mdr_env_t* env, void* stream) { return step_end_impl(env, nullptr, 0, stream); }
+int mdr_env_step_end(mdr_env_t* env, void* stream) { return step_end_impl(env, nullptr, nullptr, 0, stream); }
 
 int mdr_env_step_end_gathered(mdr_env_t* env, const double* gathered, int32_t world, void* stream) {
   if (!gathered) return env ? fail(env, MDR_ERR_INVALID, "gathered is NULL") : MDR_ERR_INVALID;
-  return step_end_impl(env, gathered, world, stream);
+  return step_end_impl(env, gathered, nullptr, world, stream);
+}
+
+int mdr_env_step_end_records(mdr_env_t* env, const double* records, int32_t world, void* stream) {
+  if (!env) return MDR_ERR_INVALID;
+  if (!records) {          // this device's own records: a world of one
+    records = env->bound ? env->buf.partials : nullptr;
+    world = 1;
+  }
+  if (!records) return fail(env, MDR_ERR_UNBOUND, "buffer 'partials' is NULL");
+  return step_end_impl(env, nullptr, records, world, stream);
 }
 
 int mdr_env_cursor(const mdr_env_t* env, int64_t* k, int64_t* j0) {
@@ -828,6 +864,7 @@ int mdr_env_set_cursor(mdr_env_t* env, uint64_t seed, uint32_t episode, int64_t 
   env->has_episode = true;
   env->has_tables = true;
   env->split_pending = false;
+  env->records_stride = 0;
   env->interp_due = false;
   return MDR_OK;
 }

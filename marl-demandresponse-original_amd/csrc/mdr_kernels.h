@@ -83,6 +83,7 @@ struct StepArgs {
   float* obs;
   double *P, *tot_sum, *tot_max, *partials;
   const double* gathered;              // [world][3][E] all-gathered local aggregates (sharded houses), or nullptr
+  const double* records;               // [world][E][nblk][3] per-workgroup partial records for the finish kernel to re-sum, or nullptr
   int world;
   const float *od_old, *solar_new;     // table rows for this step: OD temp at time index k-1, solar at k
   const double *sig_old, *sig_new;     // regulation signal at k-1 (reward) and k (observation)
@@ -176,7 +177,7 @@ hipError_t launch_obs_vector_ext(const ObsArgs& a, int layout, hipStream_t s);  
 hipError_t launch_comm_draws(const ObsArgs& a, int32_t* senders, uint8_t* keep, hipStream_t s);   // per-slot sender ids + keep flags
 int obs_message_fields(const mdr_obs_spec_t& s);
 int obs_vector_length(const mdr_obs_spec_t& spec);
-hipError_t launch_step_begin_split(const StepArgs& a, hipStream_t s);
+hipError_t launch_step_begin_split(const StepArgs& a, bool reduce, hipStream_t s);
 hipError_t launch_step_end_split(const StepArgs& a, hipStream_t s);
 
 }  // namespace mdr

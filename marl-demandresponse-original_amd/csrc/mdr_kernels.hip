@@ -1084,15 +1084,36 @@ __global__ __launch_bounds__(256) void k_reduce_partials(StepArgs a) {
   }
 }
 
-// rewards and the two power columns from the (possibly all-reduced) totals; re-derives the penalty
+// rewards and the two power columns from the env's totals; re-derives the penalty.  Where the totals come from:
+//   records != nullptr  the per-workgroup partial records themselves, [world][E][nblk][3] (world = 1: this device's own
+//                       `partials`; world > 1: every rank's records, all-gathered): EVERY finish workgroup re-sums its env's
+//                       world * nblk records from L2 in one fixed order (thread t: ranks in order, records t, t + 256, ... ;
+//                       then the workgroup tree) - identical totals in every workgroup, no reduction launch in between;
+//   gathered != nullptr [world][3][E] per-rank totals (mdr_env_step_end_gathered): summed in rank order;
+//   else                tot_sum / tot_max as the caller left them (mdr_env_step_end).
 template <int VEC>
 __global__ __launch_bounds__(256) void k_step_finish(StepArgs a) {
   rebase(a);
+  __shared__ double lds[3 * 4];
   const int e = blockIdx.y;
   const int h = ((int)blockIdx.x * 256 + (int)threadIdx.x) * VEC;
   double P, sum_pen;
   float max_pen;
-  if (a.gathered != nullptr) {   // [world][3][E] local aggregates of every rank: reduce here, in rank order
+  if (a.records != nullptr) {
+    Red3 acc{0.0, 0.0, 0.0f};
+    for (int r = 0; r < a.world; ++r) {
+      const double* rec = a.records + ((int64_t)r * a.E + e) * a.nblk * 3;
+      for (int b = threadIdx.x; b < a.nblk; b += 256) {
+        acc.sum_p += rec[3 * b];
+        acc.sum_pen += rec[3 * b + 1];
+        acc.max_pen = fmaxf(acc.max_pen, (float)rec[3 * b + 2]);
+      }
+    }
+    const Red3 tot = block_reduce<256>(acc, lds);
+    P = tot.sum_p;
+    sum_pen = tot.sum_pen;
+    max_pen = tot.max_pen;
+  } else if (a.gathered != nullptr) {   // [world][3][E] local aggregates of every rank: reduce here, in rank order
     P = 0.0;
     sum_pen = 0.0;
     max_pen = 0.0f;
@@ -2124,18 +2145,20 @@ int64_t split_blocks(int N) {
   return ((int64_t)N + 256 * vec - 1) / (256 * vec);
 }
 
-hipError_t launch_step_begin_split(const StepArgs& a, hipStream_t s) {
-  const dim3 g((unsigned)a.nblk, (unsigned)a.E), b(256);
+// `reduce`: also sum the records into tot_sum / tot_max (mdr_env_step_begin's contract); the two-launch forms leave that to
+// the finish kernel.  a.nblk is the record stride of `partials`; the grid covers the split_blocks(N) workgroups that exist.
+hipError_t launch_step_begin_split(const StepArgs& a, bool reduce, hipStream_t s) {
+  const dim3 g((unsigned)split_blocks(a.N), (unsigned)a.E), b(256);
   if (a.N % 4 == 0)
     hipLaunchKernelGGL(k_step_partial<4>, g, b, 0, s, a);
   else
     hipLaunchKernelGGL(k_step_partial<1>, g, b, 0, s, a);
-  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)a.E), b, 0, s, a);
+  if (reduce) hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)a.E), b, 0, s, a);
   return hipGetLastError();
 }
 
 hipError_t launch_step_end_split(const StepArgs& a, hipStream_t s) {
-  const dim3 g((unsigned)a.nblk, (unsigned)a.E), b(256);
+  const dim3 g((unsigned)split_blocks(a.N), (unsigned)a.E), b(256);
   if (a.N % 4 == 0)
     hipLaunchKernelGGL(k_step_finish<4>, g, b, 0, s, a);
   else
@@ -2225,9 +2248,13 @@ hipError_t launch_step(const StepArgs& a, const StepPlan& p, hipStream_t s) {
 #undef MDR_GROUP
     return hipGetLastError();
   }
-  hipError_t err = launch_step_begin_split(a, s);
+  // split path on one device: partial records, then the finish kernel re-sums them itself (two launches)
+  hipError_t err = launch_step_begin_split(a, false, s);
   if (err != hipSuccess) return err;
-  return launch_step_end_split(a, s);
+  StepArgs f = a;
+  f.records = a.partials;
+  f.world = 1;
+  return launch_step_end_split(f, s);
 }
 
 }  // namespace mdr

@@ -116,12 +116,36 @@ def np_contig(a):
 
 
 class TorchDistExchange:
-    """The two exchanges of the sharded-houses layout over torch.distributed (RCCL on the GPU box, gloo in CPU tests):
-    one SUM all-reduce of `max_power` per episode and ONE all-gather of the [3][E] aggregate block per step."""
+    """The exchanges of the sharded-houses layout over torch.distributed (RCCL on the GPU box, gloo in CPU tests):
+    one SUM all-reduce of `max_power` per episode and ONE all-gather of the per-workgroup partial records per step."""
 
     def __init__(self, process_group=None):
         self.process_group = process_group
         self._gathered = None
+        self._records = None
+
+    def agree_partial_records(self, env) -> None:
+        """Every rank all-gathers equal blocks: raise the record stride of `partials` to the largest shard's (once per env)."""
+        import torch
+        import torch.distributed as dist
+        if getattr(env, "_records_agreed", False):
+            return
+        m = torch.tensor([env._partial_records], dtype=torch.int64, device=env.device)
+        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.process_group)
+        env._grow_partials(int(m.item()))
+        env._records_agreed = True
+
+    def gather_partials(self, env):
+        """every rank's `partials` [E][R][3] -> [world][E][R][3] on every rank (R = the agreed record stride)"""
+        import torch
+        import torch.distributed as dist
+        world = dist.get_world_size(self.process_group)
+        part = env.t["partials"]
+        shape = (world,) + tuple(part.shape)
+        if self._records is None or tuple(self._records.shape) != shape:
+            self._records = torch.empty(shape, dtype=torch.float64, device=env.device)
+        dist.all_gather_into_tensor(self._records.view(world * part.shape[0], part.shape[1], 3), part, group=self.process_group)
+        return self._records, world
 
     def sum_max_power(self, env) -> None:
         import torch.distributed as dist
@@ -164,19 +188,22 @@ class TorchDistExchange:
 class LocalShardGroup:
     """All house shards of the same envs driven from ONE process: `nb_shards` BatchedDemandResponseEnv objects, spread
     round-robin over `devices` (a single device rehearses BASELINE config 5's eight 125,000-house shards on one GPU).
-    The per-step exchange is a stack of the shards' [3][E] blocks copied to each shard's device - the peer-copy
+    The per-step exchange is a stack of the shards' partial-record blocks copied to each shard's device - the peer-copy
     alternative to the RCCL all-gather that one-process-per-GPU runs use - and every shard's
     kernels are issued before the exchange so that the shards overlap.  Results are identical to the
-    torch.distributed path: both feed mdr_env_step_end_gathered the same [world][3][E] tensor."""
+    torch.distributed path: both feed mdr_env_step_end_records the same [world][E][records][3] tensor."""
 
     def __init__(self, config: dict, nb_envs: int, nb_shards: int, devices: Sequence = ("cuda:0",), seed: int = 0, **kw):
         from .batched_env import BatchedDemandResponseEnv
         total = int(config["default_env_prop"]["cluster_prop"]["nb_agents"])
         self.nb_shards, self.nb_envs, self.nb_agents = int(nb_shards), int(nb_envs), total
         self.shards: List = []
+        from . import _native as nat
+        ranges = [house_shard(total, self.nb_shards, r) for r in range(self.nb_shards)]
+        records = max(int(nat.load().mdr_partials_per_env(c)) for _, c in ranges)      # equal blocks: the largest shard's count
         for r in range(self.nb_shards):
             env = BatchedDemandResponseEnv(config, nb_envs=nb_envs, device=devices[r % len(devices)], seed=seed,
-                                           house_shard=house_shard(total, self.nb_shards, r), **kw)
+                                           house_shard=ranges[r], partial_records=records, **kw)
             env._exchange_impl = self            # a lone shard.step() would wait for peers that never come: refuse it
             self.shards.append(env)
 
@@ -184,7 +211,10 @@ class LocalShardGroup:
     def sum_max_power(self, env):
         raise RuntimeError("shards of a LocalShardGroup are stepped through the group, not one by one")
 
-    gather_totals = sum_base_power = sum_max_power
+    gather_totals = gather_partials = sum_base_power = sum_max_power
+
+    def agree_partial_records(self, env):
+        pass                                             # the constructor gave every shard the largest shard's count
 
     def _interp_exchange(self):
         due = [env._interp_due() for env in self.shards]
@@ -222,7 +252,7 @@ class LocalShardGroup:
         import torch
         first = self.shards[0]
         self._sync_devices()
-        block = torch.stack([env.t["tot"].to(first.device) for env in self.shards])     # [world][3][E]
+        block = torch.stack([env.t["partials"].to(first.device) for env in self.shards])     # [world][E][records][3]
         for env in self.shards:
             env._gathered_local = block if env.device == first.device else block.to(env.device)
             env._step_end(env._gathered_local, self.nb_shards)

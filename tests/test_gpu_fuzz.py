@@ -212,26 +212,45 @@ def _interp_case(idx):
 @pytest.mark.parametrize("idx", range(50 * SCALE))
 def test_fuzz_interpolation_mode_vs_oracle(idx):
     """Random base-power grids (axis lengths, values, queries outside the axes), update periods ceil(300 / dt) from 1 to 75
-    steps, N below / at / above the 100-house sampling limit."""
+    steps, N below / at / above the 100-house sampling limit.
+    The random grids are steep (thousands of W per axis step), so the fp32 temperatures of the device's query move the result
+    visibly (case 894 of a 40x campaign: 1.4e-5 relative).  tests/interp_util.py splits that from the lookup itself: against the
+    oracle fed the device's own query the base power, the signal (1e-9) and the rewards (1e-5) hold the tight bar; against the
+    pure fp64 oracle the difference stays inside the slope bound of the grid."""
     import mdr_amd
     from oracle import mdr_oracle as mo
+    from tests.interp_util import DeviceFedOracle, base_power_bound
     cfg, E, N, seed, values, axes = _interp_case(idx)
     env = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=seed, interp_grid=(values, axes))
     env.reset(episode=3)
+    grid = mo.InterpGrid(values, axes)
     ora = mo.OracleEnv(cfg, nb_envs=E)
-    ora.interp_grid = mo.InterpGrid(values, axes)
+    fed = DeviceFedOracle(cfg, nb_envs=E)
+    fed.device_env = env
+    ora.interp_grid = fed.interp_grid = grid
     ora.reset(seed=seed, episode=3)
-    np.testing.assert_allclose(env.t["base_power"].cpu().numpy(), ora.base_power, rtol=1e-5, atol=1e-3)
+    fed.reset(seed=seed, episode=3)
+
+    def check_power(t):
+        dev = env.t["base_power"].cpu().numpy()
+        np.testing.assert_allclose(dev, fed.base_power, rtol=1e-9, atol=1e-6, err_msg="case %d step %d (device-fed oracle)" % (idx, t))
+        np.testing.assert_allclose(env.reg_signal().cpu().numpy(), fed.S, rtol=1e-9, atol=1e-6)
+        # the bound is evaluated on the current state differences; the base power in force was computed at the last update, when
+        # they were no larger than the largest seen so far
+        check_power.bound = max(check_power.bound, base_power_bound(grid, env, ora, N))
+        assert np.all(np.abs(dev - ora.base_power) <= check_power.bound * (1 + 1e-9) + 1e-6), \
+            "case %d step %d: |d base_power| %.3e above the slope bound %.3e" % (idx, t, float(np.max(np.abs(dev - ora.base_power))), check_power.bound)
+
+    check_power.bound = 0.0
+    check_power(-1)
     rng = np.random.default_rng(idx)
     for t in range(80):
         act = (rng.random((E, N)) < 0.5).astype(np.uint8)
         _, reward, _, _ = env.step(torch.from_numpy(act).cuda())
-        r_ref = ora.step(act)
+        ora.step(act)
+        r_fed = fed.step(act)
         np.testing.assert_array_equal(env.t["P"].cpu().numpy(), ora.P, err_msg="case %d step %d" % (idx, t))
-        # the random grids are steep (thousands of W per axis step) and the query is built from fp32 temperatures: a 2e-5 degC
-        # difference after 60 steps moves the interpolated power by 1e-5 of its value (seen once in an 11,000-case campaign)
-        np.testing.assert_allclose(env.t["base_power"].cpu().numpy(), ora.base_power, rtol=5e-5, atol=1e-3, err_msg="case %d step %d" % (idx, t))
-        np.testing.assert_allclose(env.reg_signal().cpu().numpy(), ora.S, rtol=5e-5, atol=1e-3)
-        np.testing.assert_allclose(reward.cpu().numpy(), r_ref, rtol=3e-5, atol=3e-5)
+        check_power(t)
+        np.testing.assert_allclose(reward.cpu().numpy(), r_fed, rtol=1e-5, atol=1e-5, err_msg="case %d step %d" % (idx, t))
     # big_noise start temperatures reach 0 degC, where a bound relative to the Celsius value is ill-posed: 1e-5 degC floor
     np.testing.assert_allclose(env.house_temp().cpu().numpy(), ora.Ta, rtol=1e-5, atol=1e-5)

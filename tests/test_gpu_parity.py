@@ -325,23 +325,37 @@ def test_interpolated_base_power_matches_oracle(E, N):
     cfg = _cfg(N, **{"noise_house_prop.noise_mode": "small_noise", "noise_hvac_prop.noise_mode": "big_noise",
                      "default_env_prop.power_grid_prop.base_power_mode": "interpolation",
                      "default_env_prop.power_grid_prop.signal_mode": "sinusoidals"})
+    from tests.interp_util import DeviceFedOracle, base_power_bound
     mdr = _mdr()
     env = mdr.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=77, interp_grid=(values, axes))
     env.reset(episode=2)
+    grid = mo.InterpGrid(values, axes)
     ora = mo.OracleEnv(cfg, nb_envs=E)
-    ora.interp_grid = mo.InterpGrid(values, axes)
+    fed = DeviceFedOracle(cfg, nb_envs=E)       # the oracle with the device's fp32 state as interpolatePower's query
+    fed.device_env = env
+    ora.interp_grid = fed.interp_grid = grid
     ora.reset(seed=77, episode=2)
+    fed.reset(seed=77, episode=2)
+    np.testing.assert_allclose(env.t["base_power"].cpu().numpy(), fed.base_power, rtol=1e-9)
     np.testing.assert_allclose(env.t["base_power"].cpu().numpy(), ora.base_power, rtol=3e-6)
     rng = np.random.default_rng(1)
+    bound = 0.0
     for t in range(160):
         act = (rng.random((E, N)) < 0.5).astype(np.uint8)
         obs, reward, _, _ = env.step(torch.from_numpy(act).cuda())
-        r_ref = ora.step(act)
+        ora.step(act)
+        r_fed = fed.step(act)
         if t % 75 in (73, 74, 0, 1):
-            np.testing.assert_allclose(env.t["base_power"].cpu().numpy(), ora.base_power, rtol=3e-6)
-            np.testing.assert_allclose(env.reg_signal().cpu().numpy(), ora.S, rtol=3e-6)
-            np.testing.assert_allclose(obs[5].cpu().numpy(), np.broadcast_to((ora.S / (7500.0 * N))[:, None], (E, N)), rtol=3e-6)
-            np.testing.assert_allclose(reward.cpu().numpy(), r_ref, rtol=2e-5, atol=2e-5)
+            dev = env.t["base_power"].cpu().numpy()
+            # same query, both lookups in fp64: rounding only; rewards then hold north_star's 1e-5
+            np.testing.assert_allclose(dev, fed.base_power, rtol=1e-9)
+            np.testing.assert_allclose(env.reg_signal().cpu().numpy(), fed.S, rtol=1e-9)
+            np.testing.assert_allclose(obs[5].cpu().numpy(), np.broadcast_to((fed.S / (7500.0 * N))[:, None], (E, N)), rtol=1e-6)
+            np.testing.assert_allclose(reward.cpu().numpy(), r_fed, rtol=R_RTOL, atol=R_ATOL)
+            # pure fp64 oracle: inside what the fp32 temperatures can move the lookup (steepest grid edge x state difference)
+            bound = max(bound, base_power_bound(grid, env, ora, N))
+            assert np.all(np.abs(dev - ora.base_power) <= bound * (1 + 1e-9) + 1e-6)
+            np.testing.assert_allclose(dev, ora.base_power, rtol=3e-6)
             np.testing.assert_array_equal(env.t["P"].cpu().numpy(), ora.P)
     assert len(np.unique(env.t["base_power"].cpu().numpy())) == E
 

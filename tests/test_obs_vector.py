@@ -63,7 +63,8 @@ def test_hip_obs_vector_matches_reference(name):
             rows = env.obs_vector("rows")
             assert planes.shape == (F, 1, g.N) and rows.shape == (1, g.N, F)
             torch.testing.assert_close(planes[:, 0, :].t().contiguous(), rows[0], rtol=1e-6, atol=1e-7)
-            want = g.a["norm_state"][k] if ora is None else ora.norm_state(g.config)[0]
+            static = g.a["links"].astype(np.int64) if "links" in g.a else None      # the episode's table (None: circular / random_sample)
+            want = g.a["norm_state"][k] if ora is None else ora.norm_state(g.config, static)[0]
             np.testing.assert_allclose(rows[0].cpu().numpy(), want, rtol=2e-5, atol=2e-6)
             if ora is not None:       # and the columns that do not depend on the draws still match the reference itself
                 np.testing.assert_allclose(rows[0, :, :11].cpu().numpy(), g.a["norm_state"][k][:, :11], rtol=2e-5, atol=2e-6)
