@@ -202,8 +202,10 @@ const char *mdr_status_string(int status);
 /* Last error text of a handle ("" if none); valid until the next call on that handle. */
 const char *mdr_last_error(const mdr_env_t *env);
 
-/* Number of per-env partial records the split path needs for (nb_houses): size `partials` with it. */
+/* Upper bound of the per-env partial records the split path writes for (nb_houses), whatever nb_envs: size `partials` with it.
+ * mdr_env_partial_records: the count THIS env writes (one per workgroup of 1024 houses) - what a sharded run all-gathers. */
 int64_t mdr_partials_per_env(int32_t nb_houses);
+int64_t mdr_env_partial_records(const mdr_env_t *env);
 
 /* MADemandResponseEnv.__init__ (env 73-96) minus build_environment: validates and stores the config. */
 int mdr_env_create(const mdr_config_t *config, mdr_env_t **out);
@@ -282,8 +284,8 @@ int mdr_env_step_end(mdr_env_t *env, void *stream);
 int mdr_env_step_end_gathered(mdr_env_t *env, const double *gathered, int32_t world, void *stream);
 
 /* The same split with one launch less: step_begin_records stops at the per-workgroup partial records - `partials`
- * [E][records_per_env][3] (power sum, penalty sum, penalty max per 1024-house workgroup; records_per_env >=
- * mdr_partials_per_env(nb_houses), the tail stays as the caller left it: zero) - the caller ALL-GATHERS the ranks' `partials`
+ * [E][records_per_env][3] (power sum, penalty sum, penalty max per workgroup; records_per_env >=
+ * mdr_env_partial_records(env), the tail stays as the caller left it: zero) - the caller ALL-GATHERS the ranks' `partials`
  * into `records` [world][E][records_per_env][3] (equal records_per_env on every rank: the largest shard's), and every workgroup
  * of step_end_records re-sums its env's world * records_per_env records from L2 in one fixed order while it writes the rewards.
  * Two launches around ONE collective; payload 24 B per 1024 houses instead of 24 B per rank - still latency-bound.

@@ -120,7 +120,7 @@ class MdrRolloutOut(C.Structure):
 OBS_PLANES, OBS_ROWS = 0, 1
 
 EXPORTS = (
-    "mdr_abi_version", "mdr_status_string", "mdr_last_error", "mdr_partials_per_env",
+    "mdr_abi_version", "mdr_status_string", "mdr_last_error", "mdr_partials_per_env", "mdr_env_partial_records",
     "mdr_env_create", "mdr_env_destroy", "mdr_env_bind", "mdr_env_reset", "mdr_env_load_episode",
     "mdr_env_set_od_table", "mdr_env_set_interp_grid", "mdr_env_begin_episode", "mdr_env_step", "mdr_env_rollout", "mdr_env_rollout_fused",
     "mdr_env_step_begin", "mdr_env_step_end", "mdr_env_step_end_gathered", "mdr_env_step_begin_records", "mdr_env_step_end_records",
@@ -154,6 +154,7 @@ def load():
         "mdr_status_string": (C.c_char_p, [C.c_int]),
         "mdr_last_error": (C.c_char_p, [vp]),
         "mdr_partials_per_env": (i64, [i32]),
+        "mdr_env_partial_records": (i64, [vp]),
         "mdr_env_create": (C.c_int, [C.POINTER(MdrConfig), C.POINTER(vp)]),
         "mdr_env_destroy": (C.c_int, [vp]),
         "mdr_env_bind": (C.c_int, [vp, C.POINTER(MdrBuffers)]),

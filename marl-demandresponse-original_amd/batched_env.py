@@ -127,7 +127,7 @@ class BatchedDemandResponseEnv:
 
     def _layout(self):
         E, N, K1 = self.nb_envs, self.nb_houses, self.table_steps + 1
-        nblk = int(self._lib.mdr_partials_per_env(N))
+        nblk = int(self._lib.mdr_env_partial_records(self._handle))      # one record per workgroup of the split path
         if self._partial_records is not None and self._partial_records < nblk:
             raise ValueError("partial_records smaller than the %d workgroups this shard needs" % nblk)
         nblk = self._partial_records = max(nblk, self._partial_records or 0)

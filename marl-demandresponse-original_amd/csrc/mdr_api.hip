@@ -351,7 +351,12 @@ const char* mdr_status_string(int status) {
 
 const char* mdr_last_error(const mdr_env_t* env) { return env ? env->err.c_str() : ""; }
 
-int64_t mdr_partials_per_env(int32_t nb_houses) { return nb_houses < 1 ? 0 : mdr::split_blocks(nb_houses); }
+// upper bound over every batch size (the 64-thread form): what `partials` must be able to hold
+int64_t mdr_partials_per_env(int32_t nb_houses) {
+  return nb_houses < 1 ? 0 : mdr::split_blocks(nb_houses, nb_houses % 4 == 0 ? 64 : 256);
+}
+
+int64_t mdr_env_partial_records(const mdr_env_t* env) { return env ? env->nblk : 0; }
 
 int mdr_env_create(const mdr_config_t* config, mdr_env_t** out) {
   if (!config || !out) return MDR_ERR_INVALID;
@@ -369,7 +374,7 @@ int mdr_env_create(const mdr_config_t* config, mdr_env_t** out) {
     return MDR_ERR_UNSUPPORTED;
   }
   env->rollout_plan = mdr::plan_rollout(config->nb_houses, config->nb_envs);
-  env->nblk = mdr::split_blocks(config->nb_houses);
+  env->nblk = mdr::split_blocks(config->nb_houses, mdr::split_threads(config->nb_houses, config->nb_envs));
   return MDR_OK;
 }
 
@@ -642,7 +647,7 @@ int mdr_env_step_begin_records(mdr_env_t* env, uint8_t* actions, int action_sour
   if (env->interp_due)
     return fail(env, MDR_ERR_INVALID, "base power update pending: mdr_env_interp_local, SUM all-reduce of base_power, mdr_env_interp_apply");
   if (env->bound && !env->buf.partials) return fail(env, MDR_ERR_UNBOUND, "buffer 'partials' is NULL");
-  if (records_per_env < env->nblk) return fail(env, MDR_ERR_INVALID, "records_per_env smaller than mdr_partials_per_env(nb_houses)");
+  if (records_per_env < env->nblk) return fail(env, MDR_ERR_INVALID, "records_per_env smaller than mdr_env_partial_records()");
   mdr::StepArgs a;
   int rc = step_args(env, actions, action_source, (hipStream_t)stream, &a);
   if (rc != MDR_OK) return rc;

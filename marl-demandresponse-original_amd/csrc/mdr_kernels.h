@@ -154,7 +154,8 @@ struct StepPlan {
 
 StepPlan plan_step(int N, int64_t E);
 StepPlan plan_rollout(int N, int64_t E);
-int64_t split_blocks(int N);
+int split_threads(int N, int64_t E);          // workgroup size of the split path for this shape
+int64_t split_blocks(int N, int threads);     // workgroups (= partial records) per env
 
 hipError_t launch_sample(const EpisodeArgs& a, hipStream_t s);
 hipError_t launch_load(const EpisodeArgs& a, const mdr_episode_t& ep, hipStream_t s);

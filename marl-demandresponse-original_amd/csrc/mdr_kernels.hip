@@ -1032,13 +1032,15 @@ __global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs r
 }
 
 // ---- (3) split path: any N, several workgroups per env, and the sharded-houses case -------------
-// grid = (nblk, E); workgroup b of env e owns houses [b * 256 * VEC, (b + 1) * 256 * VEC)
-template <int VEC>
-__global__ __launch_bounds__(256) void k_step_partial(StepArgs a) {
+// grid = (split_blocks, E); workgroup b of env e owns houses [b * THREADS * VEC, (b + 1) * THREADS * VEC).  THREADS = 64 when
+// the launch would otherwise have fewer workgroups than CUs to spread over (a 125,000-house shard is 123 workgroups of 1024
+// houses: half the CUs idle and each busy one limited by what a single CU can stream).
+template <int VEC, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_step_partial(StepArgs a) {
   rebase(a);
   __shared__ double lds[3 * 4];
   const int e = blockIdx.y;
-  const int h = ((int)blockIdx.x * 256 + (int)threadIdx.x) * VEC;
+  const int h = ((int)blockIdx.x * THREADS + (int)threadIdx.x) * VEC;
   const int64_t base = (int64_t)e * a.N;
   Red3 acc{0.0, 0.0, 0.0f};
   if (h < a.N) {
@@ -1056,7 +1058,7 @@ __global__ __launch_bounds__(256) void k_step_partial(StepArgs a) {
     acc.sum_pen = (double)ps;
     store_obs_local<VEC>(a, base + h, o, lockout);
   }
-  const Red3 tot = block_reduce<256>(acc, lds);
+  const Red3 tot = block_reduce<THREADS>(acc, lds);
   if (threadIdx.x == 0) {
     double* rec = a.partials + ((int64_t)e * a.nblk + blockIdx.x) * 3;
     rec[0] = tot.sum_p;
@@ -1087,29 +1089,29 @@ __global__ __launch_bounds__(256) void k_reduce_partials(StepArgs a) {
 // rewards and the two power columns from the env's totals; re-derives the penalty.  Where the totals come from:
 //   records != nullptr  the per-workgroup partial records themselves, [world][E][nblk][3] (world = 1: this device's own
 //                       `partials`; world > 1: every rank's records, all-gathered): EVERY finish workgroup re-sums its env's
-//                       world * nblk records from L2 in one fixed order (thread t: ranks in order, records t, t + 256, ... ;
+//                       world * nblk records from L2 in one fixed order (thread t: ranks in order, records t, t + THREADS, ... ;
 //                       then the workgroup tree) - identical totals in every workgroup, no reduction launch in between;
 //   gathered != nullptr [world][3][E] per-rank totals (mdr_env_step_end_gathered): summed in rank order;
 //   else                tot_sum / tot_max as the caller left them (mdr_env_step_end).
-template <int VEC>
-__global__ __launch_bounds__(256) void k_step_finish(StepArgs a) {
+template <int VEC, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_step_finish(StepArgs a) {
   rebase(a);
   __shared__ double lds[3 * 4];
   const int e = blockIdx.y;
-  const int h = ((int)blockIdx.x * 256 + (int)threadIdx.x) * VEC;
+  const int h = ((int)blockIdx.x * THREADS + (int)threadIdx.x) * VEC;
   double P, sum_pen;
   float max_pen;
   if (a.records != nullptr) {
     Red3 acc{0.0, 0.0, 0.0f};
     for (int r = 0; r < a.world; ++r) {
       const double* rec = a.records + ((int64_t)r * a.E + e) * a.nblk * 3;
-      for (int b = threadIdx.x; b < a.nblk; b += 256) {
+      for (int b = threadIdx.x; b < a.nblk; b += THREADS) {
         acc.sum_p += rec[3 * b];
         acc.sum_pen += rec[3 * b + 1];
         acc.max_pen = fmaxf(acc.max_pen, (float)rec[3 * b + 2]);
       }
     }
-    const Red3 tot = block_reduce<256>(acc, lds);
+    const Red3 tot = block_reduce<THREADS>(acc, lds);
     P = tot.sum_p;
     sum_pen = tot.sum_pen;
     max_pen = tot.max_pen;
@@ -2140,29 +2142,46 @@ StepPlan plan_rollout(int N, int64_t E) {
   return p;
 }
 
-int64_t split_blocks(int N) {
+// Workgroup size of the split path: 256 threads (1024 houses with 16-byte accesses; N % 4 != 0: one house per lane).
+// MDR_SPLIT_THREADS=64 selects 256-house workgroups for small launches (experiment knob): measured SLOWER on a 125,000-house
+// shard (10.4 us against 8.7 us for the two launches) - four times the records for every finish workgroup to re-sum buy
+// nothing while both launches sit on the dispatch-latency floor.
+int split_threads(int N, int64_t E) {
+  if (N % 4 != 0) return 256;
+  static const int knob = [] { const char* t = getenv("MDR_SPLIT_THREADS"); return t ? atoi(t) : 0; }();
+  if (knob == 64 && E * (((int64_t)N + 1023) / 1024) < 512) return 64;
+  return 256;
+}
+
+int64_t split_blocks(int N, int threads) {
   const int vec = (N % 4 == 0) ? 4 : 1;
-  return ((int64_t)N + 256 * vec - 1) / (256 * vec);
+  return ((int64_t)N + threads * vec - 1) / (threads * vec);
 }
 
 // `reduce`: also sum the records into tot_sum / tot_max (mdr_env_step_begin's contract); the two-launch forms leave that to
 // the finish kernel.  a.nblk is the record stride of `partials`; the grid covers the split_blocks(N) workgroups that exist.
 hipError_t launch_step_begin_split(const StepArgs& a, bool reduce, hipStream_t s) {
-  const dim3 g((unsigned)split_blocks(a.N), (unsigned)a.E), b(256);
-  if (a.N % 4 == 0)
-    hipLaunchKernelGGL(k_step_partial<4>, g, b, 0, s, a);
+  const int th = split_threads(a.N, a.E);
+  const dim3 g((unsigned)split_blocks(a.N, th), (unsigned)a.E), b(th);
+  if (a.N % 4 != 0)
+    hipLaunchKernelGGL((k_step_partial<1, 256>), g, b, 0, s, a);
+  else if (th == 64)
+    hipLaunchKernelGGL((k_step_partial<4, 64>), g, b, 0, s, a);
   else
-    hipLaunchKernelGGL(k_step_partial<1>, g, b, 0, s, a);
-  if (reduce) hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)a.E), b, 0, s, a);
+    hipLaunchKernelGGL((k_step_partial<4, 256>), g, b, 0, s, a);
+  if (reduce) hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)a.E), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
 hipError_t launch_step_end_split(const StepArgs& a, hipStream_t s) {
-  const dim3 g((unsigned)split_blocks(a.N), (unsigned)a.E), b(256);
-  if (a.N % 4 == 0)
-    hipLaunchKernelGGL(k_step_finish<4>, g, b, 0, s, a);
+  const int th = split_threads(a.N, a.E);
+  const dim3 g((unsigned)split_blocks(a.N, th), (unsigned)a.E), b(th);
+  if (a.N % 4 != 0)
+    hipLaunchKernelGGL((k_step_finish<1, 256>), g, b, 0, s, a);
+  else if (th == 64)
+    hipLaunchKernelGGL((k_step_finish<4, 64>), g, b, 0, s, a);
   else
-    hipLaunchKernelGGL(k_step_finish<1>, g, b, 0, s, a);
+    hipLaunchKernelGGL((k_step_finish<4, 256>), g, b, 0, s, a);
   return hipGetLastError();
 }
 

@@ -198,14 +198,14 @@ class LocalShardGroup:
         total = int(config["default_env_prop"]["cluster_prop"]["nb_agents"])
         self.nb_shards, self.nb_envs, self.nb_agents = int(nb_shards), int(nb_envs), total
         self.shards: List = []
-        from . import _native as nat
-        ranges = [house_shard(total, self.nb_shards, r) for r in range(self.nb_shards)]
-        records = max(int(nat.load().mdr_partials_per_env(c)) for _, c in ranges)      # equal blocks: the largest shard's count
         for r in range(self.nb_shards):
             env = BatchedDemandResponseEnv(config, nb_envs=nb_envs, device=devices[r % len(devices)], seed=seed,
-                                           house_shard=ranges[r], partial_records=records, **kw)
+                                           house_shard=house_shard(total, self.nb_shards, r), **kw)
             env._exchange_impl = self            # a lone shard.step() would wait for peers that never come: refuse it
             self.shards.append(env)
+        records = max(env._partial_records for env in self.shards)      # equal blocks: the largest shard's record count
+        for env in self.shards:
+            env._grow_partials(records)
 
     # the shards must move in lockstep, which only the group can guarantee
     def sum_max_power(self, env):
