@@ -18,6 +18,8 @@
 
 #include <stdint.h>
 
+#include "mdr.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -41,6 +43,11 @@ typedef struct mdr_actor {
   int32_t hidden2;     /* units of hidden layer 2 (<= MDR_ACTOR_MAX_HIDDEN) */
   int32_t greedy;      /* 0: action ~ Categorical(softmax) (PPOAgent.act, agents/rl_controllers.py:28-36); 1: action = argmax of the two
                           outputs (DQNAgent.act, rl_controllers.py:53-60: the same Linear/ReLU stack read as Q-values), no draw */
+  int32_t feature_order; /* which input feature column k of W1 multiplies: 0 = MDR_FEATURES_NORMSTATE, normStateDict's own order
+                            (mdr_actor_sample); 1 = MDR_FEATURES_OBSERVE, the order mdr_env_actor_sample stages the default observation
+                            in - the 10 messages first (k = 4 m + field), then the 11 own features (k = 40 + i): W1's columns
+                            permuted with k -> normStateDict index (k < 40 ? 11 + k : k - 40) */
+  int32_t reserved0;
   /* device, MFMA fragment order.  W1z / W2z / W3z: the weight matrices zero-padded to 128 rows / columns.
    * MDR_ACTOR_FRAG32 (S1 = ceil((F + 1) / 2), S2 = mdr_actor_steps2, r = lane & 31, h = lane >> 5) carries the biases as a
    * constant-1 input feature / hidden unit:  W1e = [[W1 b1] [0 1]],  W2e = [[W2 b2] [0 1]],  W3e = [W3 b3]:
@@ -75,6 +82,17 @@ int64_t mdr_actor_frag2_floats(int32_t layout, int32_t hidden1);    /* size of f
  * the time index of mdr_buffers_t.cursor ([1]) so that a captured launch draws fresh numbers at every replay.  Returns 0, or -1 (invalid argument) / -3 (HIP error) / -4 (shape without a kernel). */
 int mdr_actor_sample(const mdr_actor_t *actor, const float *obs, int64_t obs_plane_stride, int64_t nb_agents, uint64_t seed,
                      uint64_t step, const int32_t *step_dev, uint8_t *action, float *a_prob, float *probs, void *stream);
+
+/* Observe -> act in ONE kernel (SURVEY 8f-1 + 8f-2 fused): what train_ppo.py:69-75 does per agent - utils.normStateDict(obs_dict[i]) then
+ * PPO.select_action - for every agent of every env, WITHOUT materialising the 204-byte observation rows: each wavefront stages the
+ * compact state of its 32 (16) consecutive houses and their 5 + 5 circular neighbours in LDS (own features and SingleHouse.message
+ * records, the very arithmetic of mdr_env_obs_vector), and the matrix-core forward reads its B operand from there.  Draws, outputs and
+ * `step_dev` as mdr_actor_sample (agent index = env * nb_houses + house).  Covers the reference's DEFAULT observation only - every
+ * optional state / message column off, agents_comm_mode "neighbours" with nb_agents_comm = 10, no link defects (spec says which; 51
+ * features) - with nb_houses a multiple of 32, unsharded houses, and an actor packed as MDR_ACTOR_FRAG16 or MDR_ACTOR_BF16X3 in
+ * MDR_FEATURES_OBSERVE order; anything else returns MDR_ERR_UNSUPPORTED (-4): fall back to mdr_env_obs_vector + mdr_actor_sample. */
+int mdr_env_actor_sample(mdr_env_t *env, const mdr_obs_spec_t *spec, const mdr_actor_t *actor, uint64_t seed, uint64_t step,
+                         const int32_t *step_dev, uint8_t *action, float *a_prob, float *probs, void *stream);
 
 /* The Monte-Carlo return scan of PPO.update (agents/ppo.py:123-134) for every agent at once: backwards over t,
  * R <- reward[t] + gamma * (done[t] ? bootstrap[t] : R).  `reward`, `out` float [nb_steps][nb_agents]; `done` uint8 of that

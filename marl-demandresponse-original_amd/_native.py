@@ -128,7 +128,8 @@ EXPORTS = (
     "mdr_obs_message_fields", "mdr_env_obs_messages", "mdr_env_obs_vector_ext", "mdr_env_comm_draws",
     "mdr_env_graph_room", "mdr_env_graph_replayed", "mdr_env_pack", "mdr_env_cursor", "mdr_env_set_cursor",
     # include/mdr_policy.h
-    "mdr_actor_steps1", "mdr_actor_steps2", "mdr_actor_frag1_floats", "mdr_actor_frag2_floats", "mdr_actor_sample", "mdr_discounted_returns",
+    "mdr_actor_steps1", "mdr_actor_steps2", "mdr_actor_frag1_floats", "mdr_actor_frag2_floats", "mdr_actor_sample", "mdr_env_actor_sample",
+    "mdr_discounted_returns",
 )
 
 _lib = None
@@ -187,6 +188,7 @@ def load():
         "mdr_actor_frag1_floats": (i64, [i32, i32]),
         "mdr_actor_frag2_floats": (i64, [i32, i32]),
         "mdr_actor_sample": (C.c_int, [vp, vp, i64, i64, u64, u64, vp, vp, vp, vp, vp]),
+        "mdr_env_actor_sample": (C.c_int, [vp, C.POINTER(MdrObsSpec), vp, u64, u64, vp, vp, vp, vp, vp]),
         "mdr_discounted_returns": (C.c_int, [vp, vp, vp, C.c_float, i32, i64, vp, vp]),
         "mdr_env_pack": (C.c_int, [vp, i32, vp, vp]),
         "mdr_env_graph_room": (i64, [vp]),

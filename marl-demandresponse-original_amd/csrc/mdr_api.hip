@@ -7,6 +7,7 @@
 #include <new>
 #include <string>
 
+#include "../../include/mdr_policy.h"
 #include "mdr_kernels.h"
 
 struct mdr_env {
@@ -819,6 +820,30 @@ int mdr_env_obs_vector_ext(mdr_env_t* env, const mdr_obs_spec_t* spec, const flo
   a.ext_entries = entries_per_env;
   hipError_t e = mdr::launch_obs_vector_ext(a, spec->layout, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "obs_vector_ext");
+  return MDR_OK;
+}
+
+int mdr_env_actor_sample(mdr_env_t* env, const mdr_obs_spec_t* spec, const mdr_actor_t* actor, uint64_t seed, uint64_t step,
+                         const int32_t* step_dev, uint8_t* action, float* a_prob, float* probs, void* stream) {
+  if (!env || !spec || !actor || !action) return MDR_ERR_INVALID;
+  if (env->cfg.nb_houses_total != env->cfg.nb_houses) return fail(env, MDR_ERR_UNSUPPORTED, "observe -> act needs unsharded houses");
+  mdr::ObsArgs a;
+  int rc = obs_args(env, spec, false, &a);
+  if (rc == MDR_OK) rc = sync_cursor(env, (hipStream_t)stream);
+  if (rc != MDR_OK) return rc;
+  // the reference's default observation only (utils.py:774-878 with every optional column off, 10 circular neighbours, no defects)
+  if (spec->state_hour || spec->state_day || spec->state_solar_gain || spec->state_thermal || spec->state_hvac || spec->message_thermal ||
+      spec->message_hvac || spec->nb_comm != 10 || spec->links != nullptr || spec->random_links || spec->comm_defect_prob > 0.0)
+    return fail(env, MDR_ERR_UNSUPPORTED, "observe -> act covers the default observation (51 features) only");
+  mdr::ObserveArgs o{};
+  o.Ta = a.Ta; o.Tm = a.Tm; o.target = a.target; o.deadband = a.deadband; o.capacity = a.capacity; o.P_max = a.P_max;
+  o.sso = a.sso; o.lockout = a.lockout; o.flags = a.flags; o.P = a.P; o.sig_now = a.sig_now;
+  o.cursor = a.cursor; o.cursor_max = a.cursor_max;
+  o.E = a.E; o.N = a.N;
+  o.obs_tshift = a.obs_tshift; o.inv_norm_reg = a.inv_norm_reg; o.inv_cap = a.inv_cap; o.inv_obs_norm = a.inv_obs_norm;
+  rc = mdr::launch_actor_observe(actor, o, seed, step, step_dev, action, a_prob, probs, (hipStream_t)stream);
+  if (rc == MDR_ERR_UNSUPPORTED) return fail(env, rc, "observe -> act: shape or actor layout without a kernel (nb_houses % 32, FRAG16 / BF16X3 in MDR_FEATURES_OBSERVE order)");
+  if (rc != MDR_OK) return fail(env, rc, "actor_observe launch failed");
   return MDR_OK;
 }
 

@@ -147,6 +147,22 @@ struct RolloutArgs {
   int defer_last_signal_error;   // the last step's reg_signal is not final yet (interpolation update due): the host adds it
 };
 
+// Observe -> act without observation rows (mdr_env_actor_sample, csrc/mdr_policy.hip): what the fused policy kernels read
+// instead of the rows of mdr_env_obs_vector, for the reference's DEFAULT observation (11 own features + 10 circular
+// neighbours x 4 message fields, utils.py:774-878)
+struct ObserveArgs {
+  const float *Ta, *Tm, *target, *deadband, *capacity, *P_max;
+  const int32_t *sso, *lockout;
+  const uint8_t* flags;
+  const double* P;         // [E] cluster_hvac_power
+  const double* sig_now;   // [E] regulation signal of the current time index (graph mode: table row 0, the kernel adds cursor[0] rows)
+  const int32_t* cursor;   // graph mode: {table row, time index} on the device, or nullptr
+  int32_t cursor_max;
+  int E, N;
+  float obs_tshift, inv_norm_reg, inv_cap;
+  double inv_obs_norm;
+};
+
 enum StepKind { STEP_FUSED = 0, STEP_GROUP = 1, STEP_SPLIT = 2, STEP_SINGLE = 3 };
 struct StepPlan {
   int kind, vec, threads, tiles;
@@ -177,6 +193,9 @@ hipError_t launch_obs_messages(const ObsArgs& a, hipStream_t s);               /
 hipError_t launch_obs_vector_ext(const ObsArgs& a, int layout, hipStream_t s);  // senders read from msg_ext_in through links
 hipError_t launch_comm_draws(const ObsArgs& a, int32_t* senders, uint8_t* keep, hipStream_t s);   // per-slot sender ids + keep flags
 int obs_message_fields(const mdr_obs_spec_t& s);
+// the policy kernels of csrc/mdr_policy.hip on the compact state; actor / step_dev etc. as mdr_actor_sample
+int launch_actor_observe(const struct mdr_actor* actor, const ObserveArgs& o, uint64_t seed, uint64_t step, const int32_t* step_dev,
+                         uint8_t* action, float* a_prob, float* probs, hipStream_t s);
 int obs_vector_length(const mdr_obs_spec_t& spec);
 hipError_t launch_step_begin_split(const StepArgs& a, bool reduce, hipStream_t s);
 hipError_t launch_step_end_split(const StepArgs& a, hipStream_t s);

@@ -1384,15 +1384,6 @@ __device__ __forceinline__ MsgFields sender_from_lds(const ObsArgs& a, const flo
   return s;
 }
 
-// a / L for integer-valued a and L (exact in fp32) with y = RN(1 / L): q = RN(a y), r = a - q L (exact in one fma),
-// RN(q + r y) is the correctly rounded quotient (Markstein; L's significand is never all ones below 2^24 - 1; checked
-// exhaustively for a <= 20000, L <= 3000), i.e. the very bits the `/` of the other kernels gives, in 3 ops instead of ~10
-__device__ __forceinline__ float div_by_lockout(float a, float L, float y) {
-  if (L == 0.0f) return a / L;   // inf / nan exactly as the division produces them
-  const float q = a * y;
-  return __fmaf_rn(__fmaf_rn(-q, L, a), y, q);
-}
-
 // message record of a sender slot (sharded houses: local messages followed by the halo), fields in MsgFields order
 __device__ __forceinline__ MsgFields sender_from_ext(const ObsArgs& a, int e, int slot) {
   const float* r = a.msg_ext_in + ((int64_t)e * a.ext_entries + slot) * a.mf;

@@ -23,6 +23,7 @@
 #include "../../include/mdr.h"
 #include "../../include/mdr_policy.h"
 #include "mdr_device.h"
+#include "mdr_kernels.h"
 
 namespace {
 
@@ -478,6 +479,388 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) 
   }
 }
 
+
+// =================================================================================================================
+// Observe -> act: the same forwards with the B operand built from the compact state instead of observation rows.
+//
+// Per wavefront and tile of TILE consecutive agents (= houses h0 .. h0 + TILE - 1 of ONE env: N % TILE == 0) the lanes
+// p < TILE + 10 load the nine per-house values of house h0 - 5 + p (circular in the env), turn them into
+//   the house's SingleHouse.message record   (Ta - target) / 5 | seconds_since_off | curr / norm | max / norm      (env 624-662)
+//   its own normStateDict features           (Ta-20)/5 (Tm-20)/5 (target-20)/5 deadband cap/def on lock sso/L L/L S/norm P/norm
+// with the very expressions of obs_features() / sender_from_global() in mdr_kernels.hip, and write them into the wave's LDS
+// window as ready rows  row[r] = [ message of slot 0..9 (40 floats) | own (11) | L | 1/L | pad ]  (OBS_ROW floats): the record
+// of the house at window position p is message slot m of the agents r = p - m - (m >= 5) - up to ten 16-byte stores.
+// The matrix-core forward then reads each lane's feature run with 16-byte LDS loads; the sender's seconds_since_off is
+// divided by the RECEIVER's lockout (utils.py:849-851) on the way, with div_by_lockout() as k_obs_rows_default does.
+// Feature k of a row is normStateDict index (k < 40 ? 11 + k : k - 40): the weights come packed in that order
+// (mdr_actor_t.feature_order = 1).  The loads for the next tile are issued before layer 1 and land during it; the rows
+// are staged between the k-steps of layer 2, read back before the head, so one window per wave suffices.
+// =================================================================================================================
+constexpr int OBS_HALO = 5, OBS_C = 10, OBS_ROW = 56, OBS_PAD = 16;   // floats; 56 = 40 + 11 + L + 1/L + 3 (16-byte rows)
+
+struct HouseRegs {
+  float Ta, Tm, tg, db, cap, pm;
+  int sso, lk;
+  unsigned fl;
+  float sig, pw;
+};
+
+__device__ __forceinline__ const double* observe_sig_row(const mdr::ObserveArgs& o) {
+  if (o.cursor == nullptr) return o.sig_now;
+  return o.sig_now + (int64_t)min(o.cursor[0], o.cursor_max + 1) * o.E;   // as rebase(ObsArgs&) in mdr_kernels.hip
+}
+
+template <int TILE>
+__device__ __forceinline__ HouseRegs observe_load(const mdr::ObserveArgs& o, const double* sig_row, int e, int h0, int lane) {
+  HouseRegs r{};
+  if (lane < TILE + 2 * OBS_HALO) {
+    int hh = h0 - OBS_HALO + lane;
+    hh += hh < 0 ? o.N : 0;
+    hh -= hh >= o.N ? o.N : 0;
+    const int64_t i = (int64_t)e * o.N + hh;
+    r.Ta = o.Ta[i];
+    r.Tm = o.Tm[i];
+    r.tg = o.target[i];
+    r.db = o.deadband[i];
+    r.cap = o.capacity[i];
+    r.pm = o.P_max[i];
+    r.sso = o.sso[i];
+    r.lk = o.lockout[i];
+    r.fl = o.flags[i];
+  }
+  r.sig = (float)(sig_row[e] * o.inv_obs_norm);   // utils.py:832-841, per env
+  r.pw = (float)(o.P[e] * o.inv_obs_norm);
+  return r;
+}
+
+template <int TILE>
+__device__ __forceinline__ void observe_stage(const mdr::ObserveArgs& o, const HouseRegs& r, float* rows, int lane) {
+  if (lane >= TILE + 2 * OBS_HALO) return;
+  const float4 rec = make_float4((r.Ta - r.tg) * 0.2f, (float)r.sso, ((r.fl & 1u) ? r.pm : 0.0f) * o.inv_norm_reg, r.pm * o.inv_norm_reg);
+#pragma unroll
+  for (int m = 0; m < OBS_C; ++m) {
+    const int rr = lane - m - (m >= OBS_HALO ? 1 : 0);   // the agent this house is sender slot m of (env 816-828)
+    if (rr >= 0 && rr < TILE) *reinterpret_cast<float4*>(rows + rr * OBS_ROW + 4 * m) = rec;
+  }
+  const int rr = lane - OBS_HALO;
+  if (rr >= 0 && rr < TILE) {
+    const float L = (float)r.lk;
+    float* own = rows + rr * OBS_ROW + 4 * OBS_C;
+    *reinterpret_cast<float4*>(own) = make_float4((r.Ta + o.obs_tshift) * 0.2f, (r.Tm + o.obs_tshift) * 0.2f, (r.tg + o.obs_tshift) * 0.2f, r.db);
+    *reinterpret_cast<float4*>(own + 4) = make_float4(r.cap * o.inv_cap, (r.fl & 1u) ? 1.0f : 0.0f, (r.fl & 2u) ? 1.0f : 0.0f, (float)r.sso / L);
+    *reinterpret_cast<float4*>(own + 8) = make_float4(L / L, r.sig, r.pw, L);
+    own[12] = 1.0f / L;
+  }
+}
+
+// (env, first house) of a tile, advanced by a fixed stride without a division per tile
+struct TileCursor {
+  int e, h0, de, dh, N;
+  __device__ __forceinline__ void init(int64_t first_agent, int64_t stride_agents, int n) {
+    N = n;
+    e = (int)(first_agent / n);
+    h0 = (int)(first_agent - (int64_t)e * n);
+    de = (int)(stride_agents / n);
+    dh = (int)(stride_agents - (int64_t)de * n);
+  }
+  __device__ __forceinline__ void next() {
+    e += de;
+    h0 += dh;
+    if (h0 >= N) {
+      h0 -= N;
+      e += 1;
+    }
+  }
+};
+
+// ---- bf16x3 form: 32 agents per wavefront (two 16-agent column blocks), k-step s of layer 1 = row floats [32 s + 8 g, + 8)
+template <int MB>
+__global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a, mdr::ObserveArgs o) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int S2B = (MB + 1) / 2, TILE = 16 * NCB, WIN = TILE * OBS_ROW + OBS_PAD;
+  uint4* f1 = reinterpret_cast<uint4*>(lds);                    // [2][8][2][64] fragments of 8 bf16
+  uint4* f2 = f1 + 2 * 1024;                                    // [S2B][8][2][64]
+  float* wd = reinterpret_cast<float*>(f2 + S2B * 1024);        // head weights + biases (512 floats reserved)
+  const int tid = threadIdx.x;
+  float* rows = wd + 512 + (tid >> 6) * WIN;                    // this wave's window
+  const uint4* g1 = reinterpret_cast<const uint4*>(a.frag1);
+  const uint4* g2 = reinterpret_cast<const uint4*>(a.frag2);
+  for (int i = tid; i < 2 * 1024; i += 64 * WAVESB) f1[i] = g1[i];
+  for (int i = tid; i < S2B * 1024; i += 64 * WAVESB) f2[i] = g2[i];
+  if (tid < 388) wd[tid] = a.wdiff[tid];
+  const int lane = tid & 63;
+  for (int i = lane; i < WIN; i += 64) rows[i] = 0.0f;          // pads are read (against zero weights): they must be finite
+  __syncthreads();
+
+  const int r = lane & 15, g = lane >> 4;
+  const int64_t wave = (int64_t)blockIdx.x * WAVESB + (tid >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * WAVESB;
+  const f32x4* bias1 = reinterpret_cast<const f32x4*>(wd + 128) + g;
+  const f32x4* bias2 = reinterpret_cast<const f32x4*>(wd + 256) + g;
+  const float bias3 = wd[384];
+  const double* sig_row = observe_sig_row(o);
+  TileCursor tc;
+  tc.init(wave * TILE, nwaves * TILE, o.N);
+  float xr[NCB][16];
+  // the lane's 16 features of column block c: two runs of 8 floats of row c * 16 + r
+  auto gather = [&]() {
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+      const float* row = rows + (c * 16 + r) * OBS_ROW;
+      const float L = row[4 * OBS_C + 11], y = row[4 * OBS_C + 12];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const float4 v0 = *reinterpret_cast<const float4*>(row + 32 * s + 8 * g);
+        const float4 v1 = *reinterpret_cast<const float4*>(row + 32 * s + 8 * g + 4);
+        const bool msg = (s == 0) || (g == 0);   // this run holds two message records: their second field is seconds_since_off
+        xr[c][8 * s + 0] = v0.x;
+        xr[c][8 * s + 1] = msg ? mdr::div_by_lockout(v0.y, L, y) : v0.y;
+        xr[c][8 * s + 2] = v0.z;
+        xr[c][8 * s + 3] = v0.w;
+        xr[c][8 * s + 4] = v1.x;
+        xr[c][8 * s + 5] = msg ? mdr::div_by_lockout(v1.y, L, y) : v1.y;
+        xr[c][8 * s + 6] = v1.z;
+        xr[c][8 * s + 7] = v1.w;
+      }
+    }
+  };
+  if (wave < a.ntiles) {
+    const HouseRegs first = observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
+    observe_stage<TILE>(o, first, rows, lane);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // compiler ordering only: LDS operations of one wave complete in issue order
+    gather();
+  }
+  uint32_t rnd[NCB] = {};
+  int it = 0;
+  for (int64_t t = wave; t < a.ntiles; t += nwaves, ++it) {
+    if ((it & 3) == 0) {
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) {
+        const int64_t ag = ((t + g * nwaves) * NCB + c) * 16 + r;
+        rnd[c] = philox4x32_10((uint32_t)ag, (uint32_t)((uint64_t)ag >> 32), a.step_lo + (a.step_dev ? (uint32_t)*a.step_dev : 0u),
+                               TAG_ACTION ^ a.step_hi, a.k0, a.k1).x;
+      }
+    }
+    // the next tile's compact state: issued now, consumed between the k-steps of layer 2
+    const bool more = t + nwaves < a.ntiles;
+    tc.next();
+    HouseRegs nxt{};
+    if (more) nxt = observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
+    f32x4 acc[NCB][MB];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) acc[c][mb] = bias1[mb * 4];
+    // ---- layer 1 (F = 51: both k-steps)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 Bh[NCB], Bl[NCB];
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) {
+        uint4 bh, bl;
+        split8(xr[c] + 8 * s, bh, bl);
+        Bh[c] = __builtin_bit_cast(bf16x8, bh);
+        Bl[c] = __builtin_bit_cast(bf16x8, bl);
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const bf16x8 Ah = __builtin_bit_cast(bf16x8, f1[((s * 8 + mb) * 2 + 0) * 64 + lane]);
+        const bf16x8 Al = __builtin_bit_cast(bf16x8, f1[((s * 8 + mb) * 2 + 1) * 64 + lane]);
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+          acc[c][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh[c], acc[c][mb], 0, 0, 0);
+          acc[c][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh[c], acc[c][mb], 0, 0, 0);
+          acc[c][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl[c], acc[c][mb], 0, 0, 0);
+        }
+      }
+    }
+    // ---- layer 2; the next tile's rows are staged after its first k-step (this tile's rows were read before its layer 1)
+    f32x4 out[NCB][MB];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) out[c][mb] = bias2[mb * 4];
+#pragma unroll
+    for (int s = 0; s < S2B; ++s) {
+      if (s == 1 && more) observe_stage<TILE>(o, nxt, rows, lane);
+      bf16x8 Bh[NCB], Bl[NCB];
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (2 * s + (j >> 2) < MB) ? relu(acc[c][2 * s + (j >> 2) < MB ? 2 * s + (j >> 2) : 0][j & 3]) : 0.0f;
+        uint4 bh, bl;
+        split8(v, bh, bl);
+        Bh[c] = __builtin_bit_cast(bf16x8, bh);
+        Bl[c] = __builtin_bit_cast(bf16x8, bl);
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const bf16x8 Ah = __builtin_bit_cast(bf16x8, f2[((s * 8 + mb) * 2 + 0) * 64 + lane]);
+        const bf16x8 Al = __builtin_bit_cast(bf16x8, f2[((s * 8 + mb) * 2 + 1) * 64 + lane]);
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+          out[c][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh[c], out[c][mb], 0, 0, 0);
+          out[c][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh[c], out[c][mb], 0, 0, 0);
+          out[c][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl[c], out[c][mb], 0, 0, 0);
+        }
+      }
+    }
+    if (more) {   // LDS operations of one wave complete in order: the rows staged above are what these loads see
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // compiler ordering only: LDS operations of one wave complete in issue order
+      gather();
+    }
+    // ---- head
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+      const int64_t agent = (t * NCB + c) * 16 + r;
+      const bool valid = agent < a.A;
+      float d = 0.0f;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d = fmaf(wd[(mb * 4 + i) * 4 + g], relu(out[c][mb][i]), d);
+      d += __shfl_xor(d, 16);
+      d += __shfl_xor(d, 32);
+      d += bias3;
+      const float e = expf(-d);
+      const float p0 = 1.0f / (1.0f + e);
+      const float p1 = e > 1e30f ? 1.0f : e * p0;
+      const uint32_t draw = (uint32_t)__shfl((int)rnd[c], r + 16 * (it & 3));
+      if (g == 0 && valid) {
+        const float u = ((float)(draw >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const int act = a.greedy ? (d >= 0.0f ? 0 : 1) : (u < p0 ? 0 : 1);
+        a.action[agent] = (uint8_t)act;
+        if (a.a_prob) a.a_prob[agent] = act ? p1 : p0;
+        if (a.probs) {
+          a.probs[agent * 2] = p0;
+          a.probs[agent * 2 + 1] = p1;
+        }
+      }
+    }
+  }
+}
+
+// ---- exact-fp32 form (v_mfma_f32_16x16x4_f32): 16 agents per wavefront, lane group g holds features [13 g, 13 g + 13) of its agent
+template <int MB>
+__global__ __launch_bounds__(64 * WAVES16) void k_actor_observe16(ActorArgs a, mdr::ObserveArgs o) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int TILE = 16, WIN = TILE * OBS_ROW + OBS_PAD, S1 = 13;
+  float* f1 = lds;                       // [13][64][8]
+  float* f2 = f1 + S1 * 512;             // [S2][64][8]
+  float* wd = f2 + a.S2 * 512;           // head weights + biases (512 floats reserved)
+  const int tid = threadIdx.x;
+  float* rows = wd + 512 + (tid >> 6) * WIN;
+  for (int i = tid * 4; i < S1 * 512; i += 64 * WAVES16 * 4) *reinterpret_cast<float4*>(f1 + i) = *reinterpret_cast<const float4*>(a.frag1 + i);
+  for (int i = tid * 4; i < a.S2 * 512; i += 64 * WAVES16 * 4) *reinterpret_cast<float4*>(f2 + i) = *reinterpret_cast<const float4*>(a.frag2 + i);
+  if (tid < 388) wd[tid] = a.wdiff[tid];
+  const int lane = tid & 63;
+  for (int i = lane; i < WIN; i += 64) rows[i] = 0.0f;
+  __syncthreads();
+
+  const int r = lane & 15, g = lane >> 4;
+  const int64_t wave = (int64_t)blockIdx.x * WAVES16 + (tid >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * WAVES16;
+  const f32x4* bias1 = reinterpret_cast<const f32x4*>(wd + 128) + g;
+  const f32x4* bias2 = reinterpret_cast<const f32x4*>(wd + 256) + g;
+  const float bias3 = wd[384];
+  const double* sig_row = observe_sig_row(o);
+  TileCursor tc;
+  tc.init(wave * TILE, nwaves * TILE, o.N);
+  // which of the lane's 13 features are a sender's seconds_since_off (row float k = 13 g + s with k < 40, k % 4 == 1)
+  uint32_t sso_mask = 0;
+#pragma unroll
+  for (int s = 0; s < S1; ++s) {
+    const int k = S1 * g + s;
+    if (k < 4 * OBS_C && (k & 3) == 1) sso_mask |= 1u << s;
+  }
+  float xr[16];
+  auto gather = [&]() {
+    const float* row = rows + r * OBS_ROW;
+    const float L = row[4 * OBS_C + 11], y = row[4 * OBS_C + 12];
+#pragma unroll
+    for (int s = 0; s < S1; ++s) {
+      const float v = row[S1 * g + s];
+      xr[s] = ((sso_mask >> s) & 1u) ? mdr::div_by_lockout(v, L, y) : v;
+    }
+  };
+  if (wave < a.ntiles) {
+    const HouseRegs first = observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
+    observe_stage<TILE>(o, first, rows, lane);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // compiler ordering only: LDS operations of one wave complete in issue order
+    gather();
+  }
+  uint32_t rnd = 0;
+  int it = 0;
+  for (int64_t t = wave; t < a.ntiles; t += nwaves, ++it) {
+    const int64_t agent = t * 16 + r;
+    const bool valid = agent < a.A;
+    if ((it & 3) == 0) {
+      const int64_t ag = (t + g * nwaves) * 16 + r;
+      rnd = philox4x32_10((uint32_t)ag, (uint32_t)((uint64_t)ag >> 32), a.step_lo + (a.step_dev ? (uint32_t)*a.step_dev : 0u), TAG_ACTION ^ a.step_hi, a.k0, a.k1).x;
+    }
+    const bool more = t + nwaves < a.ntiles;
+    tc.next();
+    HouseRegs nxt{};
+    if (more) nxt = observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
+    f32x4 acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = bias1[mb * 4];
+    // ---- layer 1
+#pragma unroll
+    for (int s = 0; s < S1; ++s) {
+      const float4 w0 = *reinterpret_cast<const float4*>(f1 + s * 512 + lane * 8);
+      const float4 w1 = *reinterpret_cast<const float4*>(f1 + s * 512 + lane * 8 + 4);
+      const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[mb], xr[s], acc[mb], 0, 0, 0);
+    }
+    // ---- layer 2; the next tile's rows are staged after a few k-steps, read back at the end
+    f32x4 out[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) out[mb] = bias2[mb * 4];
+#pragma unroll
+    for (int q = 0; q < 4 * MB; ++q) {
+      if (q == 8 && more) observe_stage<TILE>(o, nxt, rows, lane);
+      if (q < a.S2) {
+        const float b = relu(acc[q >> 2][q & 3]);
+        const float4 w0 = *reinterpret_cast<const float4*>(f2 + q * 512 + lane * 8);
+        const float4 w1 = *reinterpret_cast<const float4*>(f2 + q * 512 + lane * 8 + 4);
+        const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) out[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[mb], b, out[mb], 0, 0, 0);
+      }
+    }
+    if (more) {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // compiler ordering only: LDS operations of one wave complete in issue order
+      gather();
+    }
+    // ---- head
+    float d = 0.0f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) d = fmaf(wd[(mb * 4 + i) * 4 + g], relu(out[mb][i]), d);
+    d += __shfl_xor(d, 16);
+    d += __shfl_xor(d, 32);
+    d += bias3;
+    const float e = expf(-d);
+    const float p0 = 1.0f / (1.0f + e);
+    const float p1 = e > 1e30f ? 1.0f : e * p0;
+    const uint32_t draw = (uint32_t)__shfl((int)rnd, r + 16 * (it & 3));
+    if (g == 0 && valid) {
+      const float u = ((float)(draw >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const int act = a.greedy ? (d >= 0.0f ? 0 : 1) : (u < p0 ? 0 : 1);
+      a.action[agent] = (uint8_t)act;
+      if (a.a_prob) a.a_prob[agent] = act ? p1 : p0;
+      if (a.probs) {
+        a.probs[agent * 2] = p0;
+        a.probs[agent * 2 + 1] = p1;
+      }
+    }
+  }
+}
+
 // PPO.update's Monte-Carlo return scan (agents/ppo.py:123-134), backwards over the T steps of every agent:
 // R <- reward[t] + gamma * (done[t] ? bootstrap[t] (or 0) : R).  One thread per agent, steps coalesced across agents.
 __global__ __launch_bounds__(256) void k_discounted_returns(const float* reward, const uint8_t* done, const float* bootstrap, float gamma,
@@ -521,6 +904,49 @@ bool layout_ok(int layout) { return layout == MDR_ACTOR_FRAG32 || layout == MDR_
 
 }  // namespace
 
+namespace mdr {
+
+int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_t seed, uint64_t step, const int32_t* step_dev, uint8_t* action,
+                         float* a_prob, float* probs, hipStream_t stream) {
+  if (!actor || actor->struct_size != sizeof(mdr_actor_t) || !action) return MDR_ERR_INVALID;
+  if (!actor->frag1 || !actor->frag2 || !actor->wdiff) return MDR_ERR_INVALID;
+  const int layout = actor->layout;
+  if (layout != MDR_ACTOR_FRAG16 && layout != MDR_ACTOR_BF16X3) return MDR_ERR_UNSUPPORTED;
+  if (actor->feature_order != 1 || actor->num_state != 4 * OBS_C + 11) return MDR_ERR_UNSUPPORTED;
+  if (actor->hidden1 <= 0 || actor->hidden2 <= 0 || actor->hidden1 > MDR_ACTOR_MAX_HIDDEN || actor->hidden2 > MDR_ACTOR_MAX_HIDDEN) return MDR_ERR_INVALID;
+  const bool lbf = layout == MDR_ACTOR_BF16X3;
+  const int tile = lbf ? 16 * NCB : 16, waves = lbf ? WAVESB : WAVES16;
+  if (o.N < 32 || o.N % 32 != 0) return MDR_ERR_UNSUPPORTED;   // a tile never spans two envs, the 5 + 5 neighbours wrap at most once
+  ActorArgs a{};
+  a.frag1 = static_cast<const float*>(actor->frag1); a.frag2 = static_cast<const float*>(actor->frag2); a.wdiff = actor->wdiff;
+  a.action = action; a.a_prob = a_prob; a.probs = probs;
+  a.A = (int64_t)o.E * o.N;
+  a.ntiles = a.A / tile;
+  a.F = actor->num_state; a.S1 = steps1(layout, actor->num_state); a.S2 = steps2(layout, actor->hidden1);
+  a.k0 = (uint32_t)(seed & 0xFFFFFFFFull); a.k1 = (uint32_t)(seed >> 32);
+  a.step_lo = (uint32_t)(step & 0xFFFFFFFFull); a.step_hi = (uint32_t)(step >> 32);
+  a.step_dev = step_dev;
+  a.greedy = actor->greedy != 0;
+  const size_t window = (size_t)tile * OBS_ROW + OBS_PAD;
+  const size_t lds_bytes = ((size_t)(a.S1 + a.S2) * floats_per_step(layout) + 512 + (size_t)waves * window) * sizeof(float);
+  if (lds_bytes > 160 * 1024) return MDR_ERR_UNSUPPORTED;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+  const int64_t want = (a.ntiles + waves - 1) / waves;
+  const unsigned grid = (unsigned)(want < cus ? want : cus);
+  auto launch = [&](auto kernel) -> int {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+      return MDR_ERR_HIP;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * waves), lds_bytes, stream, a, o);
+    return hipGetLastError() == hipSuccess ? MDR_OK : MDR_ERR_HIP;
+  };
+  const int mb = blocks16(actor->hidden1, actor->hidden2);
+  if (lbf) return mb == 7 ? launch(k_actor_observe_bf16<7>) : launch(k_actor_observe_bf16<8>);
+  return mb == 7 ? launch(k_actor_observe16<7>) : launch(k_actor_observe16<8>);
+}
+
+}  // namespace mdr
+
 extern "C" {
 
 int64_t mdr_actor_steps1(int32_t layout, int32_t num_state) { return (layout_ok(layout) && num_state > 0) ? steps1(layout, num_state) : -1; }
@@ -540,6 +966,7 @@ int mdr_actor_sample(const mdr_actor_t* actor, const float* obs, int64_t obs_pla
   if (obs_plane_stride != 0 && obs_plane_stride < nb_agents) return MDR_ERR_INVALID;
   if (!actor->frag1 || !actor->frag2 || !actor->wdiff || !layout_ok(actor->layout)) return MDR_ERR_INVALID;
   if (actor->num_state <= 0 || actor->hidden1 <= 0 || actor->hidden2 <= 0) return MDR_ERR_INVALID;
+  if (actor->feature_order != 0) return MDR_ERR_INVALID;   // weights packed for mdr_env_actor_sample: observation rows are in normStateDict order
   if (actor->hidden1 > MDR_ACTOR_MAX_HIDDEN || actor->hidden2 > MDR_ACTOR_MAX_HIDDEN) return MDR_ERR_UNSUPPORTED;
   if (nb_agents == 0) return MDR_OK;
   const int layout = actor->layout;

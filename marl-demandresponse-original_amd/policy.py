@@ -18,11 +18,19 @@ MAX_HIDDEN = 127
 
 
 FRAG32, FRAG16, BF16X3 = 0, 1, 2
+FEATURES_NORMSTATE, FEATURES_OBSERVE = 0, 1
+OBSERVE_NUM_STATE = 51      # the reference's default observation: 11 own features + 10 neighbours x 4 message fields
+
+
+def observe_feature_order() -> np.ndarray:
+    """normStateDict index of staged feature k in MDR_FEATURES_OBSERVE order: the 10 messages first, then the 11 own features."""
+    k = np.arange(OBSERVE_NUM_STATE)
+    return np.where(k < 40, 11 + k, k - 40)
 
 
 class MdrActor(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("layout", C.c_int32), ("num_state", C.c_int32), ("hidden1", C.c_int32),
-                ("hidden2", C.c_int32), ("greedy", C.c_int32),
+                ("hidden2", C.c_int32), ("greedy", C.c_int32), ("feature_order", C.c_int32), ("reserved0", C.c_int32),
                 ("frag1", C.c_void_p), ("frag2", C.c_void_p), ("wdiff", C.c_void_p)]
 
 
@@ -31,13 +39,21 @@ def _acc_row(reg: np.ndarray, half: np.ndarray) -> np.ndarray:
 
 
 class FusedActor:
-    def __init__(self, w1, b1, w2, b2, w3, b3, device="cuda:0", layout: Optional[int] = None, greedy: bool = False):
+    def __init__(self, w1, b1, w2, b2, w3, b3, device="cuda:0", layout: Optional[int] = None, greedy: bool = False,
+                 feature_order: int = FEATURES_NORMSTATE):
         """w1 [H1, F], b1 [H1], w2 [H2, H1], b2 [H2], w3 [2, H2], b3 [2] (torch.nn.Linear layout).
+        ``feature_order=FEATURES_OBSERVE`` packs W1's columns in the order ``sample_env`` stages the default observation in
+        (observe -> act without observation rows: ``mdr_env_actor_sample``); such an actor serves ``sample_env`` only.
         ``layout``: FRAG16 (v_mfma_f32_16x16x4_f32, exact fp32, the default whenever F <= 63), FRAG32
         (v_mfma_f32_32x32x2_f32, exact fp32, any F) or BF16X3 (bf16 MFMA on head + tail halves of every operand:
         probabilities within ~1e-5 of the fp32 forward, several times faster; F <= 63)."""
         self._lib = nat.load()
         w1, b1, w2, b2, w3, b3 = (torch.as_tensor(t, dtype=torch.float32).detach().cpu() for t in (w1, b1, w2, b2, w3, b3))
+        self.feature_order = int(feature_order)
+        if self.feature_order == FEATURES_OBSERVE:
+            if w1.shape[1] != OBSERVE_NUM_STATE:
+                raise ValueError("observe -> act covers the default observation (%d features)" % OBSERVE_NUM_STATE)
+            w1 = w1[:, torch.from_numpy(observe_feature_order())]
         H1, F = w1.shape
         H2 = w2.shape[0]
         if w2.shape[1] != H1 or tuple(w3.shape) != (2, H2):
@@ -94,7 +110,7 @@ class FusedActor:
         assert self._wdiff.numel() == (128 if self.layout == FRAG32 else 388)
         assert self._frag1.numel() == self._lib.mdr_actor_frag1_floats(self.layout, F)
         assert self._frag2.numel() == self._lib.mdr_actor_frag2_floats(self.layout, H1)
-        self._desc = MdrActor(C.sizeof(MdrActor), self.layout, F, H1, H2, int(self.greedy), self._frag1.data_ptr(), self._frag2.data_ptr(),
+        self._desc = MdrActor(C.sizeof(MdrActor), self.layout, F, H1, H2, int(self.greedy), self.feature_order, 0, self._frag1.data_ptr(), self._frag2.data_ptr(),
                               self._wdiff.data_ptr())
 
     def _bias_block(self, b1, b2, b3) -> torch.Tensor:
@@ -140,18 +156,45 @@ class FusedActor:
         assert self._wdiff.numel() == 388
         assert self._frag1.numel() * 2 == 4 * self._lib.mdr_actor_frag1_floats(self.layout, F)
         assert self._frag2.numel() * 2 == 4 * self._lib.mdr_actor_frag2_floats(self.layout, H1)
-        self._desc = MdrActor(C.sizeof(MdrActor), self.layout, F, H1, H2, int(self.greedy), self._frag1.data_ptr(), self._frag2.data_ptr(),
+        self._desc = MdrActor(C.sizeof(MdrActor), self.layout, F, H1, H2, int(self.greedy), self.feature_order, 0, self._frag1.data_ptr(), self._frag2.data_ptr(),
                               self._wdiff.data_ptr())
 
     @classmethod
-    def from_module(cls, actor, device=None, layout: Optional[int] = None, greedy: bool = False) -> "FusedActor":
+    def from_module(cls, actor, device=None, layout: Optional[int] = None, greedy: bool = False,
+                    feature_order: int = FEATURES_NORMSTATE) -> "FusedActor":
         """From an ``ActorMLP`` / the reference's ``Actor`` - or, with ``greedy=True``, its ``DQN_network`` (the same ``fc``
         ModuleList of three Linear layers, agents/network.py:58-77, whose two outputs are Q-values: action = argmax)."""
         fc = list(actor.fc)
         if len(fc) != 3:
             raise ValueError("the fused kernel covers two hidden layers (config.py: layers = [100, 100])")
         dev = device if device is not None else fc[0].weight.device
-        return cls(fc[0].weight, fc[0].bias, fc[1].weight, fc[1].bias, fc[2].weight, fc[2].bias, device=dev, layout=layout, greedy=greedy)
+        return cls(fc[0].weight, fc[0].bias, fc[1].weight, fc[1].bias, fc[2].weight, fc[2].bias, device=dev, layout=layout, greedy=greedy,
+                   feature_order=feature_order)
+
+    def sample_env(self, env, seed: int, step: int, want_probs: bool = False, action: Optional[torch.Tensor] = None,
+                   a_prob: Optional[torch.Tensor] = None, step_dev: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, ...]:
+        """Observe -> act in ONE kernel (``mdr_env_actor_sample``): ``utils.normStateDict`` of every agent of ``env`` (a
+        ``BatchedDemandResponseEnv`` in its current state) is built in LDS from the compact state and fed straight to the
+        matrix-core forward - no observation rows.  Needs an actor packed with ``feature_order=FEATURES_OBSERVE`` (layout FRAG16
+        or BF16X3), the default observation, ``nb_houses % 32 == 0``; raises ``NotImplementedError`` otherwise (use
+        ``env.obs_vector('rows')`` + ``sample``).  Same draws and outputs as ``sample`` on the rows (agent = env * N + house)."""
+        A = env.nb_envs * env.nb_houses
+        action = torch.empty(A, dtype=torch.uint8, device=self.device) if action is None else action
+        a_prob = torch.empty(A, dtype=torch.float32, device=self.device) if a_prob is None else a_prob
+        probs = torch.empty((A, 2), dtype=torch.float32, device=self.device) if want_probs else None
+        if step_dev is not None and (step_dev.dtype != torch.int32 or step_dev.device != self.device):
+            raise ValueError("step_dev must be an int32 tensor on the device (env.device_time_index)")
+        spec = env._obs_spec("rows")
+        with torch.cuda.device(self.device):
+            rc = self._lib.mdr_env_actor_sample(env._handle, C.byref(spec), C.byref(self._desc), C.c_uint64(seed & (2 ** 64 - 1)),
+                                                C.c_uint64(step & (2 ** 64 - 1)), C.c_void_p(step_dev.data_ptr()) if step_dev is not None else None,
+                                                C.c_void_p(action.data_ptr()), C.c_void_p(a_prob.data_ptr()),
+                                                C.c_void_p(probs.data_ptr()) if want_probs else None,
+                                                C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if rc == nat.MDR_ERR_UNSUPPORTED:
+            raise NotImplementedError("observe -> act: " + self._lib.mdr_last_error(env._handle).decode())
+        nat.check(self._lib, env._handle, rc, "mdr_env_actor_sample")
+        return (action, a_prob, probs) if want_probs else (action, a_prob)
 
     def sample(self, obs: torch.Tensor, seed: int, step: int, want_probs: bool = False,
                action: Optional[torch.Tensor] = None, a_prob: Optional[torch.Tensor] = None,

@@ -70,18 +70,31 @@ def _discounted_returns_hip(reward, done, gamma, bootstrap):
     return out
 
 
-def _fused_policy(actor, dev, precision: str = "fp32"):
-    """FusedActor of `actor`, re-packed only when a parameter changed (torch bumps `_version` on in-place updates)."""
-    from .policy import BF16X3, FusedActor
+def _fused_policy(actor, dev, precision: str = "fp32", observe: bool = False):
+    """FusedActor of `actor`, re-packed only when a parameter changed (torch bumps `_version` on in-place updates).
+    ``observe``: packed for ``FusedActor.sample_env`` (W1's columns in the order the observe -> act kernels stage the features)."""
+    from .policy import BF16X3, FEATURES_NORMSTATE, FEATURES_OBSERVE, FRAG16, FusedActor
     if precision not in ("fp32", "bf16x3"):
         raise ValueError("policy_precision must be 'fp32' or 'bf16x3'")
     key = tuple((p.data_ptr(), p._version) for p in actor.parameters()) + (str(dev), precision)
-    cached = getattr(actor, "_mdr_fused", None)
+    slot = "_mdr_fused_observe" if observe else "_mdr_fused"
+    cached = getattr(actor, slot, None)
     if cached is None or cached[0] != key:
-        layout = BF16X3 if precision == "bf16x3" and actor.fc[0].in_features <= 64 else None
-        cached = (key, FusedActor.from_module(actor, device=dev, layout=layout))
-        actor._mdr_fused = cached
+        layout = BF16X3 if precision == "bf16x3" and actor.fc[0].in_features <= 64 else (FRAG16 if observe else None)
+        cached = (key, FusedActor.from_module(actor, device=dev, layout=layout,
+                                              feature_order=FEATURES_OBSERVE if observe else FEATURES_NORMSTATE))
+        setattr(actor, slot, cached)
     return cached[1]
+
+
+def _observe_act_supported(env, actor) -> bool:
+    """Can ``FusedActor.sample_env`` serve this env / actor?  (default observation = 51 features with 10 circular neighbours and
+    no link defects, nb_houses a multiple of 32, unsharded houses)"""
+    from .policy import OBSERVE_NUM_STATE
+    cluster = env.config["default_env_prop"]["cluster_prop"]
+    return (not env.sharded and env.nb_houses % 32 == 0 and env.nb_houses >= 32 and actor.fc[0].in_features == OBSERVE_NUM_STATE
+            and env.obs_vector_length() == OBSERVE_NUM_STATE and cluster["agents_comm_mode"] == "neighbours"
+            and not getattr(env, "_links_forced", False) and float(cluster["comm_defect_prob"]) == 0.0)
 
 
 def _fusable(actor) -> bool:
@@ -114,7 +127,8 @@ def discounted_returns(reward: torch.Tensor, done: torch.Tensor, gamma: float,
 @torch.no_grad()
 def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.99, critic: Optional[nn.Module] = None,
                         generator: Optional[torch.Generator] = None, store_states: bool = True,
-                        fused: Optional[bool] = None, seed: int = 0, policy_precision: str = "fp32") -> Dict[str, torch.Tensor]:
+                        fused: Optional[bool] = None, seed: int = 0, policy_precision: str = "fp32",
+                        observe_act: Optional[bool] = None) -> Dict[str, torch.Tensor]:
     """Roll ``nb_steps`` with actions sampled from ``actor`` for every agent of every env.
 
     ``fused`` (default: whenever the actor has the reference's shape - two hidden layers of <= 127 units, two actions -
@@ -123,6 +137,9 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
     ``seed`` with the env's step counter in the counter; otherwise torch GEMMs + ``torch.multinomial``.
     ``policy_precision="bf16x3"`` runs the fused kernel on bf16 matrix instructions with every operand split into a
     bf16 head and tail (16 significand bits; probabilities within ~1e-5 of the fp32 forward) - about 2.7x faster.
+    ``observe_act`` (default: whenever the states are not stored and the shape allows it - the reference's default observation,
+    ``nb_houses % 32 == 0``): observation and policy are ONE kernel (``FusedActor.sample_env``): the 51 features of every agent
+    are built in LDS from the compact state, the 204-byte observation rows are neither written nor read.
 
     Returns tensors with the agents flattened as [T, E*N, ...] in the reference's per-agent order:
     ``state`` [T+1, E*N, F] (``state[t+1]`` is ``next_state[t]``; omitted if ``store_states`` is False), ``action`` int64,
@@ -139,8 +156,12 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
     policy = None
     if fused is None:
         fused = generator is None and _fusable(actor)
+    if observe_act is None:
+        observe_act = bool(fused) and not store_states and critic is None and _observe_act_supported(env, actor)
+    if observe_act and (store_states or not fused):
+        raise ValueError("observe_act needs the fused policy and store_states=False")
     if fused:
-        policy = _fused_policy(actor, dev, policy_precision)
+        policy = _fused_policy(actor, dev, policy_precision, observe=observe_act)
         act_u8 = torch.empty((T, E * N), dtype=torch.uint8, device=dev)
 
     def observe(t):      # straight into the transition buffer when states are kept: no 4 F bytes/agent copy per step
@@ -148,10 +169,13 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
             return env.obs_vector("rows", out=states[t].view(E, N, F_len)).view(E * N, F_len)
         return env.obs_vector("rows").view(E * N, F_len)
 
-    obs = observe(0)
+    obs = None if observe_act else observe(0)
     step0 = env.steps_taken
     for t in range(T):
-        if policy is not None:      # agents/ppo.py:68-75 for all agents: one kernel, action and a_prob written in place
+        if observe_act:             # normStateDict + select_action for all agents in ONE kernel: no observation rows at all
+            policy.sample_env(env, seed, step0 + t, action=act_u8[t], a_prob=a_prob[t])
+            _, r, _, _ = env.step(act_u8[t].view(E, N))
+        elif policy is not None:    # agents/ppo.py:68-75 for all agents: one kernel, action and a_prob written in place
             policy.sample(obs, seed, step0 + t, action=act_u8[t], a_prob=a_prob[t])
             _, r, _, _ = env.step(act_u8[t].view(E, N))
         else:
@@ -161,7 +185,8 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
             a_prob[t] = probs.gather(1, a[:, None]).squeeze(1)
             _, r, _, _ = env.step(a.to(torch.uint8).view(E, N))
         reward[t] = r.reshape(-1)
-        obs = observe(t + 1)
+        if not observe_act:
+            obs = observe(t + 1)
     if policy is not None:
         action.copy_(act_u8)        # one widening pass at the end (the reference stores Categorical's int64)
     done = torch.zeros((T, E * N), dtype=torch.bool, device=dev)

@@ -1,0 +1,166 @@
+"""Observe -> act in one kernel (mdr_env_actor_sample): utils.normStateDict of every agent built in LDS from the
+compact state and fed to the matrix-core Actor forward, against (a) the two-kernel path - mdr_env_obs_vector rows + mdr_actor_sample -
+whose observation is pinned on the reference's normStateDict vectors (tests/test_obs_vector.py) and (b) a plain PyTorch fp32 forward
+of the same Actor on those rows.  The staged features are the rows' bits; only the k order of layer 1 differs (messages first), so
+the probabilities agree to fp32 summation-order rounding (2e-6) - bf16x3: to its own 2e-5."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(N, **patches):
+    import mdr_amd
+    cfg = mdr_amd.default_config()
+    cfg["default_env_prop"]["cluster_prop"]["nb_agents"] = N
+    cfg["default_env_prop"]["power_grid_prop"]["base_power_mode"] = "constant"
+    cfg["default_env_prop"]["power_grid_prop"]["signal_mode"] = "perlin"
+    cfg["noise_house_prop"]["noise_mode"] = "big_noise"
+    cfg["noise_hvac_prop"]["noise_mode"] = "big_noise"
+    cfg["default_hvac_prop"]["lockout_noise"] = 15
+    for dotted, v in patches.items():
+        node = cfg
+        parts = dotted.split(".")
+        for p in parts[:-1]:
+            node = node[p]
+        node[parts[-1]] = v
+    return cfg
+
+
+def _actor(seed=0, scale=2.0, layers=(100, 100)):
+    from mdr_amd.rollout import ActorMLP
+    torch.manual_seed(seed)
+    actor = ActorMLP(51, 2, layers).to("cuda:0")
+    with torch.no_grad():
+        for lin in actor.fc:
+            lin.weight.mul_(scale)
+            lin.bias.uniform_(-0.5, 0.5)
+    return actor
+
+
+def _walk(env, steps, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    for _ in range(steps):
+        env.step((torch.rand((env.nb_envs, env.nb_houses), generator=g) < 0.5).to(torch.uint8).cuda())
+
+
+@pytest.mark.parametrize("E,N", [(3, 32), (5, 64), (2, 1024), (33, 96), (1, 4096), (700, 160)])
+@pytest.mark.parametrize("layout,layers", [(1, (100, 100)), (2, (100, 100)), (1, (127, 120)), (2, (64, 32))])
+def test_observe_act_equals_rows_then_actor(E, N, layout, layers):
+    import mdr_amd
+    from mdr_amd.policy import FEATURES_OBSERVE, FusedActor
+    env = mdr_amd.BatchedDemandResponseEnv(_cfg(N), nb_envs=E, device="cuda:0", seed=5 + N)
+    env.reset(episode=0)
+    actor = _actor(seed=E, layers=layers)
+    by_rows = FusedActor.from_module(actor, layout=layout)
+    by_state = FusedActor.from_module(actor, layout=layout, feature_order=FEATURES_OBSERVE)
+    for k in range(3):                                   # reset state (all off, sso = lockout), then two walked states
+        rows = env.obs_vector("rows").view(E * N, 51)
+        a0, p0, probs0 = by_rows.sample(rows, seed=9, step=k, want_probs=True)
+        a1, p1, probs1 = by_state.sample_env(env, seed=9, step=k, want_probs=True)
+        with torch.no_grad():
+            ref = actor(rows)
+        if layout == 2:
+            torch.testing.assert_close(probs1, ref, rtol=2e-3, atol=2e-5)
+            torch.testing.assert_close(probs1, probs0, rtol=2e-3, atol=2e-5)
+        else:
+            torch.testing.assert_close(probs1, ref, rtol=1e-5, atol=2e-6)
+            torch.testing.assert_close(probs1, probs0, rtol=1e-5, atol=2e-6)
+        assert torch.equal(p1, probs1.gather(1, a1.long()[:, None]).squeeze(1))
+        # same Philox draw per agent: the actions differ only where u falls between the two (nearly equal) probabilities
+        differ = a0 != a1
+        assert int(differ.sum()) <= max(2, E * N // 20000)
+        if bool(differ.any()):
+            assert float((probs0[differ, 0] - probs1[differ, 0]).abs().max()) < (1e-4 if layout == 2 else 1e-5)
+        _walk(env, 7, seed=k)
+
+
+def test_observe_act_refuses_what_it_does_not_cover():
+    import mdr_amd
+    from mdr_amd.policy import FEATURES_OBSERVE, FusedActor
+    actor = _actor()
+    by_state = FusedActor.from_module(actor, layout=1, feature_order=FEATURES_OBSERVE)
+    env = mdr_amd.BatchedDemandResponseEnv(_cfg(50), nb_envs=4, device="cuda:0", seed=1)          # N % 32 != 0
+    env.reset(episode=0)
+    with pytest.raises(NotImplementedError):
+        by_state.sample_env(env, 0, 0)
+    env = mdr_amd.BatchedDemandResponseEnv(_cfg(64, **{"default_env_prop.cluster_prop.comm_defect_prob": 0.2}), nb_envs=4, device="cuda:0", seed=1)
+    env.reset(episode=0)
+    with pytest.raises(NotImplementedError):
+        by_state.sample_env(env, 0, 0)
+    env = mdr_amd.BatchedDemandResponseEnv(_cfg(64), nb_envs=4, device="cuda:0", seed=1)
+    env.reset(episode=0)
+    with pytest.raises(NotImplementedError):          # an actor packed for observation rows
+        FusedActor.from_module(actor, layout=1).sample_env(env, 0, 0)
+    with pytest.raises(RuntimeError):                 # and the other way round
+        by_state.sample(env.obs_vector("rows").view(-1, 51), 0, 0)
+    with pytest.raises(ValueError):
+        FusedActor.from_module(__import__("mdr_amd.rollout", fromlist=["ActorMLP"]).ActorMLP(47).cuda(), feature_order=FEATURES_OBSERVE)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_collect_rollout_observe_act_vs_rows(precision):
+    """collect_ppo_rollout(store_states=False) takes the observe -> act path by itself; against the rows path the first step agrees
+    to rounding, the trajectories then differ only through the handful of agents whose draw sat between the two probabilities."""
+    import mdr_amd
+    from mdr_amd.rollout import collect_ppo_rollout
+    E, N, T = 16, 256, 12
+    cfg = _cfg(N)
+    actor = _actor(seed=3)
+    outs = []
+    for observe in (True, False, None):
+        env = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=4)
+        env.reset(episode=0)
+        outs.append(collect_ppo_rollout(env, actor, T, store_states=False, seed=11, policy_precision=precision, observe_act=observe))
+        assert env.steps_taken == T
+    a, b, c = outs
+    for k in ("action", "a_prob", "reward", "return"):
+        assert torch.equal(a[k], c[k]), k                      # None == True here: the default picks the fused path
+    tol = 3e-5 if precision == "bf16x3" else 3e-6
+    assert float((a["a_prob"][0] - b["a_prob"][0]).abs().max()) < tol or int((a["action"][0] != b["action"][0]).sum()) <= 2
+    assert float((a["action"] != b["action"]).float().mean()) < 2e-3
+    torch.testing.assert_close(a["reward"].mean(), b["reward"].mean(), rtol=1e-3, atol=1e-4)
+    with pytest.raises(ValueError):
+        collect_ppo_rollout(env, actor, 2, store_states=True, observe_act=True)
+
+
+def test_observe_act_in_a_replayed_graph():
+    """Graph mode: the fused kernel takes the table row of the regulation signal and its Philox step from the device cursor."""
+    import mdr_amd
+    from mdr_amd.policy import FEATURES_OBSERVE, FusedActor
+    E, N, T = 8, 64, 40
+    cfg = _cfg(N)
+    policy = FusedActor.from_module(_actor(seed=1), layout=2, feature_order=FEATURES_OBSERVE)
+    envs = [mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=2, table_steps=16, graph_mode=True) for _ in range(2)]
+    plain = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=2, table_steps=16)
+    acts = [torch.empty(E * N, dtype=torch.uint8, device="cuda:0") for _ in range(3)]
+    for e in envs + [plain]:
+        e.reset(episode=0)
+
+    def one(env, act):
+        policy.sample_env(env, 77, 0, action=act, step_dev=env.device_time_index)
+        env.step(act.view(E, N))
+
+    for t in range(T):
+        one(envs[0], acts[0])
+        policy.sample_env(plain, 77, t, action=acts[2])
+        plain.step(acts[2].view(E, N))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        one(envs[1], acts[1])
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        one(envs[1], acts[1])
+    done = 1
+    while done < T:
+        n = min(envs[1].graph_room(), T - done)
+        for _ in range(n):
+            g.replay()
+        envs[1].graph_replayed(n)
+        done += n
+    for k in ("Ta", "sso", "flags", "reward", "P"):
+        assert torch.equal(envs[0].t[k], plain.t[k]) and torch.equal(envs[1].t[k], plain.t[k]), k
+    assert torch.equal(acts[0], acts[2]) and torch.equal(acts[1], acts[2])
