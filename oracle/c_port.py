@@ -15,6 +15,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libmdr_oracle_c.so")
+SANITIZED = os.environ.get("MDR_ORACLE_C_SANITIZED", "") not in ("", "0")   # load the ASan + UBSan build (needs libasan preloaded)
 
 
 class _Cfg(C.Structure):
@@ -29,6 +30,9 @@ class _Buf(C.Structure):
 
 
 def build():
+    if SANITIZED:
+        subprocess.run(["make", "-s", "-C", HERE, "asan"], check=True)
+        return os.path.join(HERE, "libmdr_oracle_c_asan.so")
     if not os.path.isfile(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(HERE, "mdr_oracle_c.c")):
         subprocess.run(["make", "-s", "-C", HERE], check=True)
     return LIB
