@@ -242,17 +242,22 @@ def ppo_leg(rk: Ranks, env, args):
     E, N = env.nb_envs, env.nb_houses
     torch.manual_seed(0)
     actor = ActorMLP(env.obs_vector_length()).to(rk.device)
-    out = {"metric": "agent-steps/s, policy in the loop (observation -> actor -> sample -> env step)",
-           "workload": "%d envs x %d houses per GPU (the C3 batch), Actor %d-100-100-2 random init, transitions kept on the GPU "
-                       "(action, a_prob, reward; states not stored)" % (E, N, env.obs_vector_length()),
+    out = {"metric": "agent-steps/s, policy in the loop (normStateDict -> Actor forward -> Categorical.sample -> env step)",
+           "workload": "%d envs x %d houses per GPU (the C3 batch), Actor %d-100-100-2 random init; observation and policy are ONE kernel "
+                       "(mdr_env_actor_sample: the 51 features built in LDS from the compact state); transitions stay on the GPU: "
+                       "`transitions` = state (204 B/agent, written on the side by the same kernel) + action + a_prob + reward + return, "
+                       "`no_states` = the same without keeping the states" % (E, N, env.obs_vector_length()),
            "steps": args.ppo_steps, "n_gpus": rk.world, "scaling": "weak"}
     for prec in ("fp32", "bf16x3"):
-        collect_ppo_rollout(env, actor, 3, store_states=False, policy_precision=prec, seed=rk.rank)      # warm-up + packing
-        wall, ev_ms = timed(rk, lambda: collect_ppo_rollout(env, actor, args.ppo_steps, store_states=False,
-                                                             policy_precision=prec, seed=rk.rank), args.ppo_steps)
-        out[prec] = {"agent_steps_per_s": E * N * rk.world * args.ppo_steps / wall, "ms_per_step": wall / args.ppo_steps * 1e3,
-                     "event_ms_per_step_rank0": ev_ms}
-    out["value"] = out["fp32"]["agent_steps_per_s"]
+        out[prec] = {}
+        for key, keep in (("transitions", True), ("no_states", False)):
+            collect_ppo_rollout(env, actor, 3, store_states=keep, policy_precision=prec, seed=rk.rank)      # warm-up + packing
+            wall, ev_ms = timed(rk, lambda: collect_ppo_rollout(env, actor, args.ppo_steps, store_states=keep,
+                                                                 policy_precision=prec, seed=rk.rank), args.ppo_steps)
+            out[prec][key] = {"agent_steps_per_s": E * N * rk.world * args.ppo_steps / wall, "ms_per_step": wall / args.ppo_steps * 1e3,
+                              "event_ms_per_step_rank0": ev_ms}
+            torch.cuda.empty_cache()
+    out["value"] = out["fp32"]["transitions"]["agent_steps_per_s"]
     out["unit"] = "agent-steps/s"
     out["dtype"] = "f32 (exact fp32 MFMA); bf16x3 = split-bf16 operands, fp32 accumulate, probabilities within 2e-5"
     return out

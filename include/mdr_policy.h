@@ -90,9 +90,12 @@ int mdr_actor_sample(const mdr_actor_t *actor, const float *obs, int64_t obs_pla
  * `step_dev` as mdr_actor_sample (agent index = env * nb_houses + house).  Covers the reference's DEFAULT observation only - every
  * optional state / message column off, agents_comm_mode "neighbours" with nb_agents_comm = 10, no link defects (spec says which; 51
  * features) - with nb_houses a multiple of 32, unsharded houses, and an actor packed as MDR_ACTOR_FRAG16 or MDR_ACTOR_BF16X3 in
- * MDR_FEATURES_OBSERVE order; anything else returns MDR_ERR_UNSUPPORTED (-4): fall back to mdr_env_obs_vector + mdr_actor_sample. */
+ * MDR_FEATURES_OBSERVE order; anything else returns MDR_ERR_UNSUPPORTED (-4): fall back to mdr_env_obs_vector + mdr_actor_sample.
+ * `rows_out` (may be NULL; 16-byte aligned): the observation rows themselves, float [nb_agents][51] in normStateDict order - bit for
+ * bit what mdr_env_obs_vector(MDR_OBS_ROWS) writes - copied out of the staged window on the side, for callers that keep the `state` of
+ * every transition (train_ppo.py:87-98): the rows are then written once and never read back by the policy. */
 int mdr_env_actor_sample(mdr_env_t *env, const mdr_obs_spec_t *spec, const mdr_actor_t *actor, uint64_t seed, uint64_t step,
-                         const int32_t *step_dev, uint8_t *action, float *a_prob, float *probs, void *stream);
+                         const int32_t *step_dev, uint8_t *action, float *a_prob, float *probs, float *rows_out, void *stream);
 
 /* The Monte-Carlo return scan of PPO.update (agents/ppo.py:123-134) for every agent at once: backwards over t,
  * R <- reward[t] + gamma * (done[t] ? bootstrap[t] : R).  `reward`, `out` float [nb_steps][nb_agents]; `done` uint8 of that

@@ -188,7 +188,7 @@ def load():
         "mdr_actor_frag1_floats": (i64, [i32, i32]),
         "mdr_actor_frag2_floats": (i64, [i32, i32]),
         "mdr_actor_sample": (C.c_int, [vp, vp, i64, i64, u64, u64, vp, vp, vp, vp, vp]),
-        "mdr_env_actor_sample": (C.c_int, [vp, C.POINTER(MdrObsSpec), vp, u64, u64, vp, vp, vp, vp, vp]),
+        "mdr_env_actor_sample": (C.c_int, [vp, C.POINTER(MdrObsSpec), vp, u64, u64, vp, vp, vp, vp, vp, vp]),
         "mdr_discounted_returns": (C.c_int, [vp, vp, vp, C.c_float, i32, i64, vp, vp]),
         "mdr_env_pack": (C.c_int, [vp, i32, vp, vp]),
         "mdr_env_graph_room": (i64, [vp]),

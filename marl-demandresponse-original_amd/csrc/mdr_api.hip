@@ -824,7 +824,7 @@ int mdr_env_obs_vector_ext(mdr_env_t* env, const mdr_obs_spec_t* spec, const flo
 }
 
 int mdr_env_actor_sample(mdr_env_t* env, const mdr_obs_spec_t* spec, const mdr_actor_t* actor, uint64_t seed, uint64_t step,
-                         const int32_t* step_dev, uint8_t* action, float* a_prob, float* probs, void* stream) {
+                         const int32_t* step_dev, uint8_t* action, float* a_prob, float* probs, float* rows_out, void* stream) {
   if (!env || !spec || !actor || !action) return MDR_ERR_INVALID;
   if (env->cfg.nb_houses_total != env->cfg.nb_houses) return fail(env, MDR_ERR_UNSUPPORTED, "observe -> act needs unsharded houses");
   mdr::ObsArgs a;
@@ -841,7 +841,7 @@ int mdr_env_actor_sample(mdr_env_t* env, const mdr_obs_spec_t* spec, const mdr_a
   o.cursor = a.cursor; o.cursor_max = a.cursor_max;
   o.E = a.E; o.N = a.N;
   o.obs_tshift = a.obs_tshift; o.inv_norm_reg = a.inv_norm_reg; o.inv_cap = a.inv_cap; o.inv_obs_norm = a.inv_obs_norm;
-  rc = mdr::launch_actor_observe(actor, o, seed, step, step_dev, action, a_prob, probs, (hipStream_t)stream);
+  rc = mdr::launch_actor_observe(actor, o, seed, step, step_dev, action, a_prob, probs, rows_out, (hipStream_t)stream);
   if (rc == MDR_ERR_UNSUPPORTED) return fail(env, rc, "observe -> act: shape or actor layout without a kernel (nb_houses % 32, FRAG16 / BF16X3 in MDR_FEATURES_OBSERVE order)");
   if (rc != MDR_OK) return fail(env, rc, "actor_observe launch failed");
   return MDR_OK;

@@ -195,7 +195,7 @@ hipError_t launch_comm_draws(const ObsArgs& a, int32_t* senders, uint8_t* keep, 
 int obs_message_fields(const mdr_obs_spec_t& s);
 // the policy kernels of csrc/mdr_policy.hip on the compact state; actor / step_dev etc. as mdr_actor_sample
 int launch_actor_observe(const struct mdr_actor* actor, const ObserveArgs& o, uint64_t seed, uint64_t step, const int32_t* step_dev,
-                         uint8_t* action, float* a_prob, float* probs, hipStream_t s);
+                         uint8_t* action, float* a_prob, float* probs, float* rows_out, hipStream_t s);
 int obs_vector_length(const mdr_obs_spec_t& spec);
 hipError_t launch_step_begin_split(const StepArgs& a, bool reduce, hipStream_t s);
 hipError_t launch_step_end_split(const StepArgs& a, hipStream_t s);

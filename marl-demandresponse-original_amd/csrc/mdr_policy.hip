@@ -50,6 +50,7 @@ struct ActorArgs {
   uint32_t k0, k1, step_lo, step_hi;
   const int32_t* step_dev;   // optional: added to the step counter on the device (graph replays: the env's time index)
   int greedy;                // action = argmax instead of a draw (DQNAgent.act)
+  float* rows_out;           // observe -> act only, optional: the observation rows [A][51] in normStateDict order (the transition buffer's `state`)
 };
 
 // max(x, 0) in one instruction (v_med3_f32; fmaxf costs a canonicalising v_max_f32 x, x before the v_max_f32 x, 0)
@@ -497,6 +498,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) 
 // are staged between the k-steps of layer 2, read back before the head, so one window per wave suffices.
 // =================================================================================================================
 constexpr int OBS_HALO = 5, OBS_C = 10, OBS_ROW = 56, OBS_PAD = 16;   // floats; 56 = 40 + 11 + L + 1/L + 3 (16-byte rows)
+typedef float v4f_nt __attribute__((ext_vector_type(4)));
 
 struct HouseRegs {
   float Ta, Tm, tg, db, cap, pm;
@@ -553,6 +555,33 @@ __device__ __forceinline__ void observe_stage(const mdr::ObserveArgs& o, const H
   }
 }
 
+// Optional side product of observe -> act: the tile's observation rows, in normStateDict order, for the transition buffer
+// (train_ppo.py:87-98 stores `state` with every transition).  The window holds them already - in staging order and with the raw
+// seconds_since_off, which the gathering lanes replace by the quotient they computed - so the tile's TILE * 51 contiguous
+// output floats are copied out with 16-byte non-temporal stores through a source-offset table built once per workgroup
+// (output float o = 51 r + n  <-  window float OBS_ROW r + (n < 11 ? 40 + n : n - 11)).
+template <int TILE>
+__device__ __forceinline__ void observe_build_table(uint16_t* table, int tid, int nthreads) {
+  for (int o = tid; o < TILE * 51; o += nthreads) {
+    const int r = o / 51, n = o - 51 * r;
+    table[o] = (uint16_t)(OBS_ROW * r + (n < 11 ? 4 * OBS_C + n : n - 11));
+  }
+}
+
+template <int TILE>
+__device__ __forceinline__ void observe_store_rows(const float* rows, const uint16_t* table, float* out_tile, int lane) {
+  constexpr int QUADS = TILE * 51 / 4;   // 408 | 204
+#pragma unroll
+  for (int i = 0; i < (QUADS + 63) / 64; ++i) {
+    const int q = i * 64 + lane;
+    if (q < QUADS) {
+      const uint2 src = *reinterpret_cast<const uint2*>(table + 4 * q);   // four 16-bit window offsets
+      v4f_nt v = {rows[src.x & 0xFFFFu], rows[src.x >> 16], rows[src.y & 0xFFFFu], rows[src.y >> 16]};
+      __builtin_nontemporal_store(v, reinterpret_cast<v4f_nt*>(out_tile) + q);
+    }
+  }
+}
+
 // (env, first house) of a tile, advanced by a fixed stride without a division per tile
 struct TileCursor {
   int e, h0, de, dh, N;
@@ -574,7 +603,7 @@ struct TileCursor {
 };
 
 // ---- bf16x3 form: 32 agents per wavefront (two 16-agent column blocks), k-step s of layer 1 = row floats [32 s + 8 g, + 8)
-template <int MB>
+template <int MB, bool STORE>
 __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a, mdr::ObserveArgs o) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int S2B = (MB + 1) / 2, TILE = 16 * NCB, WIN = TILE * OBS_ROW + OBS_PAD;
@@ -583,6 +612,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
   float* wd = reinterpret_cast<float*>(f2 + S2B * 1024);        // head weights + biases (512 floats reserved)
   const int tid = threadIdx.x;
   float* rows = wd + 512 + (tid >> 6) * WIN;                    // this wave's window
+  uint16_t* table = reinterpret_cast<uint16_t*>(wd + 512 + WAVESB * WIN);   // [TILE * 51] (only when rows are stored)
   const uint4* g1 = reinterpret_cast<const uint4*>(a.frag1);
   const uint4* g2 = reinterpret_cast<const uint4*>(a.frag2);
   for (int i = tid; i < 2 * 1024; i += 64 * WAVESB) f1[i] = g1[i];
@@ -590,6 +620,8 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
   if (tid < 388) wd[tid] = a.wdiff[tid];
   const int lane = tid & 63;
   for (int i = lane; i < WIN; i += 64) rows[i] = 0.0f;          // pads are read (against zero weights): they must be finite
+  constexpr bool store = STORE;   // rows_out != nullptr (a compile-time variant: the plain form keeps its registers)
+  if (store) observe_build_table<TILE>(table, tid, 64 * WAVESB);
   __syncthreads();
 
   const int r = lane & 15, g = lane >> 4;
@@ -602,11 +634,12 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
   TileCursor tc;
   tc.init(wave * TILE, nwaves * TILE, o.N);
   float xr[NCB][16];
-  // the lane's 16 features of column block c: two runs of 8 floats of row c * 16 + r
-  auto gather = [&]() {
+  // the lane's 16 features of column block c: two runs of 8 floats of row c * 16 + r.  `first_agent`: the tile's first agent -
+  // with `store`, the quotients go back into the window and the wave copies the tile's rows out (observe_store_rows)
+  auto gather = [&](int64_t first_agent) {
 #pragma unroll
     for (int c = 0; c < NCB; ++c) {
-      const float* row = rows + (c * 16 + r) * OBS_ROW;
+      float* row = rows + (c * 16 + r) * OBS_ROW;
       const float L = row[4 * OBS_C + 11], y = row[4 * OBS_C + 12];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -621,14 +654,22 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
         xr[c][8 * s + 5] = msg ? mdr::div_by_lockout(v1.y, L, y) : v1.y;
         xr[c][8 * s + 6] = v1.z;
         xr[c][8 * s + 7] = v1.w;
+        if (store && msg) {
+          row[32 * s + 8 * g + 1] = xr[c][8 * s + 1];
+          row[32 * s + 8 * g + 5] = xr[c][8 * s + 5];
+        }
       }
+    }
+    if (store) {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      observe_store_rows<TILE>(rows, table, a.rows_out + first_agent * 51, lane);
     }
   };
   if (wave < a.ntiles) {
     const HouseRegs first = observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
     observe_stage<TILE>(o, first, rows, lane);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // compiler ordering only: LDS operations of one wave complete in issue order
-    gather();
+    gather(wave * TILE);
   }
   uint32_t rnd[NCB] = {};
   int it = 0;
@@ -708,7 +749,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
     }
     if (more) {   // LDS operations of one wave complete in order: the rows staged above are what these loads see
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // compiler ordering only: LDS operations of one wave complete in issue order
-      gather();
+      gather((t + nwaves) * TILE);
     }
     // ---- head
 #pragma unroll
@@ -742,7 +783,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
 }
 
 // ---- exact-fp32 form (v_mfma_f32_16x16x4_f32): 16 agents per wavefront, lane group g holds features [13 g, 13 g + 13) of its agent
-template <int MB>
+template <int MB, bool STORE>
 __global__ __launch_bounds__(64 * WAVES16) void k_actor_observe16(ActorArgs a, mdr::ObserveArgs o) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TILE = 16, WIN = TILE * OBS_ROW + OBS_PAD, S1 = 13;
@@ -751,11 +792,14 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_observe16(ActorArgs a, m
   float* wd = f2 + a.S2 * 512;           // head weights + biases (512 floats reserved)
   const int tid = threadIdx.x;
   float* rows = wd + 512 + (tid >> 6) * WIN;
+  uint16_t* table = reinterpret_cast<uint16_t*>(wd + 512 + WAVES16 * WIN);   // [TILE * 51] (only when rows are stored)
   for (int i = tid * 4; i < S1 * 512; i += 64 * WAVES16 * 4) *reinterpret_cast<float4*>(f1 + i) = *reinterpret_cast<const float4*>(a.frag1 + i);
   for (int i = tid * 4; i < a.S2 * 512; i += 64 * WAVES16 * 4) *reinterpret_cast<float4*>(f2 + i) = *reinterpret_cast<const float4*>(a.frag2 + i);
   if (tid < 388) wd[tid] = a.wdiff[tid];
   const int lane = tid & 63;
   for (int i = lane; i < WIN; i += 64) rows[i] = 0.0f;
+  constexpr bool store = STORE;   // rows_out != nullptr (a compile-time variant: the plain form keeps its registers)
+  if (store) observe_build_table<TILE>(table, tid, 64 * WAVES16);
   __syncthreads();
 
   const int r = lane & 15, g = lane >> 4;
@@ -775,20 +819,26 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_observe16(ActorArgs a, m
     if (k < 4 * OBS_C && (k & 3) == 1) sso_mask |= 1u << s;
   }
   float xr[16];
-  auto gather = [&]() {
-    const float* row = rows + r * OBS_ROW;
+  auto gather = [&](int64_t first_agent) {
+    float* row = rows + r * OBS_ROW;
     const float L = row[4 * OBS_C + 11], y = row[4 * OBS_C + 12];
 #pragma unroll
     for (int s = 0; s < S1; ++s) {
       const float v = row[S1 * g + s];
-      xr[s] = ((sso_mask >> s) & 1u) ? mdr::div_by_lockout(v, L, y) : v;
+      const bool fix = ((sso_mask >> s) & 1u) != 0u;
+      xr[s] = fix ? mdr::div_by_lockout(v, L, y) : v;
+      if (store && fix) row[S1 * g + s] = xr[s];
+    }
+    if (store) {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      observe_store_rows<TILE>(rows, table, a.rows_out + first_agent * 51, lane);
     }
   };
   if (wave < a.ntiles) {
     const HouseRegs first = observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
     observe_stage<TILE>(o, first, rows, lane);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // compiler ordering only: LDS operations of one wave complete in issue order
-    gather();
+    gather(wave * TILE);
   }
   uint32_t rnd = 0;
   int it = 0;
@@ -833,7 +883,7 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_observe16(ActorArgs a, m
     }
     if (more) {
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // compiler ordering only: LDS operations of one wave complete in issue order
-      gather();
+      gather((t + nwaves) * TILE);
     }
     // ---- head
     float d = 0.0f;
@@ -907,7 +957,7 @@ bool layout_ok(int layout) { return layout == MDR_ACTOR_FRAG32 || layout == MDR_
 namespace mdr {
 
 int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_t seed, uint64_t step, const int32_t* step_dev, uint8_t* action,
-                         float* a_prob, float* probs, hipStream_t stream) {
+                         float* a_prob, float* probs, float* rows_out, hipStream_t stream) {
   if (!actor || actor->struct_size != sizeof(mdr_actor_t) || !action) return MDR_ERR_INVALID;
   if (!actor->frag1 || !actor->frag2 || !actor->wdiff) return MDR_ERR_INVALID;
   const int layout = actor->layout;
@@ -920,6 +970,8 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
   ActorArgs a{};
   a.frag1 = static_cast<const float*>(actor->frag1); a.frag2 = static_cast<const float*>(actor->frag2); a.wdiff = actor->wdiff;
   a.action = action; a.a_prob = a_prob; a.probs = probs;
+  if (rows_out && ((uintptr_t)rows_out & 15u) != 0) return MDR_ERR_INVALID;   // 16-byte stores
+  a.rows_out = rows_out;
   a.A = (int64_t)o.E * o.N;
   a.ntiles = a.A / tile;
   a.F = actor->num_state; a.S1 = steps1(layout, actor->num_state); a.S2 = steps2(layout, actor->hidden1);
@@ -928,7 +980,8 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
   a.step_dev = step_dev;
   a.greedy = actor->greedy != 0;
   const size_t window = (size_t)tile * OBS_ROW + OBS_PAD;
-  const size_t lds_bytes = ((size_t)(a.S1 + a.S2) * floats_per_step(layout) + 512 + (size_t)waves * window) * sizeof(float);
+  const size_t lds_bytes = ((size_t)(a.S1 + a.S2) * floats_per_step(layout) + 512 + (size_t)waves * window) * sizeof(float) +
+                           (rows_out ? (size_t)tile * 51 * sizeof(uint16_t) : 0);
   if (lds_bytes > 160 * 1024) return MDR_ERR_UNSUPPORTED;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
@@ -941,8 +994,12 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
     return hipGetLastError() == hipSuccess ? MDR_OK : MDR_ERR_HIP;
   };
   const int mb = blocks16(actor->hidden1, actor->hidden2);
-  if (lbf) return mb == 7 ? launch(k_actor_observe_bf16<7>) : launch(k_actor_observe_bf16<8>);
-  return mb == 7 ? launch(k_actor_observe16<7>) : launch(k_actor_observe16<8>);
+  if (rows_out) {
+    if (lbf) return mb == 7 ? launch(k_actor_observe_bf16<7, true>) : launch(k_actor_observe_bf16<8, true>);
+    return mb == 7 ? launch(k_actor_observe16<7, true>) : launch(k_actor_observe16<8, true>);
+  }
+  if (lbf) return mb == 7 ? launch(k_actor_observe_bf16<7, false>) : launch(k_actor_observe_bf16<8, false>);
+  return mb == 7 ? launch(k_actor_observe16<7, false>) : launch(k_actor_observe16<8, false>);
 }
 
 }  // namespace mdr

@@ -172,12 +172,15 @@ class FusedActor:
                    feature_order=feature_order)
 
     def sample_env(self, env, seed: int, step: int, want_probs: bool = False, action: Optional[torch.Tensor] = None,
-                   a_prob: Optional[torch.Tensor] = None, step_dev: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, ...]:
+                   a_prob: Optional[torch.Tensor] = None, step_dev: Optional[torch.Tensor] = None,
+                   rows_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, ...]:
         """Observe -> act in ONE kernel (``mdr_env_actor_sample``): ``utils.normStateDict`` of every agent of ``env`` (a
         ``BatchedDemandResponseEnv`` in its current state) is built in LDS from the compact state and fed straight to the
         matrix-core forward - no observation rows.  Needs an actor packed with ``feature_order=FEATURES_OBSERVE`` (layout FRAG16
         or BF16X3), the default observation, ``nb_houses % 32 == 0``; raises ``NotImplementedError`` otherwise (use
-        ``env.obs_vector('rows')`` + ``sample``).  Same draws and outputs as ``sample`` on the rows (agent = env * N + house)."""
+        ``env.obs_vector('rows')`` + ``sample``).  Same draws and outputs as ``sample`` on the rows (agent = env * N + house).
+        ``rows_out`` (float32 [A, 51] contiguous): also receives the observation rows in normStateDict order - bit for bit
+        ``env.obs_vector('rows')`` - written on the side by the same kernel (the transition buffer's ``state``)."""
         A = env.nb_envs * env.nb_houses
         action = torch.empty(A, dtype=torch.uint8, device=self.device) if action is None else action
         a_prob = torch.empty(A, dtype=torch.float32, device=self.device) if a_prob is None else a_prob
@@ -185,11 +188,15 @@ class FusedActor:
         if step_dev is not None and (step_dev.dtype != torch.int32 or step_dev.device != self.device):
             raise ValueError("step_dev must be an int32 tensor on the device (env.device_time_index)")
         spec = env._obs_spec("rows")
+        if rows_out is not None and (rows_out.dtype != torch.float32 or rows_out.device != self.device or not rows_out.is_contiguous()
+                                     or rows_out.numel() != A * OBSERVE_NUM_STATE):
+            raise ValueError("rows_out must be a contiguous float32 [A, %d] tensor on the device" % OBSERVE_NUM_STATE)
         with torch.cuda.device(self.device):
             rc = self._lib.mdr_env_actor_sample(env._handle, C.byref(spec), C.byref(self._desc), C.c_uint64(seed & (2 ** 64 - 1)),
                                                 C.c_uint64(step & (2 ** 64 - 1)), C.c_void_p(step_dev.data_ptr()) if step_dev is not None else None,
                                                 C.c_void_p(action.data_ptr()), C.c_void_p(a_prob.data_ptr()),
                                                 C.c_void_p(probs.data_ptr()) if want_probs else None,
+                                                C.c_void_p(rows_out.data_ptr()) if rows_out is not None else None,
                                                 C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         if rc == nat.MDR_ERR_UNSUPPORTED:
             raise NotImplementedError("observe -> act: " + self._lib.mdr_last_error(env._handle).decode())

@@ -137,9 +137,10 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
     ``seed`` with the env's step counter in the counter; otherwise torch GEMMs + ``torch.multinomial``.
     ``policy_precision="bf16x3"`` runs the fused kernel on bf16 matrix instructions with every operand split into a
     bf16 head and tail (16 significand bits; probabilities within ~1e-5 of the fp32 forward) - about 2.7x faster.
-    ``observe_act`` (default: whenever the states are not stored and the shape allows it - the reference's default observation,
-    ``nb_houses % 32 == 0``): observation and policy are ONE kernel (``FusedActor.sample_env``): the 51 features of every agent
-    are built in LDS from the compact state, the 204-byte observation rows are neither written nor read.
+    ``observe_act`` (default: whenever the shape allows it - the reference's default observation, ``nb_houses % 32 == 0``):
+    observation and policy are ONE kernel (``FusedActor.sample_env``): the 51 features of every agent are built in LDS from the
+    compact state and fed to the matrix cores from there; with ``store_states`` the same kernel copies the rows into the
+    transition buffer on the side (written once, never read back by the policy), without it they are not materialised at all.
 
     Returns tensors with the agents flattened as [T, E*N, ...] in the reference's per-agent order:
     ``state`` [T+1, E*N, F] (``state[t+1]`` is ``next_state[t]``; omitted if ``store_states`` is False), ``action`` int64,
@@ -157,9 +158,9 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
     if fused is None:
         fused = generator is None and _fusable(actor)
     if observe_act is None:
-        observe_act = bool(fused) and not store_states and critic is None and _observe_act_supported(env, actor)
-    if observe_act and (store_states or not fused):
-        raise ValueError("observe_act needs the fused policy and store_states=False")
+        observe_act = bool(fused) and _observe_act_supported(env, actor)
+    if observe_act and not fused:
+        raise ValueError("observe_act needs the fused policy")
     if fused:
         policy = _fused_policy(actor, dev, policy_precision, observe=observe_act)
         act_u8 = torch.empty((T, E * N), dtype=torch.uint8, device=dev)
@@ -172,8 +173,8 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
     obs = None if observe_act else observe(0)
     step0 = env.steps_taken
     for t in range(T):
-        if observe_act:             # normStateDict + select_action for all agents in ONE kernel: no observation rows at all
-            policy.sample_env(env, seed, step0 + t, action=act_u8[t], a_prob=a_prob[t])
+        if observe_act:             # normStateDict + select_action for all agents in ONE kernel; `state` stored on the side if wanted
+            policy.sample_env(env, seed, step0 + t, action=act_u8[t], a_prob=a_prob[t], rows_out=states[t] if store_states else None)
             _, r, _, _ = env.step(act_u8[t].view(E, N))
         elif policy is not None:    # agents/ppo.py:68-75 for all agents: one kernel, action and a_prob written in place
             policy.sample(obs, seed, step0 + t, action=act_u8[t], a_prob=a_prob[t])
@@ -187,6 +188,8 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
         reward[t] = r.reshape(-1)
         if not observe_act:
             obs = observe(t + 1)
+    if observe_act and (store_states or critic is not None):
+        obs = observe(T)            # next_state of the last transition / the critic's bootstrap input
     if policy is not None:
         action.copy_(act_u8)        # one widening pass at the end (the reference stores Categorical's int64)
     done = torch.zeros((T, E * N), dtype=torch.bool, device=dev)

@@ -68,6 +68,11 @@ def test_observe_act_equals_rows_then_actor(E, N, layout, layers):
             torch.testing.assert_close(probs1, ref, rtol=1e-5, atol=2e-6)
             torch.testing.assert_close(probs1, probs0, rtol=1e-5, atol=2e-6)
         assert torch.equal(p1, probs1.gather(1, a1.long()[:, None]).squeeze(1))
+        # the rows written on the side are the rows of mdr_env_obs_vector, bit for bit, and storing them changes nothing else
+        kept = torch.full((E * N, 51), float("nan"), device="cuda:0")
+        a2, p2, probs2 = by_state.sample_env(env, seed=9, step=k, want_probs=True, rows_out=kept)
+        assert torch.equal(kept, rows), "rows_out differs from obs_vector('rows')"
+        assert torch.equal(a2, a1) and torch.equal(probs2, probs1)
         # same Philox draw per agent: the actions differ only where u falls between the two (nearly equal) probabilities
         differ = a0 != a1
         assert int(differ.sum()) <= max(2, E * N // 20000)
@@ -121,8 +126,18 @@ def test_collect_rollout_observe_act_vs_rows(precision):
     assert float((a["a_prob"][0] - b["a_prob"][0]).abs().max()) < tol or int((a["action"][0] != b["action"][0]).sum()) <= 2
     assert float((a["action"] != b["action"]).float().mean()) < 2e-3
     torch.testing.assert_close(a["reward"].mean(), b["reward"].mean(), rtol=1e-3, atol=1e-4)
-    with pytest.raises(ValueError):
-        collect_ppo_rollout(env, actor, 2, store_states=True, observe_act=True)
+    # with the states kept: the transition buffer's `state` is what the rows kernel would have written at every step of ITS trajectory
+    env = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=4)
+    env.reset(episode=0)
+    kept = collect_ppo_rollout(env, actor, T, store_states=True, seed=11, policy_precision=precision)      # observe -> act + rows on the side
+    for k in ("action", "a_prob", "reward", "return"):
+        assert torch.equal(kept[k], a[k]), k
+    replay = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=4)
+    replay.reset(episode=0)
+    for s in range(T):
+        assert torch.equal(kept["state"][s], replay.obs_vector("rows").view(E * N, 51)), s
+        replay.step(kept["action"][s].to(torch.uint8).view(E, N))
+    assert torch.equal(kept["state"][T], replay.obs_vector("rows").view(E * N, 51))
 
 
 def test_observe_act_in_a_replayed_graph():

@@ -51,12 +51,16 @@ def main():
             by_state = FusedActor.from_module(actor, layout=layout, feature_order=FEATURES_OBSERVE)
             out["actor_on_rows_%s_us" % name] = round(timeit(lambda: by_rows.sample(rows, 1, 2), args.steps), 1)
             out["observe_act_%s_us" % name] = round(timeit(lambda: by_state.sample_env(env, 1, 2), args.steps), 1)
-            for key, observe in (("rows", False), ("observe_act", True)):
-                collect_ppo_rollout(env, actor, 3, store_states=False, policy_precision=name, observe_act=observe)
-                us = [timeit(lambda: collect_ppo_rollout(env, actor, args.steps, store_states=False, policy_precision=name, observe_act=observe), 1, warm=0) / args.steps
+            kept = torch.empty((E * N, 51), device="cuda:0")
+            out["observe_act_store_rows_%s_us" % name] = round(timeit(lambda: by_state.sample_env(env, 1, 2, rows_out=kept), args.steps), 1)
+            del kept
+            for key, observe, keep in (("rows", False, False), ("observe_act", True, False), ("rows_states_kept", False, True),
+                                       ("observe_act_states_kept", True, True)):
+                collect_ppo_rollout(env, actor, 3, store_states=keep, policy_precision=name, observe_act=observe)
+                us = [timeit(lambda: collect_ppo_rollout(env, actor, args.steps, store_states=keep, policy_precision=name, observe_act=observe), 1, warm=0) / args.steps
                       for _ in range(3)]
                 out["rollout_step_%s_%s_us" % (key, name)] = round(min(us), 1)
-                out["rollout_step_%s_%s_us_all" % (key, name)] = [round(u, 1) for u in us]
+                torch.cuda.empty_cache()
         print(json.dumps(out), flush=True)
         del env
         torch.cuda.empty_cache()
