@@ -111,7 +111,7 @@ def traffic_from_profiles():
     """HBM bytes per launch of the step kernel from the newest committed PMC passes (profiles/*traffic*.json), or None.
     A constant read from the profile directory, not a measurement of this run (PMC passes need rocprofv3 around the process)."""
     best, src = None, None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json"))):   # the C3 passes of the newest round
         try:
             with open(path) as f:
                 best, src = json.load(f), os.path.relpath(path, ROOT)
