@@ -89,9 +89,11 @@ int mdr_actor_sample(const mdr_actor_t *actor, const float *obs, int64_t obs_pla
  * records, the very arithmetic of mdr_env_obs_vector), and the matrix-core forward reads its B operand from there.  Draws, outputs and
  * `step_dev` as mdr_actor_sample (agent index = env * nb_houses + house).  Covers the reference's DEFAULT observation only - every
  * optional state / message column off, agents_comm_mode "neighbours" with nb_agents_comm = 10, no link defects (spec says which; 51
- * features) - with nb_houses a multiple of 32, unsharded houses, and an actor packed as MDR_ACTOR_FRAG16 or MDR_ACTOR_BF16X3 in
+ * features, hence nb_houses >= 11) - with unsharded houses and an actor packed as MDR_ACTOR_FRAG16 or MDR_ACTOR_BF16X3 in
  * MDR_FEATURES_OBSERVE order; anything else returns MDR_ERR_UNSUPPORTED (-4): fall back to mdr_env_obs_vector + mdr_actor_sample.
- * `rows_out` (may be NULL; 16-byte aligned): the observation rows themselves, float [nb_agents][51] in normStateDict order - bit for
+ * Any cluster size: tiles of 32 (16) consecutive agents may start anywhere in an env and span several (the reference trains with 20
+ * houses and deploys with 50); nb_houses % 32 == 0 takes a leaner staging path.
+ * `rows_out` (may be NULL; 16-byte aligned for the wide-store path, else 4-byte stores): the observation rows themselves, float [nb_agents][51] in normStateDict order - bit for
  * bit what mdr_env_obs_vector(MDR_OBS_ROWS) writes - copied out of the staged window on the side, for callers that keep the `state` of
  * every transition (train_ppo.py:87-98): the rows are then written once and never read back by the policy. */
 int mdr_env_actor_sample(mdr_env_t *env, const mdr_obs_spec_t *spec, const mdr_actor_t *actor, uint64_t seed, uint64_t step,

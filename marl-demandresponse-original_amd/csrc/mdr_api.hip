@@ -842,7 +842,7 @@ int mdr_env_actor_sample(mdr_env_t* env, const mdr_obs_spec_t* spec, const mdr_a
   o.E = a.E; o.N = a.N;
   o.obs_tshift = a.obs_tshift; o.inv_norm_reg = a.inv_norm_reg; o.inv_cap = a.inv_cap; o.inv_obs_norm = a.inv_obs_norm;
   rc = mdr::launch_actor_observe(actor, o, seed, step, step_dev, action, a_prob, probs, rows_out, (hipStream_t)stream);
-  if (rc == MDR_ERR_UNSUPPORTED) return fail(env, rc, "observe -> act: shape or actor layout without a kernel (nb_houses % 32, FRAG16 / BF16X3 in MDR_FEATURES_OBSERVE order)");
+  if (rc == MDR_ERR_UNSUPPORTED) return fail(env, rc, "observe -> act: shape or actor layout without a kernel (nb_houses >= 11, FRAG16 / BF16X3 in MDR_FEATURES_OBSERVE order)");
   if (rc != MDR_OK) return fail(env, rc, "actor_observe launch failed");
   return MDR_OK;
 }

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "../../include/mdr.h"
 #include "../../include/mdr_policy.h"
@@ -292,9 +293,15 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
 // i.e. register [2 s + (j >> 2)][j & 3] of the lane itself - again no LDS and no lane movement for the activations.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {   // (bf16(hi) << 16) | bf16(lo), round to nearest even
+// (bf16(hi) << 16) | bf16(lo), round to nearest even.  Inline assembly is opaque to hipcc's hazard recogniser: a VGPR written here and
+// read as an MFMA operand by the very next instruction needs two wait states that nobody else inserts (round 1 shipped this
+// statement without them; the stale-operand reads surfaced when a new kernel variant changed the instruction schedule:
+// half the agents of the second column block came out with garbage logits).  Hence the `s_nop 1` INSIDE the string.  The
+// plain vector conversion (__builtin_convertvector to bf16x2) is hazard-safe too and selects the same instruction, but lets the
+// scheduler hoist the conversions until k_actor_sample_bf16 spills (1.1 KB of scratch per lane, 6x slower).
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
 }
 
@@ -500,6 +507,12 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) 
 constexpr int OBS_HALO = 5, OBS_C = 10, OBS_ROW = 56, OBS_PAD = 16;   // floats; 56 = 40 + 11 + L + 1/L + 3 (16-byte rows)
 typedef float v4f_nt __attribute__((ext_vector_type(4)));
 
+// between a wave's window stores and its loads of what OTHER lanes stored
+__device__ __forceinline__ void observe_window_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 struct HouseRegs {
   float Ta, Tm, tg, db, cap, pm;
   int sso, lk;
@@ -555,6 +568,83 @@ __device__ __forceinline__ void observe_stage(const mdr::ObserveArgs& o, const H
   }
 }
 
+// ---- any cluster size (N >= 11): a tile of TILE consecutive agents may start anywhere in an env and span several (the reference
+// trains with 20 houses and deploys with 50).  The tile is cut into per-env segments; a segment of `len` houses [hs, hs + len)
+// stages the window of houses hs - 5 .. hs + len + 4 (circular) - or the whole env when that wraps onto itself (len + 10 >= N).
+// Windows are laid out one after the other over the lanes (at most 52 lanes for TILE = 32, 36 for TILE = 16: checked for every
+// N and tile start); a staging lane keeps (house, segment bounds, first tile row of the segment) with its loaded values.
+struct SegSlot {
+  int j, hs, len, rb;   // this lane's house in its segment's env; the segment's receivers [hs, hs + len) = tile rows [rb, rb + len)
+  bool live;
+};
+
+template <int TILE>
+__device__ __forceinline__ HouseRegs observe_load_gen(const mdr::ObserveArgs& o, const double* sig_row, int e0, int h0, int64_t a0, int64_t A,
+                                                      int lane, SegSlot& slot) {
+  HouseRegs r{};
+  slot = SegSlot{0, 0, 0, 0, false};
+  // the segment walk is wave-uniform: keep it on the scalar unit (the tile index comes out of threadIdx, which the compiler
+  // cannot see is uniform across the wave)
+  int rem = __builtin_amdgcn_readfirstlane((int)((A - a0) < (int64_t)TILE ? (A - a0) : (int64_t)TILE));
+  int e = __builtin_amdgcn_readfirstlane(e0), hs = __builtin_amdgcn_readfirstlane(h0), wb = 0, rb = 0, my_e = 0;
+#pragma unroll 1
+  while (rem > 0) {                          // at most 4 segments
+    const int len = min(o.N - hs, rem);
+    const bool whole = len + 2 * OBS_HALO >= o.N;
+    const int start = whole ? 0 : (hs - OBS_HALO + o.N) % o.N;
+    const int wlen = whole ? o.N : len + 2 * OBS_HALO;
+    if (lane >= wb && lane < wb + wlen) {
+      int j = start + (lane - wb);
+      j -= j >= o.N ? o.N : 0;
+      slot = SegSlot{j, hs, len, rb, true};
+      my_e = e;
+    }
+    wb += wlen;
+    rb += len;
+    rem -= len;
+    hs = 0;
+    e += 1;
+  }
+  if (slot.live) {
+    const int64_t i = (int64_t)my_e * o.N + slot.j;
+    r.Ta = o.Ta[i];
+    r.Tm = o.Tm[i];
+    r.tg = o.target[i];
+    r.db = o.deadband[i];
+    r.cap = o.capacity[i];
+    r.pm = o.P_max[i];
+    r.sso = o.sso[i];
+    r.lk = o.lockout[i];
+    r.fl = o.flags[i];
+    r.sig = (float)(sig_row[my_e] * o.inv_obs_norm);
+    r.pw = (float)(o.P[my_e] * o.inv_obs_norm);
+  }
+  return r;
+}
+
+__device__ __forceinline__ void observe_stage_gen(const mdr::ObserveArgs& o, const HouseRegs& r, const SegSlot& slot, float* rows) {
+  if (!slot.live) return;
+  const float4 rec = make_float4((r.Ta - r.tg) * 0.2f, (float)r.sso, ((r.fl & 1u) ? r.pm : 0.0f) * o.inv_norm_reg, r.pm * o.inv_norm_reg);
+#pragma unroll
+  for (int m = 0; m < OBS_C; ++m) {
+    const int off = m < OBS_HALO ? m - OBS_HALO : m - OBS_HALO + 1;   // slot m listens to house h + off (env 816-828)
+    int h = slot.j - off;                                            // ... so this house is slot m of house j - off
+    h += h < 0 ? o.N : 0;
+    h -= h >= o.N ? o.N : 0;
+    const int k = h - slot.hs;
+    if (k >= 0 && k < slot.len) *reinterpret_cast<float4*>(rows + (slot.rb + k) * OBS_ROW + 4 * m) = rec;
+  }
+  const int k = slot.j - slot.hs;
+  if (k >= 0 && k < slot.len) {
+    const float L = (float)r.lk;
+    float* own = rows + (slot.rb + k) * OBS_ROW + 4 * OBS_C;
+    *reinterpret_cast<float4*>(own) = make_float4((r.Ta + o.obs_tshift) * 0.2f, (r.Tm + o.obs_tshift) * 0.2f, (r.tg + o.obs_tshift) * 0.2f, r.db);
+    *reinterpret_cast<float4*>(own + 4) = make_float4(r.cap * o.inv_cap, (r.fl & 1u) ? 1.0f : 0.0f, (r.fl & 2u) ? 1.0f : 0.0f, (float)r.sso / L);
+    *reinterpret_cast<float4*>(own + 8) = make_float4(L / L, r.sig, r.pw, L);
+    own[12] = 1.0f / L;
+  }
+}
+
 // Optional side product of observe -> act: the tile's observation rows, in normStateDict order, for the transition buffer
 // (train_ppo.py:87-98 stores `state` with every transition).  The window holds them already - in staging order and with the raw
 // seconds_since_off, which the gathering lanes replace by the quotient they computed - so the tile's TILE * 51 contiguous
@@ -569,12 +659,18 @@ __device__ __forceinline__ void observe_build_table(uint16_t* table, int tid, in
 }
 
 template <int TILE>
-__device__ __forceinline__ void observe_store_rows(const float* rows, const uint16_t* table, float* out_tile, int lane) {
+__device__ __forceinline__ void observe_store_rows(const float* rows, const uint16_t* table, float* out_tile, int lane, int nrows = TILE) {
   constexpr int QUADS = TILE * 51 / 4;   // 408 | 204
+  if (((uintptr_t)out_tile & 15u) != 0) {   // a transition buffer whose per-step slice is not 16-byte aligned (A * 51 % 4 != 0): 4-byte stores
+    for (int i = lane; i < nrows * 51; i += 64) __builtin_nontemporal_store(rows[table[i]], out_tile + i);
+    return;
+  }
+  const int quads = nrows * 51 / 4;      // the last tile of a batch may hold fewer agents (51 nrows need not be a multiple of 4)
+  if (lane < nrows * 51 - 4 * quads) out_tile[4 * quads + lane] = rows[table[4 * quads + lane]];
 #pragma unroll
   for (int i = 0; i < (QUADS + 63) / 64; ++i) {
     const int q = i * 64 + lane;
-    if (q < QUADS) {
+    if (q < quads) {
       const uint2 src = *reinterpret_cast<const uint2*>(table + 4 * q);   // four 16-bit window offsets
       v4f_nt v = {rows[src.x & 0xFFFFu], rows[src.x >> 16], rows[src.y & 0xFFFFu], rows[src.y >> 16]};
       __builtin_nontemporal_store(v, reinterpret_cast<v4f_nt*>(out_tile) + q);
@@ -603,7 +699,7 @@ struct TileCursor {
 };
 
 // ---- bf16x3 form: 32 agents per wavefront (two 16-agent column blocks), k-step s of layer 1 = row floats [32 s + 8 g, + 8)
-template <int MB, bool STORE>
+template <int MB, bool STORE, bool GEN>
 __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a, mdr::ObserveArgs o) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int S2B = (MB + 1) / 2, TILE = 16 * NCB, WIN = TILE * OBS_ROW + OBS_PAD;
@@ -662,13 +758,20 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
     }
     if (store) {
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      observe_store_rows<TILE>(rows, table, a.rows_out + first_agent * 51, lane);
+      observe_store_rows<TILE>(rows, table, a.rows_out + first_agent * 51, lane,
+                               GEN ? (int)((a.A - first_agent) < (int64_t)TILE ? (a.A - first_agent) : (int64_t)TILE) : TILE);
     }
   };
+  SegSlot slot{};
   if (wave < a.ntiles) {
-    const HouseRegs first = observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
-    observe_stage<TILE>(o, first, rows, lane);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // compiler ordering only: LDS operations of one wave complete in issue order
+    if (GEN) {
+      const HouseRegs first = observe_load_gen<TILE>(o, sig_row, tc.e, tc.h0, wave * TILE, a.A, lane, slot);
+      observe_stage_gen(o, first, slot, rows);
+    } else {
+      const HouseRegs first = observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
+      observe_stage<TILE>(o, first, rows, lane);
+    }
+    observe_window_fence();
     gather(wave * TILE);
   }
   uint32_t rnd[NCB] = {};
@@ -686,7 +789,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
     const bool more = t + nwaves < a.ntiles;
     tc.next();
     HouseRegs nxt{};
-    if (more) nxt = observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
+    if (more) nxt = GEN ? observe_load_gen<TILE>(o, sig_row, tc.e, tc.h0, (t + nwaves) * TILE, a.A, lane, slot) : observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
     f32x4 acc[NCB][MB];
 #pragma unroll
     for (int c = 0; c < NCB; ++c)
@@ -723,7 +826,10 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
       for (int mb = 0; mb < MB; ++mb) out[c][mb] = bias2[mb * 4];
 #pragma unroll
     for (int s = 0; s < S2B; ++s) {
-      if (s == 1 && more) observe_stage<TILE>(o, nxt, rows, lane);
+      if (s == 1 && more) {
+        if (GEN) observe_stage_gen(o, nxt, slot, rows);
+        else observe_stage<TILE>(o, nxt, rows, lane);
+      }
       bf16x8 Bh[NCB], Bl[NCB];
 #pragma unroll
       for (int c = 0; c < NCB; ++c) {
@@ -748,7 +854,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
       }
     }
     if (more) {   // LDS operations of one wave complete in order: the rows staged above are what these loads see
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // compiler ordering only: LDS operations of one wave complete in issue order
+      observe_window_fence();
       gather((t + nwaves) * TILE);
     }
     // ---- head
@@ -783,7 +889,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
 }
 
 // ---- exact-fp32 form (v_mfma_f32_16x16x4_f32): 16 agents per wavefront, lane group g holds features [13 g, 13 g + 13) of its agent
-template <int MB, bool STORE>
+template <int MB, bool STORE, bool GEN>
 __global__ __launch_bounds__(64 * WAVES16) void k_actor_observe16(ActorArgs a, mdr::ObserveArgs o) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TILE = 16, WIN = TILE * OBS_ROW + OBS_PAD, S1 = 13;
@@ -831,13 +937,20 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_observe16(ActorArgs a, m
     }
     if (store) {
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      observe_store_rows<TILE>(rows, table, a.rows_out + first_agent * 51, lane);
+      observe_store_rows<TILE>(rows, table, a.rows_out + first_agent * 51, lane,
+                               GEN ? (int)((a.A - first_agent) < (int64_t)TILE ? (a.A - first_agent) : (int64_t)TILE) : TILE);
     }
   };
+  SegSlot slot{};
   if (wave < a.ntiles) {
-    const HouseRegs first = observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
-    observe_stage<TILE>(o, first, rows, lane);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // compiler ordering only: LDS operations of one wave complete in issue order
+    if (GEN) {
+      const HouseRegs first = observe_load_gen<TILE>(o, sig_row, tc.e, tc.h0, wave * TILE, a.A, lane, slot);
+      observe_stage_gen(o, first, slot, rows);
+    } else {
+      const HouseRegs first = observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
+      observe_stage<TILE>(o, first, rows, lane);
+    }
+    observe_window_fence();
     gather(wave * TILE);
   }
   uint32_t rnd = 0;
@@ -852,7 +965,7 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_observe16(ActorArgs a, m
     const bool more = t + nwaves < a.ntiles;
     tc.next();
     HouseRegs nxt{};
-    if (more) nxt = observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
+    if (more) nxt = GEN ? observe_load_gen<TILE>(o, sig_row, tc.e, tc.h0, (t + nwaves) * TILE, a.A, lane, slot) : observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
     f32x4 acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[mb] = bias1[mb * 4];
@@ -871,7 +984,10 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_observe16(ActorArgs a, m
     for (int mb = 0; mb < MB; ++mb) out[mb] = bias2[mb * 4];
 #pragma unroll
     for (int q = 0; q < 4 * MB; ++q) {
-      if (q == 8 && more) observe_stage<TILE>(o, nxt, rows, lane);
+      if (q == 8 && more) {
+        if (GEN) observe_stage_gen(o, nxt, slot, rows);
+        else observe_stage<TILE>(o, nxt, rows, lane);
+      }
       if (q < a.S2) {
         const float b = relu(acc[q >> 2][q & 3]);
         const float4 w0 = *reinterpret_cast<const float4*>(f2 + q * 512 + lane * 8);
@@ -882,7 +998,7 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_observe16(ActorArgs a, m
       }
     }
     if (more) {
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // compiler ordering only: LDS operations of one wave complete in issue order
+      observe_window_fence();
       gather((t + nwaves) * TILE);
     }
     // ---- head
@@ -966,14 +1082,16 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
   if (actor->hidden1 <= 0 || actor->hidden2 <= 0 || actor->hidden1 > MDR_ACTOR_MAX_HIDDEN || actor->hidden2 > MDR_ACTOR_MAX_HIDDEN) return MDR_ERR_INVALID;
   const bool lbf = layout == MDR_ACTOR_BF16X3;
   const int tile = lbf ? 16 * NCB : 16, waves = lbf ? WAVESB : WAVES16;
-  if (o.N < 32 || o.N % 32 != 0) return MDR_ERR_UNSUPPORTED;   // a tile never spans two envs, the 5 + 5 neighbours wrap at most once
+  if (o.N < OBS_C + 1) return MDR_ERR_UNSUPPORTED;   // 10 distinct circular neighbours
+  static const bool force_gen = [] { const char* t = getenv("MDR_OBSERVE_GEN"); return t && t[0] == '1'; }();   // experiment knob
+  const bool gen = o.N % 32 != 0 || force_gen;     // tiles that start anywhere in an env / span several: the general staging
   ActorArgs a{};
   a.frag1 = static_cast<const float*>(actor->frag1); a.frag2 = static_cast<const float*>(actor->frag2); a.wdiff = actor->wdiff;
   a.action = action; a.a_prob = a_prob; a.probs = probs;
-  if (rows_out && ((uintptr_t)rows_out & 15u) != 0) return MDR_ERR_INVALID;   // 16-byte stores
+  if (rows_out && ((uintptr_t)rows_out & 3u) != 0) return MDR_ERR_INVALID;
   a.rows_out = rows_out;
   a.A = (int64_t)o.E * o.N;
-  a.ntiles = a.A / tile;
+  a.ntiles = (a.A + tile - 1) / tile;
   a.F = actor->num_state; a.S1 = steps1(layout, actor->num_state); a.S2 = steps2(layout, actor->hidden1);
   a.k0 = (uint32_t)(seed & 0xFFFFFFFFull); a.k1 = (uint32_t)(seed >> 32);
   a.step_lo = (uint32_t)(step & 0xFFFFFFFFull); a.step_hi = (uint32_t)(step >> 32);
@@ -994,12 +1112,12 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
     return hipGetLastError() == hipSuccess ? MDR_OK : MDR_ERR_HIP;
   };
   const int mb = blocks16(actor->hidden1, actor->hidden2);
-  if (rows_out) {
-    if (lbf) return mb == 7 ? launch(k_actor_observe_bf16<7, true>) : launch(k_actor_observe_bf16<8, true>);
-    return mb == 7 ? launch(k_actor_observe16<7, true>) : launch(k_actor_observe16<8, true>);
-  }
-  if (lbf) return mb == 7 ? launch(k_actor_observe_bf16<7, false>) : launch(k_actor_observe_bf16<8, false>);
-  return mb == 7 ? launch(k_actor_observe16<7, false>) : launch(k_actor_observe16<8, false>);
+#define MDR_OBSERVE_VARIANT(KERNEL, MBV)                                                     \
+  (rows_out ? (gen ? launch(KERNEL<MBV, true, true>) : launch(KERNEL<MBV, true, false>))   \
+            : (gen ? launch(KERNEL<MBV, false, true>) : launch(KERNEL<MBV, false, false>)))
+  if (lbf) return mb == 7 ? MDR_OBSERVE_VARIANT(k_actor_observe_bf16, 7) : MDR_OBSERVE_VARIANT(k_actor_observe_bf16, 8);
+  return mb == 7 ? MDR_OBSERVE_VARIANT(k_actor_observe16, 7) : MDR_OBSERVE_VARIANT(k_actor_observe16, 8);
+#undef MDR_OBSERVE_VARIANT
 }
 
 }  // namespace mdr

@@ -177,7 +177,7 @@ class FusedActor:
         """Observe -> act in ONE kernel (``mdr_env_actor_sample``): ``utils.normStateDict`` of every agent of ``env`` (a
         ``BatchedDemandResponseEnv`` in its current state) is built in LDS from the compact state and fed straight to the
         matrix-core forward - no observation rows.  Needs an actor packed with ``feature_order=FEATURES_OBSERVE`` (layout FRAG16
-        or BF16X3), the default observation, ``nb_houses % 32 == 0``; raises ``NotImplementedError`` otherwise (use
+        or BF16X3) and the default observation (51 features); raises ``NotImplementedError`` otherwise (use
         ``env.obs_vector('rows')`` + ``sample``).  Same draws and outputs as ``sample`` on the rows (agent = env * N + house).
         ``rows_out`` (float32 [A, 51] contiguous): also receives the observation rows in normStateDict order - bit for bit
         ``env.obs_vector('rows')`` - written on the side by the same kernel (the transition buffer's ``state``)."""

@@ -89,10 +89,10 @@ def _fused_policy(actor, dev, precision: str = "fp32", observe: bool = False):
 
 def _observe_act_supported(env, actor) -> bool:
     """Can ``FusedActor.sample_env`` serve this env / actor?  (default observation = 51 features with 10 circular neighbours and
-    no link defects, nb_houses a multiple of 32, unsharded houses)"""
+    no link defects - hence at least 11 houses - and unsharded houses)"""
     from .policy import OBSERVE_NUM_STATE
     cluster = env.config["default_env_prop"]["cluster_prop"]
-    return (not env.sharded and env.nb_houses % 32 == 0 and env.nb_houses >= 32 and actor.fc[0].in_features == OBSERVE_NUM_STATE
+    return (not env.sharded and env.nb_houses >= 11 and actor.fc[0].in_features == OBSERVE_NUM_STATE
             and env.obs_vector_length() == OBSERVE_NUM_STATE and cluster["agents_comm_mode"] == "neighbours"
             and not getattr(env, "_links_forced", False) and float(cluster["comm_defect_prob"]) == 0.0)
 
@@ -137,7 +137,7 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
     ``seed`` with the env's step counter in the counter; otherwise torch GEMMs + ``torch.multinomial``.
     ``policy_precision="bf16x3"`` runs the fused kernel on bf16 matrix instructions with every operand split into a
     bf16 head and tail (16 significand bits; probabilities within ~1e-5 of the fp32 forward) - about 2.7x faster.
-    ``observe_act`` (default: whenever the shape allows it - the reference's default observation, ``nb_houses % 32 == 0``):
+    ``observe_act`` (default: whenever the observation is the reference's default one - 51 features, 10 circular neighbours):
     observation and policy are ONE kernel (``FusedActor.sample_env``): the 51 features of every agent are built in LDS from the
     compact state and fed to the matrix cores from there; with ``store_states`` the same kernel copies the rows into the
     transition buffer on the side (written once, never read back by the policy), without it they are not materialised at all.

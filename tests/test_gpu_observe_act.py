@@ -45,7 +45,9 @@ def _walk(env, steps, seed):
         env.step((torch.rand((env.nb_envs, env.nb_houses), generator=g) < 0.5).to(torch.uint8).cuda())
 
 
-@pytest.mark.parametrize("E,N", [(3, 32), (5, 64), (2, 1024), (33, 96), (1, 4096), (700, 160)])
+@pytest.mark.parametrize("E,N", [(3, 32), (5, 64), (2, 1024), (33, 96), (1, 4096), (700, 160),
+                                 # any cluster size: tiles that start inside an env, span up to four envs, end in a partial tile
+                                 (100, 20), (37, 50), (5, 11), (3, 33), (9, 100), (1, 1000), (7, 31), (64, 12), (2, 4100), (1, 13)])
 @pytest.mark.parametrize("layout,layers", [(1, (100, 100)), (2, (100, 100)), (1, (127, 120)), (2, (64, 32))])
 def test_observe_act_equals_rows_then_actor(E, N, layout, layers):
     import mdr_amd
@@ -86,7 +88,7 @@ def test_observe_act_refuses_what_it_does_not_cover():
     from mdr_amd.policy import FEATURES_OBSERVE, FusedActor
     actor = _actor()
     by_state = FusedActor.from_module(actor, layout=1, feature_order=FEATURES_OBSERVE)
-    env = mdr_amd.BatchedDemandResponseEnv(_cfg(50), nb_envs=4, device="cuda:0", seed=1)          # N % 32 != 0
+    env = mdr_amd.BatchedDemandResponseEnv(_cfg(10), nb_envs=4, device="cuda:0", seed=1)          # 9 neighbours: not the 51-feature vector
     env.reset(episode=0)
     with pytest.raises(NotImplementedError):
         by_state.sample_env(env, 0, 0)
@@ -110,7 +112,7 @@ def test_collect_rollout_observe_act_vs_rows(precision):
     to rounding, the trajectories then differ only through the handful of agents whose draw sat between the two probabilities."""
     import mdr_amd
     from mdr_amd.rollout import collect_ppo_rollout
-    E, N, T = 16, 256, 12
+    E, N, T = (16, 256, 12) if precision == "fp32" else (81, 50, 12)       # 50 houses: the general staging path
     cfg = _cfg(N)
     actor = _actor(seed=3)
     outs = []
@@ -179,3 +181,34 @@ def test_observe_act_in_a_replayed_graph():
     for k in ("Ta", "sso", "flags", "reward", "P"):
         assert torch.equal(envs[0].t[k], plain.t[k]) and torch.equal(envs[1].t[k], plain.t[k]), k
     assert torch.equal(acts[0], acts[2]) and torch.equal(acts[1], acts[2])
+
+
+def test_general_staging_equals_the_lean_one_where_both_apply():
+    """MDR_OBSERVE_GEN=1 sends nb_houses % 32 == 0 shapes through the any-cluster-size staging too: same rows, same probabilities
+    (a child process: the library reads the knob once)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = r"""
+import torch, mdr_amd
+from mdr_amd.policy import FEATURES_OBSERVE, FusedActor
+from mdr_amd.rollout import ActorMLP
+from tests.test_gpu_observe_act import _cfg, _actor, _walk
+for E, N in ((40, 64), (3, 1024), (9, 96)):
+    env = mdr_amd.BatchedDemandResponseEnv(_cfg(N), nb_envs=E, device="cuda:0", seed=3)
+    env.reset(episode=0)
+    _walk(env, 5, seed=1)
+    rows = env.obs_vector("rows").view(E * N, 51)
+    actor = _actor(seed=N)
+    for layout in (1, 2):
+        a0, p0, probs0 = FusedActor.from_module(actor, layout=layout).sample(rows, 4, 1, want_probs=True)
+        kept = torch.empty_like(rows)
+        a1, p1, probs1 = FusedActor.from_module(actor, layout=layout, feature_order=FEATURES_OBSERVE).sample_env(env, 4, 1, want_probs=True, rows_out=kept)
+        assert torch.equal(kept, rows)
+        torch.testing.assert_close(probs1, probs0, rtol=2e-3 if layout == 2 else 1e-5, atol=2e-5 if layout == 2 else 2e-6)
+print("gen ok")
+"""
+    env = dict(os.environ, MDR_OBSERVE_GEN="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    res = subprocess.run([sys.executable, "-c", child], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "gen ok" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]

@@ -78,7 +78,7 @@ def test_collect_rollout_with_the_fused_policy_kernel():
     actor = ActorMLP(F).cuda()
     critic = CriticMLP(F).cuda()
     ro = collect_ppo_rollout(env, actor, T, gamma=0.9, critic=critic, seed=5)
-    assert hasattr(actor, "_mdr_fused")                                   # the fused path ran
+    assert hasattr(actor, "_mdr_fused_observe")                           # the fused path ran (observe -> act: default observation, N = 50)
     assert ro["action"].dtype == torch.int64 and set(ro["action"].unique().tolist()) <= {0, 1}
     # the stored probability is the actor's (torch fp32) probability of the stored action on the stored state
     for t in (0, 4, T - 1):
@@ -100,11 +100,11 @@ def test_collect_rollout_with_the_fused_policy_kernel():
     assert torch.equal(ro["action"], ro2["action"]) and torch.equal(ro["reward"], ro2["reward"])
     assert not torch.equal(ro["action"], ro3["action"])
     # a weight update invalidates the packed copy
-    packed = actor._mdr_fused[1]
+    packed = actor._mdr_fused_observe[1]
     with torch.no_grad():
         actor.fc[2].bias.add_(1.0)
     collect_ppo_rollout(_env(E, N), actor, 2, seed=5)
-    assert actor._mdr_fused[1] is not packed
+    assert actor._mdr_fused_observe[1] is not packed
 
 
 def test_collect_rollout_bf16x3_policy_stays_close_to_the_fp32_actor():
