@@ -251,12 +251,14 @@ def ppo_leg(rk: Ranks, env, args):
     for prec in ("fp32", "bf16x3"):
         out[prec] = {}
         for key, keep in (("transitions", True), ("no_states", False)):
-            collect_ppo_rollout(env, actor, 3, store_states=keep, policy_precision=prec, seed=rk.rank)      # warm-up + packing
+            # warm-up at the full length: packs the weights and leaves right-sized blocks in torch's caching allocator, so that the
+            # timed collection does not pay hipMalloc for its transition buffer (18 GB of states at 20 steps)
+            collect_ppo_rollout(env, actor, args.ppo_steps, store_states=keep, policy_precision=prec, seed=rk.rank)
             wall, ev_ms = timed(rk, lambda: collect_ppo_rollout(env, actor, args.ppo_steps, store_states=keep,
                                                                  policy_precision=prec, seed=rk.rank), args.ppo_steps)
             out[prec][key] = {"agent_steps_per_s": E * N * rk.world * args.ppo_steps / wall, "ms_per_step": wall / args.ppo_steps * 1e3,
                               "event_ms_per_step_rank0": ev_ms}
-            torch.cuda.empty_cache()
+    torch.cuda.empty_cache()
     out["value"] = out["fp32"]["transitions"]["agent_steps_per_s"]
     out["unit"] = "agent-steps/s"
     out["dtype"] = "f32 (exact fp32 MFMA); bf16x3 = split-bf16 operands, fp32 accumulate, probabilities within 2e-5"
