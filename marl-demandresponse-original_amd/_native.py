@@ -148,6 +148,14 @@ def load():
         raise NativeLibraryMissing(
             "HIP library not built: %s is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64, libmdr_hip.so is linked against the
+    # ones under /opt/rocm (same SONAMEs).  Whoever is loaded first is used by both; loaded the other way round - this library
+    # first, torch afterwards - torch's HSA runtime comes up beside /opt/rocm's and the launches of this library fail with "no
+    # ROCm-capable device is detected".  The host side owns its memory through torch anyway: bring torch's runtime in first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:      # a torch-free host (tools/c_abi_client.c is the C example) uses /opt/rocm's runtime alone
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, u32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64
     sig = {
