@@ -299,21 +299,29 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // half the agents of the second column block came out with garbage logits).  Hence the `s_nop 1` INSIDE the string.  The
 // plain vector conversion (__builtin_convertvector to bf16x2) is hazard-safe too and selects the same instruction, but lets the
 // scheduler hoist the conversions until k_actor_sample_bf16 spills (1.1 KB of scratch per lane, 6x slower).
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+// four packed conversions in ONE statement: the last write is two wait states away from whatever follows the statement, the
+// earlier ones further - one `s_nop 1` instead of four
+__device__ __forceinline__ void cvt_pk_bf16_x4(const float* v, uint32_t* out) {
+  asm("v_cvt_pk_bf16_f32 %0, %4, %5\n\tv_cvt_pk_bf16_f32 %1, %6, %7\n\tv_cvt_pk_bf16_f32 %2, %8, %9\n\tv_cvt_pk_bf16_f32 %3, %10, %11\n\ts_nop 1"
+      : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3])
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
 }
 
 // eight fp32 values -> their bf16 head and tail fragments
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
   uint32_t h[4], l[4];
+  cvt_pk_bf16_x4(v, h);
+  float res[8];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    h[p] = cvt_pk_bf16(v[2 * p], v[2 * p + 1]);
-    const float a = __uint_as_float(h[p] << 16), b = __uint_as_float(h[p] & 0xFFFF0000u);
-    l[p] = cvt_pk_bf16(v[2 * p] - a, v[2 * p + 1] - b);
+  for (int p = 0; p < 4; ++p) {   // x - float(bf16(x)), two values per v_pk_add_f32
+    const f32x2_t x = {v[2 * p], v[2 * p + 1]};
+    const f32x2_t hf = {__uint_as_float(h[p] << 16), __uint_as_float(h[p] & 0xFFFF0000u)};
+    const f32x2_t d = x - hf;
+    res[2 * p] = d.x;
+    res[2 * p + 1] = d.y;
   }
+  cvt_pk_bf16_x4(res, l);
   hi = uint4{h[0], h[1], h[2], h[3]};
   lo = uint4{l[0], l[1], l[2], l[3]};
 }
