@@ -212,3 +212,28 @@ print("gen ok")
     env = dict(os.environ, MDR_OBSERVE_GEN="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
     res = subprocess.run([sys.executable, "-c", child], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and "gen ok" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
+
+
+@pytest.mark.parametrize("idx", range(40))
+def test_fuzz_observe_act_vs_rows(idx):
+    """Random cluster sizes (11 ... 300, every tile / env alignment), batch sizes, lockout noise and walked states: the rows the fused
+    kernel copies out are bit for bit those of mdr_env_obs_vector, its probabilities those of the rows path (both layouts)."""
+    import mdr_amd
+    from mdr_amd.policy import FEATURES_OBSERVE, FusedActor
+    rng = np.random.default_rng(5100 + idx)
+    N = int(rng.choice([11, 12, 13, 15, 16, 17, 20, 21, 22, 31, 32, 33, 37, 42, 47, 48, 50, 63, 64, 65, 100, 127, 200, 300]))
+    E = int(rng.integers(1, max(2, 6000 // N)))
+    cfg = _cfg(N, **{"default_hvac_prop.lockout_noise": int(rng.choice([0, 15, 39])),
+                     "default_env_prop.time_step": int(rng.choice([4, 7, 60]))})
+    env = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=int(rng.integers(0, 2 ** 31)))
+    env.reset(episode=int(rng.integers(0, 4)))
+    _walk(env, int(rng.integers(0, 9)), seed=idx)
+    rows = env.obs_vector("rows").view(E * N, 51)
+    actor = _actor(seed=idx)
+    for layout in (1, 2):
+        kept = torch.full((E * N, 51), float("nan"), device="cuda:0")
+        a0, _, probs0 = FusedActor.from_module(actor, layout=layout).sample(rows, 3, idx, want_probs=True)
+        a1, _, probs1 = FusedActor.from_module(actor, layout=layout, feature_order=FEATURES_OBSERVE).sample_env(env, 3, idx, want_probs=True, rows_out=kept)
+        assert torch.equal(kept, rows), "case %d (E=%d N=%d layout %d): rows differ" % (idx, E, N, layout)
+        torch.testing.assert_close(probs1, probs0, rtol=2e-3 if layout == 2 else 1e-5, atol=2e-5 if layout == 2 else 2e-6)
+        assert int((a0 != a1).sum()) <= max(2, E * N // 20000)
