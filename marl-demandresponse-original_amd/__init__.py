@@ -13,6 +13,9 @@ def __getattr__(name):
     if name in ("BatchedDemandResponseEnv", "OBS_COLUMNS"):
         from . import batched_env
         return getattr(batched_env, name)
+    if name == "BatchedMetrics":
+        from .metrics import BatchedMetrics
+        return BatchedMetrics
     if name == "MADemandResponseEnv":
         from .env import MADemandResponseEnv
         return MADemandResponseEnv
