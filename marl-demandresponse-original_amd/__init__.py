@@ -13,6 +13,9 @@ def __getattr__(name):
     if name in ("BatchedDemandResponseEnv", "OBS_COLUMNS"):
         from . import batched_env
         return getattr(batched_env, name)
+    if name in ("sharding", "comm", "rollout", "policy", "metrics", "montecarlo"):      # submodules on first use (mdr_amd.sharding.house_shard ...)
+        import importlib
+        return importlib.import_module("." + name, __name__)
     if name == "BatchedMetrics":
         from .metrics import BatchedMetrics
         return BatchedMetrics
