@@ -49,6 +49,24 @@ class DeviceFedOracle(mo.OracleEnv):
                 setattr(self, k, v)
 
 
+def nearest_axis_flips(grid, env, ora) -> np.ndarray:
+    """bool [E]: envs with a house whose NEAREST grid index (the four thermal ratios and the HVAC power are looked up by
+    `np.argmin(|axis - value|)`, monteCarlo/interpolation.py:113-142) differs between the device's fp32 copy of the parameter and
+    the fp64 value - a parameter within fp32 rounding of the midpoint of two axis values (seen once in 31,000 fuzz cases: Ua ratio
+    1.0029999995 against the axis [1.0, 1.006]).  The lookup is discontinuous there, so no slope bound relates the two base
+    powers; the device-fed comparison still holds the device to its own inputs."""
+    s = ora.spec
+    flips = np.zeros(ora.E, dtype=bool)
+    for d, (name, default) in enumerate((("Ua", s.Ua), ("Cm", s.Cm), ("Ca", s.Ca), ("Hm", s.Hm), ("capacity", 1.0))):
+        ax = grid.axes[d if d < 4 else 7]
+        v32 = np.clip(env.t[name].double().cpu().numpy() / default, ax.min(), ax.max())
+        v64 = np.clip(getattr(ora, name) / default, ax.min(), ax.max())
+        i32 = np.argmin(np.abs(ax[None, None, :] - v32[..., None]), axis=-1)
+        i64 = np.argmin(np.abs(ax[None, None, :] - v64[..., None]), axis=-1)
+        flips |= (i32 != i64).any(axis=1)
+    return flips
+
+
 def base_power_bound(grid, env, ora, nb_agents):
     """Upper bound of |device base power - fp64 oracle base power| from the CURRENT state differences (see module docstring)."""
     g_air, g_mass, g_od = edge_slopes(grid)

@@ -219,7 +219,7 @@ def test_fuzz_interpolation_mode_vs_oracle(idx):
     pure fp64 oracle the difference stays inside the slope bound of the grid."""
     import mdr_amd
     from oracle import mdr_oracle as mo
-    from tests.interp_util import DeviceFedOracle, base_power_bound
+    from tests.interp_util import DeviceFedOracle, base_power_bound, nearest_axis_flips
     cfg, E, N, seed, values, axes = _interp_case(idx)
     env = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=seed, interp_grid=(values, axes))
     env.reset(episode=3)
@@ -231,6 +231,8 @@ def test_fuzz_interpolation_mode_vs_oracle(idx):
     ora.reset(seed=seed, episode=3)
     fed.reset(seed=seed, episode=3)
 
+    smooth = ~nearest_axis_flips(grid, env, ora)      # envs without a parameter on a nearest-neighbour tie (static per episode)
+
     def check_power(t):
         dev = env.t["base_power"].cpu().numpy()
         np.testing.assert_allclose(dev, fed.base_power, rtol=1e-9, atol=1e-6, err_msg="case %d step %d (device-fed oracle)" % (idx, t))
@@ -238,8 +240,8 @@ def test_fuzz_interpolation_mode_vs_oracle(idx):
         # the bound is evaluated on the current state differences; the base power in force was computed at the last update, when
         # they were no larger than the largest seen so far
         check_power.bound = max(check_power.bound, base_power_bound(grid, env, ora, N))
-        assert np.all(np.abs(dev - ora.base_power) <= check_power.bound * (1 + 1e-9) + 1e-6), \
-            "case %d step %d: |d base_power| %.3e above the slope bound %.3e" % (idx, t, float(np.max(np.abs(dev - ora.base_power))), check_power.bound)
+        assert np.all(np.abs(dev - ora.base_power)[smooth] <= check_power.bound * (1 + 1e-9) + 1e-6), \
+            "case %d step %d: |d base_power| %.3e above the slope bound %.3e" % (idx, t, float(np.max(np.abs(dev - ora.base_power)[smooth])), check_power.bound)
 
     check_power.bound = 0.0
     check_power(-1)
