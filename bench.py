@@ -28,6 +28,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -149,6 +150,8 @@ def parse(argv):
     ap.add_argument("--no-legs", action="store_true", help="skip the secondary ppo_rollout / c5 legs")
     ap.add_argument("--ppo-steps", type=int, default=20)
     ap.add_argument("--c5-steps", type=int, default=200)
+    ap.add_argument("--leg-timeout", type=float, default=float(os.environ.get("MDR_BENCH_LEG_TIMEOUT", "240")),
+                    help="seconds the secondary legs may take before the headline line is printed without them")
     ap.add_argument("--stagger", type=int, default=int(os.environ.get("MDR_STAGGER", "2304")))
     return ap.parse_args(argv)
 
@@ -344,17 +347,7 @@ def run_rank(args):
     assert env.steps_taken == args.warmup + args.steps
     assert bool(torch.isfinite(env.t["Ta"]).all()) and bool(torch.isfinite(env.t["reward"]).all())
 
-    legs = {}
-    if not args.no_legs:
-        for name, leg in (("ppo_rollout", lambda: ppo_leg(rk, env, args)), ("c5", lambda: c5_leg(rk, mdr_amd, args))):
-            try:
-                legs[name] = leg()
-            except Exception as exc:      # a secondary leg never costs the headline; with several ranks a failure is fatal for all
-                if rk.world > 1:
-                    raise
-                legs[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
-
-    if rk.rank == 0:
+    def headline(legs):
         achieved = B_ALG * e_per_gpu * N_HOUSES / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_src = traffic_from_profiles()
         line = {
@@ -377,6 +370,44 @@ def run_rank(args):
                                        "cache-assisted; the size sweep in profiles/ (r02_size_sweep.jsonl) gives the rate with the re-read set at 2-8x the cache"},
         }
         line.update(legs)
+        return line
+
+    # The secondary legs never cost the headline: the headline is measured by now, and if a leg has not returned after
+    # --leg-timeout seconds (a collective that never completes on some node, say) rank 0 prints the line without it and every
+    # rank leaves through os._exit - a hung leg would otherwise take the scaling curve with it.
+    legs, lock, printed = {}, threading.Lock(), [False]
+
+    def give_up():
+        with lock:
+            if printed[0]:
+                return
+            printed[0] = True
+            if rk.rank == 0:
+                pending = [n for n in ("ppo_rollout", "c5") if n not in legs]
+                out = dict(legs)
+                out.update({n: {"error": "leg did not finish within %.0f s" % args.leg_timeout} for n in pending})
+                print(json.dumps(headline(out)), flush=True)
+        os._exit(0)
+
+    watchdog = threading.Timer(args.leg_timeout, give_up)
+    watchdog.daemon = True
+    if not args.no_legs:
+        watchdog.start()
+        for name, leg in (("ppo_rollout", lambda: ppo_leg(rk, env, args)), ("c5", lambda: c5_leg(rk, mdr_amd, args))):
+            try:
+                legs[name] = leg()
+            except Exception as exc:      # with several ranks a failure on one would leave the others inside a collective: fatal for all
+                if rk.world > 1:
+                    raise
+                legs[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        watchdog.cancel()
+
+    with lock:
+        if printed[0]:
+            return
+        printed[0] = True
+    if rk.rank == 0:
+        line = headline(legs)
         if rk.world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -44,3 +44,12 @@ def test_two_ranks_self_launched_gloo_on_one_gpu():
     assert line["ppo_rollout"]["n_gpus"] == 2 and line["ppo_rollout"]["value"] > 1e6
     assert line["c5"]["n_gpus"] == 2 and line["c5"]["houses_per_rank"] == 500_000 and line["c5"]["backend"] == "gloo"
     assert "cpu_baseline" not in line
+
+
+@pytest.mark.gpu
+def test_a_leg_that_does_not_return_never_costs_the_headline():
+    """--leg-timeout: the headline is measured before the secondary legs; if one hangs (here: a timeout shorter than any leg) rank 0
+    still prints the ONE line - with the leg marked - and the process exits 0."""
+    line = _run({"MDR_BENCH_ENVS": "256"}, "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--leg-timeout", "0.2")
+    assert line["value"] > 1e9 and line["roofline"]["frac"] > 0
+    assert "did not finish" in line["ppo_rollout"]["error"] and "did not finish" in line["c5"]["error"]
