@@ -34,6 +34,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+_STDOUT_FD = os.dup(1)      # the ONE JSON line goes here whatever fd 1 points at meanwhile (init_group parks it on stderr for RCCL's banner)
+
+
+def emit(line: dict) -> None:
+    sys.stdout.flush()
+    os.write(_STDOUT_FD, (json.dumps(line) + "\n").encode())
 
 # algorithmic bytes per house-step of this layout
 #   state 13 R + 13 W (Ta, Tm f32; sso i32; flags u8) + parameters 40 R (9 f32 + lockout i32)
@@ -318,11 +324,11 @@ def dry_rank(rk: Ranks, args):
     rk.fence()
     elapsed = rk.max_over_ranks(time.perf_counter() - t0)
     if rk.rank == 0:
-        print(json.dumps({"metric": "house-steps/sec at 4096 envs x 1024 houses; achieved HBM GB/s vs roofline", "value": 0.0,
+        emit({"metric": "house-steps/sec at 4096 envs x 1024 houses; achieved HBM GB/s vs roofline", "value": 0.0,
                           "unit": "house-steps/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": elapsed / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "dry-run: launcher rehearsal, no kernel ran",
-                          "config": {"workload": "none (MDR_BENCH_DRY)"}, "roofline": None, "dry_run": True}), flush=True)
+                          "config": {"workload": "none (MDR_BENCH_DRY)"}, "roofline": None, "dry_run": True})
     rk.close()
 
 
@@ -386,7 +392,7 @@ def run_rank(args):
                 pending = [n for n in ("ppo_rollout", "c5") if n not in legs]
                 out = dict(legs)
                 out.update({n: {"error": "leg did not finish within %.0f s" % args.leg_timeout} for n in pending})
-                print(json.dumps(headline(out)), flush=True)
+                emit(headline(out))
         os._exit(0)
 
     watchdog = threading.Timer(args.leg_timeout, give_up)
@@ -410,7 +416,7 @@ def run_rank(args):
         line = headline(legs)
         if rk.world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
-        print(json.dumps(line), flush=True)
+        emit(line)
     rk.close()
 
 

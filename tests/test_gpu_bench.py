@@ -52,4 +52,5 @@ def test_a_leg_that_does_not_return_never_costs_the_headline():
     still prints the ONE line - with the leg marked - and the process exits 0."""
     line = _run({"MDR_BENCH_ENVS": "256"}, "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--leg-timeout", "0.2")
     assert line["value"] > 1e9 and line["roofline"]["frac"] > 0
-    assert "did not finish" in line["ppo_rollout"]["error"] and "did not finish" in line["c5"]["error"]
+    assert "did not finish" in line["c5"]["error"]                      # the last leg cannot have made it in 0.2 s
+    assert "value" in line["ppo_rollout"] or "did not finish" in line["ppo_rollout"]["error"]
