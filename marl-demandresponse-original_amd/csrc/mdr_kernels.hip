@@ -1057,6 +1057,12 @@ __global__ __launch_bounds__(THREADS) void k_step_partial(StepArgs a) {
     acc.sum_p = (double)p;
     acc.sum_pen = (double)ps;
     store_obs_local<VEC>(a, base + h, o, lockout);
+    // the house's own temperature penalty waits in the reward array for the finish kernel (which then needs neither the
+    // temperature nor the target / deadband again: 4 B written + 4 B read per house instead of 12 B re-read)
+    float pen[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) pen[v] = o[v].pen;
+    store_vec<VEC>(a.reward, base + h, pen);
   }
   const Red3 tot = block_reduce<THREADS>(acc, lds);
   if (threadIdx.x == 0) {
@@ -1086,7 +1092,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(StepArgs a) {
   }
 }
 
-// rewards and the two power columns from the env's totals; re-derives the penalty.  Where the totals come from:
+// rewards and the two power columns from the env's totals and the per-house penalties k_step_partial left in `reward`.  Where the totals come from:
 //   records != nullptr  the per-workgroup partial records themselves, [world][E][nblk][3] (world = 1: this device's own
 //                       `partials`; world > 1: every rank's records, all-gathered): EVERY finish workgroup re-sums its env's
 //                       world * nblk records from L2 in one fixed order (thread t: ranks in order, records t, t + THREADS, ... ;
@@ -1133,16 +1139,8 @@ __global__ __launch_bounds__(THREADS) void k_step_finish(StepArgs a) {
   if (blockIdx.x == 0 && threadIdx.x == 0) a.P[e] = P;
   if (h >= a.N) return;
   const int64_t i = (int64_t)e * a.N + h;
-  float Ta[VEC], tg[VEC], db[VEC], pen[VEC];
-  load_vec<VEC>(a.Ta, i, Ta);
-  load_param<VEC>(a.target, i, tg);
-  load_param<VEC>(a.deadband, i, db);
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) {
-    const float hi = fmaf(0.5f, db[v], tg[v]), lo = fmaf(-0.5f, db[v], tg[v]);
-    const float above = Ta[v] - hi, below = lo - Ta[v];
-    pen[v] = above > 0.0f ? above * above : (below > 0.0f ? below * below : 0.0f);
-  }
+  float pen[VEC];
+  load_vec<VEC>(a.reward, i, pen);   // left there by k_step_partial
   store_reward_power<VEC>(a, i, pen, sum_pen, max_pen, signal_term(a, P, a.sig_old[e]),
                           (float)(a.sig_new[e] * a.inv_obs_norm), (float)(P * a.inv_obs_norm));
 }
