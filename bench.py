@@ -274,10 +274,11 @@ def ppo_leg(rk: Ranks, env, args):
     return out
 
 
-def c5_leg(rk: Ranks, mdr, args):
+def c5_leg(rk: Ranks, mdr, args, graph=False):
     """BASELINE.json configs[4]: ONE env x 1,000,000 houses, houses sharded over the ranks, one exchange per step
-    (all-gather of every rank's [3][E] aggregate block; env/MA_DemandResponse.py:1042-1050, 274-321).  A world of one
-    still runs the exchange (through RCCL) so that the collective's cost is on record at every N."""
+    (all-gather of every rank's per-workgroup records; env/MA_DemandResponse.py:1042-1050, 274-321).  A world of one
+    still runs the exchange (through RCCL) so that the collective's cost is on record at every N.
+    `graph`: the same step - begin, all-gather, end - captured once in a hipGraph and replayed (graph mode: no host work per step)."""
     torch = rk.torch
     from mdr_amd.sharding import house_shard
     rk.init_group()
@@ -285,11 +286,22 @@ def c5_leg(rk: Ranks, mdr, args):
     cfg["default_env_prop"]["cluster_prop"]["nb_agents"] = C5_HOUSES
     off, cnt = house_shard(C5_HOUSES, rk.world, rk.rank)
     env = mdr.BatchedDemandResponseEnv(cfg, nb_envs=1, device=rk.device, seed=2024, house_shard=(off, cnt), exchange_always=True,
-                                       table_steps=64)
+                                       table_steps=64, graph_mode=graph)
     env.reset(episode=0)
     K = args.c5_steps
     env.rollout(20)
     wall, ev_ms = timed(rk, lambda: env.rollout(K), K)
+    if graph:
+        assert env.steps_taken == 20 + K and bool(torch.isfinite(env.t["Ta"]).all())
+        assert rk.backend != "nccl" or getattr(env, "_shard_graph", None) is not None, "the captured path did not run"
+        return {"metric": "house-steps/s, 1 env x 1,000,000 houses sharded over the ranks, one all-gather per step, step captured in a hipGraph",
+                "value": C5_HOUSES * K / wall, "unit": "house-steps/s", "n_gpus": rk.world, "scaling": "strong", "steps": K,
+                "houses_per_rank": cnt, "us_per_step": wall / K * 1e6, "event_us_per_step_rank0": ev_ms * 1e3,
+                "captured": getattr(env, "_shard_graph", None) is not None, "checksum_Ta": float(env.t["Ta"].double().sum()),
+                "backend": "rccl" if rk.backend == "nccl" else rk.backend,
+                "note": "step_begin_records -> all_gather_into_tensor -> step_end_records captured ONCE (device-resident time cursor) and "
+                        "replayed until the 64-row time tables need a refill: same work per step as the c5 leg, no host calls per step; "
+                        "checksum_Ta equals the c5 leg's (same seed, same number of steps)"}
     # the collective alone (same tensor, same call), and the kernels alone (an unsharded env of this rank's share: the same
     # k_step_partial / k_step_finish launches without the exchange)
     ex = env._exchange()
@@ -306,6 +318,7 @@ def c5_leg(rk: Ranks, mdr, args):
     return {"metric": "house-steps/s, 1 env x 1,000,000 houses sharded over the ranks, one all-gather per step",
             "value": C5_HOUSES * K / wall, "unit": "house-steps/s", "n_gpus": rk.world, "scaling": "strong", "steps": K,
             "houses_per_rank": cnt, "us_per_step": wall / K * 1e6, "event_us_per_step_rank0": ev_ms * 1e3,
+            "checksum_Ta": float(env.t["Ta"].double().sum()),
             "kernel_us_per_step": kern_ms * 1e3, "collective_us_per_step": coll_ms * 1e3,
             "backend": "rccl" if rk.backend == "nccl" else rk.backend,
             "note": "us_per_step is host wall-clock per step (max over ranks) of step_begin_records -> all_gather_into_tensor(24 B per 1024-house workgroup) -> "
@@ -382,6 +395,11 @@ def run_rank(args):
     # --leg-timeout seconds (a collective that never completes on some node, say) rank 0 prints the line without it and every
     # rank leaves through os._exit - a hung leg would otherwise take the scaling curve with it.
     legs, lock, printed = {}, threading.Lock(), [False]
+    leg_list = (("ppo_rollout", lambda: ppo_leg(rk, env, args)), ("c5", lambda: c5_leg(rk, mdr_amd, args)),
+                ("c5_graph", lambda: c5_leg(rk, mdr_amd, args, graph=True)))
+    baseline = None
+    if rk.rank == 0 and rk.world == 1 and not args.no_cpu_baseline:      # before the legs: a leg that hangs must not cost the line its baseline
+        baseline = cpu_baseline(cfg, args.cpu_seconds)
 
     def give_up():
         with lock:
@@ -389,9 +407,11 @@ def run_rank(args):
                 return
             printed[0] = True
             if rk.rank == 0:
-                pending = [n for n in ("ppo_rollout", "c5") if n not in legs]
+                pending = [n for n, _ in leg_list if n not in legs]
                 out = dict(legs)
                 out.update({n: {"error": "leg did not finish within %.0f s" % args.leg_timeout} for n in pending})
+                if baseline is not None:
+                    out["cpu_baseline"] = baseline
                 emit(headline(out))
         os._exit(0)
 
@@ -399,7 +419,7 @@ def run_rank(args):
     watchdog.daemon = True
     if not args.no_legs:
         watchdog.start()
-        for name, leg in (("ppo_rollout", lambda: ppo_leg(rk, env, args)), ("c5", lambda: c5_leg(rk, mdr_amd, args))):
+        for name, leg in leg_list:
             try:
                 legs[name] = leg()
             except Exception as exc:      # with several ranks a failure on one would leave the others inside a collective: fatal for all
@@ -414,8 +434,8 @@ def run_rank(args):
         printed[0] = True
     if rk.rank == 0:
         line = headline(legs)
-        if rk.world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
+        if baseline is not None:
+            line["cpu_baseline"] = baseline
         emit(line)
     rk.close()
 

@@ -289,6 +289,9 @@ int mdr_env_step_end_gathered(mdr_env_t *env, const double *gathered, int32_t wo
  * into `records` [world][E][records_per_env][3] (equal records_per_env on every rank: the largest shard's), and every workgroup
  * of step_end_records re-sums its env's world * records_per_env records from L2 in one fixed order while it writes the rewards.
  * Two launches around ONE collective; payload 24 B per 1024 houses instead of 24 B per rank - still latency-bound.
+ * Graph mode (mdr_buffers_t.cursor): the pair takes its table rows from the device cursor and step_end_records advances it, so
+ * begin - collective - end can be captured in one hipGraph (RCCL collectives are capturable) and replayed mdr_env_graph_room()
+ * times between mdr_env_graph_replayed() calls: no host work per step at all.
  * records == NULL: this device's own `partials`, world = 1 (the unsharded split path of mdr_env_step for N > 4096). */
 int mdr_env_step_begin_records(mdr_env_t *env, uint8_t *actions, int action_source, int32_t records_per_env, void *stream);
 int mdr_env_step_end_records(mdr_env_t *env, const double *records, int32_t world, void *stream);
@@ -347,7 +350,9 @@ int mdr_env_comm_draws(mdr_env_t *env, const mdr_obs_spec_t *spec, int32_t *send
  *   mdr_env_graph_room      how many replays are allowed now: the steps the time tables still cover, and - interpolation mode -
  *                           only up to the step BEFORE the next interpolatePower update: the step that lands on an update
  *                           must be an ordinary (un-captured) mdr_env_step, which runs the update before anything enqueued
- *                           behind it reads the signal.  0 = take one ordinary step now; capture needs room >= 1;
+ *                           behind it reads the signal.  0 = take one ordinary step now; capture needs room >= 1.  One
+ *                           capture may record several steps (at most `room`: the call that would record one more is
+ *                           refused); every replay of that graph then counts as that many steps;
  *   mdr_env_graph_replayed  `n` steps were replayed: the host cursor catches up, refills the tables and runs a due
  *                           interpolation update (launches on `stream`, outside any capture).
  * Ordinary (non-captured) calls keep working in graph mode; each step then costs one extra one-thread launch. */

@@ -394,11 +394,57 @@ class BatchedDemandResponseEnv:
         self._step(self.t["actions"].data_ptr(), nat.ACTIONS_BANGBANG)
         return self.t["obs"], self.t["reward"], self.done, {"cluster_hvac_power": self.t["P"]}
 
+    SHARD_GRAPH_UNROLL = 16      # steps per captured graph: a graph launch costs ~10 us, a node-to-node hop inside one ~2 us
+
+    def _rollout_sharded_graph(self, nb_steps: int, ptr: int, source: int) -> None:
+        """Sharded houses in graph mode: begin, the all-gather of the records, end - SHARD_GRAPH_UNROLL steps of it - are captured
+        in a hipGraph (RCCL collectives are capturable) and replayed; the device cursor walks the time tables, the host only comes
+        back when they run out.  The per-step work is unchanged (every step still exchanges), the per-step host cost - three
+        Python -> C calls and a torch.distributed dispatch, ~30 us against 8-19 us of kernels - is gone.  Every rank captures and
+        replays in lockstep (same cursor, same room)."""
+        done = 0
+        key = (ptr, source)
+        cached = getattr(self, "_shard_graph", None)
+        if cached is not None and cached[0] != key:
+            cached = self._shard_graph = None
+        if cached is None and nb_steps > 0:
+            self._step(ptr, source)                 # eager: sizes the exchange buffers, brings the communicator up
+            done = 1
+            cached = self._shard_graph = (key, {})
+        while done < nb_steps:
+            self.graph_replayed(0)                  # tables refilled if used up, device cursor current
+            n = min(self.graph_room(), nb_steps - done)
+            if n < 1:                               # the tables end here: one ordinary step
+                self._step(ptr, source)
+                done += 1
+                continue
+            unroll = self.SHARD_GRAPH_UNROLL if n >= self.SHARD_GRAPH_UNROLL else 1
+            g = cached[1].get(unroll)
+            if g is None:
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    for _ in range(unroll):
+                        self._step_begin(ptr, source)
+                        records, world = self._exchange().gather_partials(self)
+                        self._step_end(records, world)
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                cached[1][unroll] = g
+            reps = n // unroll
+            for _ in range(reps):
+                g.replay()
+            self.graph_replayed(reps * unroll)
+            done += reps * unroll
+
     def rollout(self, nb_steps: int, actions: Optional[torch.Tensor] = None):
         """nb_steps consecutive launches without returning to Python (bang-bang unless ``actions`` is given)."""
         if self.sharded:
+            source = nat.ACTIONS_EXTERNAL if actions is not None else nat.ACTIONS_BANGBANG
+            if self.graph_mode and self.spec.base_power_mode != 1 and getattr(self._exchange(), "capturable", False):
+                return self._rollout_sharded_graph(int(nb_steps), self._actions_ptr(actions), source)
             for _ in range(nb_steps):
-                self._step(self._actions_ptr(actions), nat.ACTIONS_EXTERNAL if actions is not None else nat.ACTIONS_BANGBANG)
+                self._step(self._actions_ptr(actions), source)
             return
         src = nat.ACTIONS_EXTERNAL if actions is not None else nat.ACTIONS_BANGBANG
         with torch.cuda.device(self.device):

@@ -17,6 +17,7 @@ struct mdr_env {
   bool has_episode = false;   // per-house parameters present
   bool has_tables = false;    // begin_episode done
   bool split_pending = false; // step_begin issued, step_end outstanding
+  int64_t captured = 0;       // graph mode: steps recorded into the capture in progress (one graph may hold several; each replay runs them all)
   bool interp_due = false;    // sharded houses, interpolation mode: the base power of the current time index awaits its exchange
   int64_t dev_row = -1, dev_k = -1;   // graph mode: what the device-resident cursor holds (as far as the host knows)
   uint64_t seed = 0;
@@ -502,14 +503,15 @@ int mdr_env_step(mdr_env_t* env, uint8_t* actions, int action_source, void* stre
     graph_rows(env, &a);
   }
   const bool recording = graph && capturing((hipStream_t)stream);   // launches are recorded, not run: the host state must not move
-  if (recording && mdr_env_graph_room(env) < 1)
-    return fail(env, MDR_ERR_INVALID, "graph mode: the next step lands on an interpolatePower update (mdr_env_graph_room() is 0): run it un-captured");
+  if (recording && mdr_env_graph_room(env) - env->captured < 1)
+    return fail(env, MDR_ERR_INVALID, "graph mode: the next step lands on an interpolatePower update or past the time tables (mdr_env_graph_room() steps were recorded): run it un-captured");
+  if (!recording) env->captured = 0;
   hipError_t e = mdr::launch_step(a, env->plan, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "step");
   if (graph) {
     e = mdr::launch_cursor_advance(env->buf.cursor, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(env, e, "cursor_advance");
-    if (recording) return MDR_OK;    // mdr_env_graph_replayed accounts for every replay (and runs a due interpolation update)
+    if (recording) { env->captured += 1; return MDR_OK; }   // mdr_env_graph_replayed accounts for every replay (and runs a due interpolation update)
     env->dev_row += 1;
     env->dev_k += 1;
   }
@@ -542,6 +544,7 @@ int64_t mdr_env_graph_room(const mdr_env_t* env) {
   // interpolation mode: the step that LANDS on an interpolatePower update is never replayed - the update is host work, and
   // whatever a graph enqueues behind the step (observation, metrics) would still read the signal built from the old base power
   if (interp_mode(env)) room = std::min<int64_t>(room, env->interp_steps - (env->k % env->interp_steps) - 1);
+  if (interp_mode(env) && sharded(env)) room = 0;   // the base-power exchange of sharded houses is host work at every update: no replays
   return room < 0 ? 0 : room;
 }
 
@@ -551,10 +554,11 @@ int mdr_env_graph_replayed(mdr_env_t* env, int64_t n, void* stream) {
   if (!env->has_tables) return fail(env, MDR_ERR_UNBOUND, "no episode: call reset/load_episode and begin_episode first");
   if (n < 0 || n > mdr_env_graph_room(env)) return fail(env, MDR_ERR_INVALID, "more steps replayed than mdr_env_graph_room() allowed");
   if (capturing((hipStream_t)stream)) return fail(env, MDR_ERR_INVALID, "mdr_env_graph_replayed inside a capture");
+  env->captured = 0;
   env->k += n;                       // the device advanced itself n times
   env->dev_row += n;
   env->dev_k += n;
-  int rc = interp_boundary(env, (hipStream_t)stream, nullptr);   // a due interpolatePower update (rebuilds the tables)
+  int rc = sharded(env) ? MDR_OK : interp_boundary(env, (hipStream_t)stream, nullptr);   // a due interpolatePower update (rebuilds the tables)
   if (rc != MDR_OK) return rc;
   if (env->k - env->j0 >= env->cfg.table_steps) {                // the tables are used up: refill from the current time index
     rc = fill_tables(env, env->k, (hipStream_t)stream);
@@ -653,6 +657,14 @@ int mdr_env_step_begin_records(mdr_env_t* env, uint8_t* actions, int action_sour
   int rc = step_args(env, actions, action_source, (hipStream_t)stream, &a);
   if (rc != MDR_OK) return rc;
   a.nblk = records_per_env;
+  if (graph_mode(env)) {   // graph mode: begin - collective - end can be captured as ONE hipGraph node sequence and replayed
+    if (!capturing((hipStream_t)stream)) env->captured = 0;
+    else if (mdr_env_graph_room(env) - env->captured < 1)
+      return fail(env, MDR_ERR_INVALID, "graph mode: no room to replay a step here (mdr_env_graph_room() steps were recorded): run it un-captured");
+    rc = sync_cursor(env, (hipStream_t)stream);
+    if (rc != MDR_OK) return rc;
+    graph_rows(env, &a);
+  }
   hipError_t e = mdr::launch_step_begin_split(a, false, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "step_begin_records");
   env->split_pending = true;
@@ -674,9 +686,19 @@ static int step_end_impl(mdr_env_t* env, const double* gathered, const double* r
   if (records) a.nblk = (int)env->records_stride;
   env->records_stride = 0;
   a.world = world;
+  const bool graph = graph_mode(env) && records != nullptr;      // the records pair is the graph-capable one
+  const bool recording = graph && capturing((hipStream_t)stream);
+  if (graph) graph_rows(env, &a);
   hipError_t e = mdr::launch_step_end_split(a, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "step_end");
   env->split_pending = false;
+  if (graph) {
+    e = mdr::launch_cursor_advance(env->buf.cursor, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(env, e, "cursor_advance");
+    if (recording) { env->captured += 1; return MDR_OK; }   // recorded, not run: mdr_env_graph_replayed accounts for every replay
+    env->dev_row += 1;
+    env->dev_k += 1;
+  }
   env->k += 1;
   if (interp_mode(env) && env->k % env->interp_steps == 0) {
     if (!sharded(env)) return interp_boundary(env, (hipStream_t)stream, nullptr);

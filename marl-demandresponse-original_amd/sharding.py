@@ -119,6 +119,13 @@ class TorchDistExchange:
     """The exchanges of the sharded-houses layout over torch.distributed (RCCL on the GPU box, gloo in CPU tests):
     one SUM all-reduce of `max_power` per episode and ONE all-gather of the per-workgroup partial records per step."""
 
+    @property
+    def capturable(self) -> bool:
+        """May its collectives sit inside a hipGraph capture?  RCCL's may (BatchedDemandResponseEnv.rollout captures begin -
+        all-gather - end as one graph); gloo's are host work."""
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_backend(self.process_group) == "nccl"
+
     def __init__(self, process_group=None):
         self.process_group = process_group
         self._gathered = None

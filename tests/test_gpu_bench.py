@@ -33,6 +33,10 @@ def test_single_gpu_line_with_legs_over_rccl():
     assert "error" not in line["c5"], line["c5"]        # the exchange of a world of one ran over RCCL
     assert line["c5"]["backend"] == "rccl" and line["c5"]["houses_per_rank"] == 1_000_000 and line["c5"]["value"] > 1e9
     assert line["c5"]["collective_us_per_step"] > 0 and line["c5"]["kernel_us_per_step"] > 0
+    g = line["c5_graph"]                                # the same step, captured with its all-gather in a hipGraph and replayed
+    assert "error" not in g, g
+    assert g["captured"] and g["backend"] == "rccl" and g["checksum_Ta"] == line["c5"]["checksum_Ta"]
+    assert g["us_per_step"] < line["c5"]["us_per_step"]
 
 
 @pytest.mark.gpu
@@ -43,6 +47,7 @@ def test_two_ranks_self_launched_gloo_on_one_gpu():
     assert line["config"]["envs_per_gpu"] == 256
     assert line["ppo_rollout"]["n_gpus"] == 2 and line["ppo_rollout"]["value"] > 1e6
     assert line["c5"]["n_gpus"] == 2 and line["c5"]["houses_per_rank"] == 500_000 and line["c5"]["backend"] == "gloo"
+    assert line["c5_graph"]["captured"] is False and line["c5_graph"]["checksum_Ta"] == line["c5"]["checksum_Ta"]   # gloo: not capturable, stepped eagerly
     assert "cpu_baseline" not in line
 
 
@@ -52,5 +57,5 @@ def test_a_leg_that_does_not_return_never_costs_the_headline():
     still prints the ONE line - with the leg marked - and the process exits 0."""
     line = _run({"MDR_BENCH_ENVS": "256"}, "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--leg-timeout", "0.2")
     assert line["value"] > 1e9 and line["roofline"]["frac"] > 0
-    assert "did not finish" in line["c5"]["error"]                      # the last leg cannot have made it in 0.2 s
+    assert "did not finish" in line["c5_graph"]["error"]                      # the last leg cannot have made it in 0.2 s
     assert "value" in line["ppo_rollout"] or "did not finish" in line["ppo_rollout"]["error"]

@@ -312,6 +312,47 @@ def test_capture_of_a_step_that_lands_on_an_update_is_refused():
             a.step_bangbang()
 
 
+def test_one_graph_may_hold_several_steps_but_not_more_than_the_tables_cover():
+    """A capture may record up to graph_room() steps (each replay then counts as that many); the call that would record one more is
+    refused - a replay would walk the device cursor past the time tables."""
+    import mdr_amd
+    cfg = _cfg(64)
+    a = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=5, device="cuda:0", seed=9, table_steps=8, graph_mode=True)
+    b = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=5, device="cuda:0", seed=9, table_steps=8)
+    a.reset(episode=0)
+    b.reset(episode=0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        a.step_bangbang()
+        a.graph_replayed(0)
+    torch.cuda.current_stream().wait_stream(side)
+    room = a.graph_room()
+    assert room == 7
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(ValueError, match="steps were recorded"):
+        with torch.cuda.graph(g):
+            for _ in range(room + 1):
+                a.step_bangbang()
+    a.graph_replayed(0)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(3):
+            a.step_bangbang()
+    g.replay()
+    g.replay()
+    a.graph_replayed(6)
+    assert a.graph_room() == 1
+    with pytest.raises(ValueError, match="more steps replayed"):
+        a.graph_replayed(3)
+    for _ in range(7):
+        b.step_bangbang()
+    torch.cuda.synchronize()
+    assert a.steps_taken == b.steps_taken == 7
+    for k in ("Ta", "Tm", "sso", "flags", "reward", "obs", "P"):
+        assert torch.equal(a.t[k], b.t[k]), k
+
+
 def test_load_state_dict_resyncs_the_device_cursor():
     """a snapshot taken while the device cursor was lazily stale, loaded into an env whose host-side picture of that
     cursor happens to match the snapshot's (k - j0, k): the cursor in the loaded slab must not be trusted."""

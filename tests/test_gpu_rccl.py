@@ -89,6 +89,35 @@ def _worker():
                 torch.testing.assert_close(rank0.t["reward"], whole.t["reward"], rtol=1e-6, atol=1e-6)
         del whole, rank0
 
+    # --- graph mode: begin - RCCL all-gather - end captured as ONE hipGraph and replayed (no host work per step) ---------------
+    for N, E, T in ((8192, 3, 60), (1000, 2, 37), (125000, 1, 25)):
+        cfg = _cfg(N, **{"noise_house_prop.noise_mode": "big_noise", "noise_hvac_prop.noise_mode": "big_noise",
+                         "default_env_prop.power_grid_prop.signal_mode": "perlin"})
+        whole = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device=dev, seed=4)
+        rank0 = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device=dev, seed=4, house_shard=(0, N), exchange_always=True,
+                                                 graph_mode=True, table_steps=16)      # 16-row tables: the replays stop for refills
+        whole.reset(episode=0)
+        rank0.reset(episode=0)
+        rank0.rollout(T)
+        assert getattr(rank0, "_shard_graph", None) is not None, "the captured path did not run"
+        whole.rollout(T)
+        act = (torch.rand((E, N), device=dev) < 0.5).to(torch.uint8)
+        rank0.rollout(9, act)          # another (pointer, source) pair: re-captured
+        whole.rollout(9, act)
+        rank0.step(act)                # and eager steps keep working in between
+        whole.step(act)
+        rank0.rollout(5, act)
+        whole.rollout(5, act)
+        torch.cuda.synchronize()
+        assert rank0.steps_taken == whole.steps_taken == T + 15
+        for k in ("Ta", "Tm", "sso", "flags", "obs", "P"):
+            assert torch.equal(rank0.t[k], whole.t[k]), ("graph", N, k)
+        if N > 4096:
+            assert torch.equal(rank0.t["reward"], whole.t["reward"]), ("graph", N)
+        else:
+            torch.testing.assert_close(rank0.t["reward"], whole.t["reward"], rtol=1e-6, atol=1e-6)
+        del whole, rank0
+
     # --- observation: all-gather of the message records (random_sample exports every record) -----------------------------------
     N, E = 600, 2
     cfg = _cfg(N, **{"noise_house_prop.noise_mode": "big_noise", "noise_hvac_prop.noise_mode": "big_noise",
