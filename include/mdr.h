@@ -150,10 +150,11 @@ typedef struct mdr_buffers {
   /* scratch for the split (multi-workgroup per env) path: [E][mdr_partials_per_env()][3] */
   double *partials;
   double *base_power;              /* [E] PowerGrid.base_power (written in interpolation mode) */
-  /* Optional (NULL = off): graph mode.  int32 [2] = {table row, time index} kept on the device: the step and observation
-   * kernels then take their table rows from it instead of from launch arguments, and every step ends with a one-thread
-   * launch that advances it - so a captured mdr_env_step / mdr_env_obs_vector (hipGraph, torch.cuda.CUDAGraph) keeps walking
-   * through the episode when it is replayed.  See mdr_env_graph_room / mdr_env_graph_replayed. */
+  /* Optional (NULL = off): graph mode.  int32 [4] = {table row, time index, the split pair's row note, arrival counter} kept on
+   * the device: the step and observation kernels then take their table rows from it instead of from launch arguments, and the
+   * step's last kernel advances it (small grids and the split pair; a big one-kernel step is followed by a one-thread launch)
+   * - so a captured mdr_env_step / mdr_env_obs_vector (hipGraph, torch.cuda.CUDAGraph) keeps walking through the episode when
+   * it is replayed.  See mdr_env_graph_room / mdr_env_graph_replayed. */
   int32_t *cursor;
   /* Optional (NULL = off): [(table_steps+1)][E] what PowerGrid.step adds to cumulated_abs_noise at that time index,
    * |base_power * amplitude * perlin| (env 1301); 0 for the signal families without noise. */
@@ -355,7 +356,7 @@ int mdr_env_comm_draws(mdr_env_t *env, const mdr_obs_spec_t *spec, int32_t *send
  *                           refused); every replay of that graph then counts as that many steps;
  *   mdr_env_graph_replayed  `n` steps were replayed: the host cursor catches up, refills the tables and runs a due
  *                           interpolation update (launches on `stream`, outside any capture).
- * Ordinary (non-captured) calls keep working in graph mode; each step then costs one extra one-thread launch. */
+ * Ordinary (non-captured) calls keep working in graph mode. */
 int64_t mdr_env_graph_room(const mdr_env_t *env);
 int mdr_env_graph_replayed(mdr_env_t *env, int64_t n, void *stream);
 

@@ -140,7 +140,7 @@ class BatchedDemandResponseEnv:
         items += [("tab_od", torch.float32, (K1, E)), ("tab_solar", torch.float32, (K1, E)), ("tab_signal", torch.float64, (K1, E)),
                   ("tab_abs_noise", torch.float64, (K1, E))]
         items += [("partials", torch.float64, (E, nblk, 3))]
-        items += [("cursor", torch.int32, (2,))]      # graph mode: {table row, time index} kept on the device
+        items += [("cursor", torch.int32, (4,))]      # graph mode: {table row, time index, arrival counter, -} kept on the device
         return items
 
     def _allocate(self):
@@ -507,7 +507,7 @@ class BatchedDemandResponseEnv:
         """int32 [1] view of the device cursor's time index (graph mode): what FusedActor.sample takes as ``step_dev``."""
         if not self.graph_mode:
             raise RuntimeError("graph_mode is off")
-        return self.t["cursor"][1:]
+        return self.t["cursor"][1:2]
 
     # ------------------------------------------------------------------ full normStateDict vector
     def _obs_spec(self, layout: str, with_links: bool = True) -> nat.MdrObsSpec:

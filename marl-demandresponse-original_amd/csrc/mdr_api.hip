@@ -254,7 +254,7 @@ int sync_cursor(mdr_env* env, hipStream_t s) {
   return MDR_OK;
 }
 
-// Graph mode: the launch carries table row 0 / 1 and the kernels add the device cursor; then one thread advances it.
+// Graph mode: the launch carries table row 0 / 1 and the kernels add the device cursor (StepArgs.cursor_adv: the last one moves it on).
 void graph_rows(const mdr_env* env, mdr::StepArgs* a) {
   const mdr_buffers_t& b = env->buf;
   a->od_old = b.tab_od;
@@ -506,11 +506,10 @@ int mdr_env_step(mdr_env_t* env, uint8_t* actions, int action_source, void* stre
   if (recording && mdr_env_graph_room(env) - env->captured < 1)
     return fail(env, MDR_ERR_INVALID, "graph mode: the next step lands on an interpolatePower update or past the time tables (mdr_env_graph_room() steps were recorded): run it un-captured");
   if (!recording) env->captured = 0;
+  if (graph) a.cursor_adv = env->buf.cursor;   // the step's last kernel moves the cursor on
   hipError_t e = mdr::launch_step(a, env->plan, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "step");
   if (graph) {
-    e = mdr::launch_cursor_advance(env->buf.cursor, (hipStream_t)stream);
-    if (e != hipSuccess) return hip_fail(env, e, "cursor_advance");
     if (recording) { env->captured += 1; return MDR_OK; }   // mdr_env_graph_replayed accounts for every replay (and runs a due interpolation update)
     env->dev_row += 1;
     env->dev_k += 1;
@@ -664,6 +663,7 @@ int mdr_env_step_begin_records(mdr_env_t* env, uint8_t* actions, int action_sour
     rc = sync_cursor(env, (hipStream_t)stream);
     if (rc != MDR_OK) return rc;
     graph_rows(env, &a);
+    a.cursor_adv = env->buf.cursor;   // k_step_partial notes the row for k_step_finish, which moves the cursor on
   }
   hipError_t e = mdr::launch_step_begin_split(a, false, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "step_begin_records");
@@ -688,13 +688,14 @@ static int step_end_impl(mdr_env_t* env, const double* gathered, const double* r
   a.world = world;
   const bool graph = graph_mode(env) && records != nullptr;      // the records pair is the graph-capable one
   const bool recording = graph && capturing((hipStream_t)stream);
-  if (graph) graph_rows(env, &a);
+  if (graph) {
+    graph_rows(env, &a);
+    a.cursor_adv = env->buf.cursor;   // k_step_finish moves the cursor on
+  }
   hipError_t e = mdr::launch_step_end_split(a, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "step_end");
   env->split_pending = false;
   if (graph) {
-    e = mdr::launch_cursor_advance(env->buf.cursor, (hipStream_t)stream);
-    if (e != hipSuccess) return hip_fail(env, e, "cursor_advance");
     if (recording) { env->captured += 1; return MDR_OK; }   // recorded, not run: mdr_env_graph_replayed accounts for every replay
     env->dev_row += 1;
     env->dev_k += 1;

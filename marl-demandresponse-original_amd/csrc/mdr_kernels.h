@@ -91,6 +91,7 @@ struct StepArgs {
   // so that a captured launch keeps stepping through the tables when it is replayed; nullptr = host-computed rows
   const int32_t* cursor;
   int32_t cursor_max;                  // last valid row (table_steps - 1): a graph replayed too often re-reads it instead of running off the tables
+  int32_t* cursor_adv;                 // graph mode: the step's LAST kernel moves the cursor on when its last workgroup retires (cursor[2] counts arrivals); else nullptr
   int64_t plane;                       // E * N: stride between observation planes
   int E, N, dt, penalty_mode, action_source, nblk;
   float c_temp;                        // alpha_temp / norm_temp_penalty
@@ -180,7 +181,6 @@ hipError_t launch_interp_base(const InterpArgs& a, hipStream_t s);
 hipError_t launch_patch_signal_plane(const StepArgs& a, hipStream_t s);   // obs plane 5 <- sig_old row
 hipError_t launch_pack_env(const StepArgs& a, int e, double temp_ref, const double* max_power, const double* ratio,
                            const double* abs_noise_row, double* out, hipStream_t s);
-hipError_t launch_cursor_advance(int32_t* cursor, hipStream_t s);                       // cursor[0] += 1, cursor[1] += 1
 hipError_t launch_cursor_set(int32_t* cursor, int32_t row, int32_t k, hipStream_t s);
 hipError_t launch_signal_error(const StepArgs& a, double* sq_signal_error_sum, hipStream_t s);   // += (sig_old - P)^2
 hipError_t launch_reset_obs(const StepArgs& a, hipStream_t s);  // uses sig_old = table row 0

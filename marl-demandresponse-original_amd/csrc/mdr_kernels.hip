@@ -312,6 +312,31 @@ __device__ __forceinline__ void rebase(ObsArgs& a) {
   a.k = a.cursor[1];
 }
 
+// Graph mode: the last workgroup of a step's last kernel moves the cursor on.  Every thread read the cursor first thing (rebase)
+// and then either left the kernel or waits at the barrier below, so when the last workgroup's thread 0 has counted all arrivals
+// nobody in this launch reads it any more; whatever reads it next is a later launch on the stream.  Saves each captured step a
+// one-thread launch of its own (~2 us of node-to-node latency on a 6-10 us step).  Thread 0 of every workgroup must get here.
+__device__ __forceinline__ void cursor_done(const StepArgs& a) {
+  if (a.cursor_adv == nullptr) return;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+  if (atomicAdd(reinterpret_cast<unsigned*>(a.cursor_adv + 3), 1u) == total - 1u) {
+    a.cursor_adv[3] = 0;
+    a.cursor_adv[0] += 1;
+    a.cursor_adv[1] += 1;
+  }
+}
+
+// The split pair needs no counting: k_step_partial notes the row in cursor[2], k_step_finish reads it from THERE - so nobody in
+// the finish launch reads cursor[0] / [1], and one of its threads moves them on whenever it likes.
+__device__ __forceinline__ void rebase_finish(StepArgs& a) {
+  if (a.cursor == nullptr) return;
+  const int64_t off = (int64_t)min(a.cursor_adv != nullptr ? a.cursor[2] : a.cursor[0], a.cursor_max) * a.E;
+  a.sig_old += off;
+  a.sig_new += off;
+}
+
 __global__ void k_cursor_advance(int32_t* cursor) {
   cursor[0] += 1;
   cursor[1] += 1;
@@ -320,6 +345,8 @@ __global__ void k_cursor_advance(int32_t* cursor) {
 __global__ void k_cursor_set(int32_t* cursor, int32_t row, int32_t k) {
   cursor[0] = row;
   cursor[1] = k;
+  cursor[2] = row;   // k_step_partial's note for k_step_finish
+  cursor[3] = 0;     // arrival counter of cursor_done
 }
 
 // Everything the dict adapter shows of env e after a step, as one fp64 vector (ONE launch + ONE device->host copy):
@@ -349,11 +376,6 @@ __global__ __launch_bounds__(256) void k_pack_env(StepArgs a, int e, double temp
 hipError_t launch_pack_env(const StepArgs& a, int e, double temp_ref, const double* max_power, const double* ratio,
                            const double* abs_noise_row, double* out, hipStream_t s) {
   hipLaunchKernelGGL(k_pack_env, dim3(1), dim3(256), 0, s, a, e, temp_ref, max_power, ratio, abs_noise_row, out);
-  return hipGetLastError();
-}
-
-hipError_t launch_cursor_advance(int32_t* cursor, hipStream_t s) {
-  hipLaunchKernelGGL(k_cursor_advance, dim3(1), dim3(1), 0, s, cursor);
   return hipGetLastError();
 }
 
@@ -623,6 +645,7 @@ __global__ __launch_bounds__(THREADS) void k_step_fused(StepArgs a) {
       store_reward_power<VEC>(a, base + h, pen, tot.sum_pen, tot.max_pen, sig_term, o_sig, o_pow);
     }
   }
+  cursor_done(a);
 }
 
 // Per-env table rows for the multi-step kernels: a window of W consecutive steps lives in W lanes (lane l holds the
@@ -835,6 +858,7 @@ __global__ __launch_bounds__(256) void k_step_group(StepArgs a) {
     store_reward_power<VEC>(a, i, pen, tot.sum_pen, tot.max_pen, sig_term, (float)(a.sig_new[e] * a.inv_obs_norm),
                             (float)(tot.sum_p * a.inv_obs_norm));
   }
+  cursor_done(a);
 }
 
 // ---- (2a) single-house envs (config.py's literal default nb_agents = 1; the Monte-Carlo grid): the "env" axis is the
@@ -894,6 +918,7 @@ __global__ __launch_bounds__(256) void k_step_single_house(StepArgs a) {
   store_out<4>(a.reward, e0, rew);
   store_out<4>(a.obs + 5 * a.plane, e0, c5);
   store_out<4>(a.obs + 6 * a.plane, e0, c6);
+  cursor_done(a);
 }
 
 // ---- (2b) multi-step closed loop for small envs: GROUP lanes per env, VEC houses per lane (the same mapping and the
@@ -1037,6 +1062,7 @@ __global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs r
 // houses: half the CUs idle and each busy one limited by what a single CU can stream).
 template <int VEC, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_step_partial(StepArgs a) {
+  if (a.cursor_adv != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.cursor_adv[2] = a.cursor[0];
   rebase(a);
   __shared__ double lds[3 * 4];
   const int e = blockIdx.y;
@@ -1101,7 +1127,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(StepArgs a) {
 //   else                tot_sum / tot_max as the caller left them (mdr_env_step_end).
 template <int VEC, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_step_finish(StepArgs a) {
-  rebase(a);
+  rebase_finish(a);
   __shared__ double lds[3 * 4];
   const int e = blockIdx.y;
   const int h = ((int)blockIdx.x * THREADS + (int)threadIdx.x) * VEC;
@@ -1136,7 +1162,13 @@ __global__ __launch_bounds__(THREADS) void k_step_finish(StepArgs a) {
     sum_pen = a.tot_sum[a.E + e];
     max_pen = (float)a.tot_max[e];
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.P[e] = P;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.P[e] = P;
+    if (a.cursor_adv != nullptr && e == 0) {   // see rebase_finish
+      a.cursor_adv[0] = a.cursor_adv[2] + 1;
+      a.cursor_adv[1] += 1;
+    }
+  }
   if (h >= a.N) return;
   const int64_t i = (int64_t)e * a.N + h;
   float pen[VEC];
@@ -2221,7 +2253,32 @@ hipError_t launch_rollout_fused(const StepArgs& a, const RolloutArgs& r, const S
   return hipGetLastError();
 }
 
-hipError_t launch_step(const StepArgs& a, const StepPlan& p, hipStream_t s) {
+// Graph mode, one-kernel steps: the last workgroup moves the cursor on (cursor_done) while the grid is small - the arrivals are
+// same-address device-scope atomics, ~9 ns apiece and serialised, so a big grid pays more for them than the one-thread launch
+// they replace costs (measured: +8.7 us at 977 workgroups, +0.3 us at 123).
+static int cursor_atomic_blocks() {
+  static const int v = [] {
+    const char* e = getenv("MDR_CURSOR_ATOMIC_BLOCKS");
+    return e ? atoi(e) : 128;
+  }();
+  return v;
+}
+
+static int64_t step_blocks(const StepArgs& a, const StepPlan& p) {
+  if (p.kind == STEP_SINGLE) return (a.E / 4 + 255) / 256;
+  if (p.kind == STEP_FUSED) return a.E;
+  return ((int64_t)a.E * p.threads + 255) / 256;
+}
+
+hipError_t launch_step(const StepArgs& args, const StepPlan& p, hipStream_t s) {
+  StepArgs a = args;
+  if (p.kind != STEP_SPLIT && a.cursor_adv != nullptr && step_blocks(a, p) > cursor_atomic_blocks()) {
+    a.cursor_adv = nullptr;
+    const hipError_t err = launch_step(a, p, s);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(k_cursor_advance, dim3(1), dim3(1), 0, s, args.cursor_adv);
+    return hipGetLastError();
+  }
   if (p.kind == STEP_SINGLE) {
     hipLaunchKernelGGL(k_step_single_house, dim3((unsigned)((a.E / 4 + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
