@@ -403,16 +403,14 @@ def run_rank(args):
 
     def give_up():
         with lock:
-            if printed[0]:
-                return
-            printed[0] = True
-            if rk.rank == 0:
+            if not printed[0] and rk.rank == 0:
                 pending = [n for n, _ in leg_list if n not in legs]
                 out = dict(legs)
                 out.update({n: {"error": "leg did not finish within %.0f s" % args.leg_timeout} for n in pending})
                 if baseline is not None:
                     out["cpu_baseline"] = baseline
                 emit(headline(out))
+            printed[0] = True
         os._exit(0)
 
     watchdog = threading.Timer(args.leg_timeout, give_up)
@@ -422,22 +420,22 @@ def run_rank(args):
         for name, leg in leg_list:
             try:
                 legs[name] = leg()
-            except Exception as exc:      # with several ranks a failure on one would leave the others inside a collective: fatal for all
-                if rk.world > 1:
-                    raise
+            except Exception as exc:
                 legs[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
-        watchdog.cancel()
+                if rk.world > 1:          # the ranks may no longer agree on what comes next: no further leg; the line goes out, and
+                    for other, _ in leg_list:   # if the others sit in a collective the watchdog ends them (and a hung close() here)
+                        legs.setdefault(other, {"error": "skipped: an earlier leg failed on this rank"})
+                    break
 
     with lock:
-        if printed[0]:
-            return
+        if rk.rank == 0 and not printed[0]:
+            line = headline(legs)
+            if baseline is not None:
+                line["cpu_baseline"] = baseline
+            emit(line)
         printed[0] = True
-    if rk.rank == 0:
-        line = headline(legs)
-        if baseline is not None:
-            line["cpu_baseline"] = baseline
-        emit(line)
-    rk.close()
+    rk.close()             # still under the watchdog: a barrier that never completes ends in os._exit(0), the line is out
+    watchdog.cancel()
 
 
 def main():
