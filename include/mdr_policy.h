@@ -30,9 +30,12 @@ enum mdr_actor_layout {
   MDR_ACTOR_FRAG32 = 0, /* v_mfma_f32_32x32x2_f32: 32 agents per wavefront, any num_state that fits the LDS */
   MDR_ACTOR_FRAG16 = 1, /* v_mfma_f32_16x16x4_f32: 16 agents per wavefront, hidden units padded to 112 instead of 128 rows and a
                            quarter of the accumulator registers; num_state <= 64 */
-  MDR_ACTOR_BF16X3 = 2  /* v_mfma_f32_16x16x32_bf16 on operands split into bf16 head + tail (x = xh + xl): w x ~ wh xh + wl xh +
+  MDR_ACTOR_BF16X3 = 2, /* v_mfma_f32_16x16x32_bf16 on operands split into bf16 head + tail (x = xh + xl): w x ~ wh xh + wl xh +
                            wh xl, fp32 accumulation - 16 significand bits per operand instead of 24 (probabilities within ~1e-5
                            of the fp32 forward) at 16 / 3 times the fp32 matrix rate; num_state <= 64.  frag1 / frag2 hold bf16 */
+  MDR_ACTOR_FRAG16T = 3 /* MDR_ACTOR_FRAG16 for hidden layers of 97..100 units (the reference's [100, 100]): six 16-row blocks on
+                           v_mfma_f32_16x16x4_f32 and the last 1..4 units of either layer on v_mfma_f32_4x4x1_16B_f32 (exact fp32,
+                           a third of the time of the block it replaces): ~9 % fewer matrix cycles per agent */
 };
 
 typedef struct mdr_actor {
@@ -54,11 +57,18 @@ typedef struct mdr_actor {
    *   frag1[s][lane][mb < 4]  = W1e[32 mb + r][h S1 + s]
    *   frag2[q][lane][mb < 4]  = W2e[32 mb + r][k2],  k2 = 32 (q >> 4) + (q & 3) + 8 ((q >> 2) & 3) + 4 h  (the accumulator row the lane holds)
    *   wdiff[mb < 4][reg < 16][h] = W3e[0][row] - W3e[1][row],  row = 32 mb + (reg & 3) + 8 (reg >> 2) + 4 h      (128 floats)
-   * MDR_ACTOR_FRAG16 (S1 = ceil(F / 4), S2 = 4 ceil(H1 / 16), r = lane & 15, g = lane >> 4); the biases start the accumulators:
+   * MDR_ACTOR_FRAG16 (S1 = ceil(F / 4), S2 = 4 floor(H1 / 16) + ceil((H1 % 16) / 4), r = lane & 15, g = lane >> 4); the biases start
+   * the accumulators.  Hidden-1 units of a partial last 16-row block are stored transposed - unit 16 b + j in row (of W1z, b1) /
+   * column (of W2z) 16 b + 4 (j % 4) + j / 4 - so that the block's first ceil((H1 % 16) / 4) k-steps of layer 2 carry them all:
    *   frag1[s][lane][mb < 8]  = W1z[16 mb + r][g S1 + s]
    *   frag2[q][lane][mb < 8]  = W2z[16 mb + r][16 (q >> 2) + 4 g + (q & 3)]
    *   wdiff (388 floats) = d[mb < 8][reg < 4][g < 4] | b1[mb][g][reg] | b2[mb][g][reg] | b3[0] - b3[1] | 0 0 0,
    *                        d = W3z[0][row] - W3z[1][row],  b1 / b2 at row (0 past H),  row = 16 mb + 4 g + reg
+   * MDR_ACTOR_FRAG16T: as MDR_ACTOR_FRAG16 with S2 = 25, except slot mb = 6 of every fragment and the tail's biases / head weights,
+   * u = 96 + (lane & 3) (zero past the layer's units):
+   *   frag1[s][lane][6] = W1[u][g S1 + s]      frag2[q < 24][lane][6] = W2[u][16 (q >> 2) + 4 g + (q & 3)]
+   *   frag2[24][lane][mb < 6] = W2z[16 mb + r][96 + g]      frag2[24][lane][6] = W2[u][96 + g]
+   *   d[6][reg][g] = (g == 0) (W3[0][96 + reg] - W3[1][96 + reg]),  b1 / b2 [6][g][reg] = (g == 0) b[96 + reg]
    * MDR_ACTOR_BF16X3 (S1 = ceil(F / 32), S2 = 4, r = lane & 15, g = lane >> 4, fragments of 8 bf16, t = 0 head / 1 tail):
    *   frag1[s][mb < 8][t][lane][j < 8] = split_t(W1z[16 mb + r][(4 s + g) 8 + j])
    *   frag2[s][mb < 8][t][lane][j < 8] = split_t(W2z[16 mb + r][16 (2 s + (j >> 2)) + 4 g + (j & 3)])

@@ -181,7 +181,30 @@ __global__ __launch_bounds__(64 * WAVES) void k_actor_sample(ActorArgs a) {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int WAVES16 = 16;
 
-template <int MB>
+// MDR_ACTOR_FRAG16T: the last of the MB blocks holds at most 4 hidden units (the reference's 100 = 6 x 16 + 4) and runs on
+// v_mfma_f32_4x4x1_16B_f32 instead - 16 independent 4x4 outer products, block = lane >> 2: D[v](lane) += A(lane (lane & ~3) + v) *
+// B(lane).  With B the same operand the 16-row blocks take (lane = 16 g + agent: the value of k-index g) and A(lane) = W[unit
+// 96 + (lane & 3)][that k], register v of a lane collects unit 96 + v for the lane's agent over its group's share of k; the four
+// groups are summed once per layer.  A third of the time of the 16x16x4 instruction it replaces (4.9 vs 15.0 ns per SIMD,
+// tools/probe/mfma4x4_probe.hip), for a block that would run three quarters empty.
+template <bool TAIL_BLOCK>
+__device__ __forceinline__ f32x4 mma16(float w, float b, f32x4 c) {
+  if (TAIL_BLOCK) return __builtin_amdgcn_mfma_f32_4x4x1f32(w, b, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(w, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 sum_lane_groups(f32x4 v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[i] += __shfl_xor(v[i], 16);
+    v[i] += __shfl_xor(v[i], 32);
+  }
+  return v;
+}
+
+__device__ __forceinline__ float pick_register(f32x4 v, int g) { return g == 0 ? v[0] : (g == 1 ? v[1] : (g == 2 ? v[2] : v[3])); }
+
+template <int MB, bool TAIL>
 __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* f1 = lds;                       // [S1][64][8]
@@ -237,9 +260,10 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
         const float4 w1 = *reinterpret_cast<const float4*>(f1 + s * 512 + lane * 8 + 4);
         const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[mb], xr[s], acc[mb], 0, 0, 0);
+        for (int mb = 0; mb < MB; ++mb) acc[mb] = mb == MB - 1 ? mma16<TAIL>(w[mb], xr[s], acc[mb]) : mma16<false>(w[mb], xr[s], acc[mb]);
       }
     }
+    if (TAIL) acc[MB - 1] = sum_lane_groups(acc[MB - 1]);   // units 96 + v of the lane's agent, in every lane group (bias: group 0 brought it)
     // ---- layer 2 (the next tile's features are loaded between its k-steps, one per step)
     const bool more = t + nwaves < a.ntiles;
     const float* xn = row_of(more ? t + nwaves : t);
@@ -250,14 +274,15 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
     for (int q = 0; q < 4 * MB; ++q) {
       if (q < 16 && q < a.S1 && more) xr[q < 16 ? q : 0] = feature(xn, q);
       if (q < a.S2) {
-        const float b = relu(acc[q >> 2][q & 3]);
+        const float b = relu(TAIL && q >= 4 * (MB - 1) ? pick_register(acc[MB - 1], g) : acc[q >> 2][q & 3]);   // tail: k-index g is unit 96 + g
         const float4 w0 = *reinterpret_cast<const float4*>(f2 + q * 512 + lane * 8);
         const float4 w1 = *reinterpret_cast<const float4*>(f2 + q * 512 + lane * 8 + 4);
         const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) out[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[mb], b, out[mb], 0, 0, 0);
+        for (int mb = 0; mb < MB; ++mb) out[mb] = mb == MB - 1 ? mma16<TAIL>(w[mb], b, out[mb]) : mma16<false>(w[mb], b, out[mb]);
       }
     }
+    if (TAIL) out[MB - 1] = sum_lane_groups(out[MB - 1]);
     // ---- head: this lane's 4 MB rows, then the other three lane groups'
     float d = 0.0f;
 #pragma unroll
@@ -893,7 +918,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
 }
 
 // ---- exact-fp32 form (v_mfma_f32_16x16x4_f32): 16 agents per wavefront, lane group g holds features [13 g, 13 g + 13) of its agent
-template <int MB, bool STORE, bool GEN>
+template <int MB, bool STORE, bool GEN, bool TAIL>
 __global__ __launch_bounds__(64 * WAVES16) void k_actor_observe16(ActorArgs a, mdr::ObserveArgs o) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TILE = 16, WIN = TILE * OBS_ROW + OBS_PAD, S1 = 13;
@@ -980,8 +1005,9 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_observe16(ActorArgs a, m
       const float4 w1 = *reinterpret_cast<const float4*>(f1 + s * 512 + lane * 8 + 4);
       const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[mb], xr[s], acc[mb], 0, 0, 0);
+      for (int mb = 0; mb < MB; ++mb) acc[mb] = mb == MB - 1 ? mma16<TAIL>(w[mb], xr[s], acc[mb]) : mma16<false>(w[mb], xr[s], acc[mb]);
     }
+    if (TAIL) acc[MB - 1] = sum_lane_groups(acc[MB - 1]);
     // ---- layer 2; the next tile's rows are staged after a few k-steps, read back at the end
     f32x4 out[MB];
 #pragma unroll
@@ -993,14 +1019,15 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_observe16(ActorArgs a, m
         else observe_stage<TILE>(o, nxt, rows, lane);
       }
       if (q < a.S2) {
-        const float b = relu(acc[q >> 2][q & 3]);
+        const float b = relu(TAIL && q >= 4 * (MB - 1) ? pick_register(acc[MB - 1], g) : acc[q >> 2][q & 3]);   // tail: k-index g is unit 96 + g
         const float4 w0 = *reinterpret_cast<const float4*>(f2 + q * 512 + lane * 8);
         const float4 w1 = *reinterpret_cast<const float4*>(f2 + q * 512 + lane * 8 + 4);
         const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) out[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[mb], b, out[mb], 0, 0, 0);
+        for (int mb = 0; mb < MB; ++mb) out[mb] = mb == MB - 1 ? mma16<TAIL>(w[mb], b, out[mb]) : mma16<false>(w[mb], b, out[mb]);
       }
     }
+    if (TAIL) out[MB - 1] = sum_lane_groups(out[MB - 1]);
     if (more) {
       observe_window_fence();
       gather((t + nwaves) * TILE);
@@ -1054,12 +1081,12 @@ int blocks16(int h1, int h2) { return ((h1 > h2 ? h1 : h2) <= 112) ? 7 : 8; }   
 
 int steps1(int layout, int num_state) {
   if (layout == MDR_ACTOR_BF16X3) return (num_state + 31) / 32;   // ceil(F / 32)
-  return layout == MDR_ACTOR_FRAG16 ? (num_state + 3) / 4 : (num_state + 2) / 2;   // FRAG16: no constant-1 feature
+  return layout == MDR_ACTOR_FRAG16 || layout == MDR_ACTOR_FRAG16T ? (num_state + 3) / 4 : (num_state + 2) / 2;   // FRAG16: no constant-1 feature
 }
 
 int steps2(int layout, int hidden1) {
   if (layout == MDR_ACTOR_BF16X3) return 4;                           // k-steps of two 16-row blocks each: all 8 stored blocks
-  if (layout == MDR_ACTOR_FRAG16) return 4 * ((hidden1 + 15) / 16);   // every register of the 16-row blocks holding rows < hidden1
+  if (layout == MDR_ACTOR_FRAG16 || layout == MDR_ACTOR_FRAG16T) return 4 * (hidden1 / 16) + (hidden1 % 16 + 3) / 4;   // a partial last block is stored transposed: its first ceil(rem / 4) registers hold it
   int n = 0;                                                             // FRAG32: (block, register) pairs whose half-0 row is <= hidden1
   for (int q = 0; q < 64; ++q)
     if (acc_row_half0(q) <= hidden1) ++n;
@@ -1067,10 +1094,18 @@ int steps2(int layout, int hidden1) {
 }
 
 int floats_per_step(int layout) {   // 4-byte units per k-step: 64 lanes x (4 | 8 floats), or 8 row blocks x (head, tail) x 64 lanes x 8 bf16
-  return layout == MDR_ACTOR_BF16X3 ? 4096 : (layout == MDR_ACTOR_FRAG16 ? 512 : 256);
+  return layout == MDR_ACTOR_BF16X3 ? 4096 : (layout == MDR_ACTOR_FRAG16 || layout == MDR_ACTOR_FRAG16T ? 512 : 256);
 }
 
-bool layout_ok(int layout) { return layout == MDR_ACTOR_FRAG32 || layout == MDR_ACTOR_FRAG16 || layout == MDR_ACTOR_BF16X3; }
+bool layout_ok(int layout) {
+  return layout == MDR_ACTOR_FRAG32 || layout == MDR_ACTOR_FRAG16 || layout == MDR_ACTOR_BF16X3 || layout == MDR_ACTOR_FRAG16T;
+}
+
+// MDR_ACTOR_FRAG16T: six full 16-row blocks and a tail of 1..4 units in both hidden layers (the reference's [100, 100])
+bool tail_shape_ok(const mdr_actor_t* actor) {
+  return actor->hidden1 / 16 == 6 && actor->hidden2 / 16 == 6 && actor->hidden1 % 16 >= 1 && actor->hidden1 % 16 <= 4 &&
+         actor->hidden2 % 16 >= 1 && actor->hidden2 % 16 <= 4;
+}
 
 }  // namespace
 
@@ -1081,7 +1116,8 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
   if (!actor || actor->struct_size != sizeof(mdr_actor_t) || !action) return MDR_ERR_INVALID;
   if (!actor->frag1 || !actor->frag2 || !actor->wdiff) return MDR_ERR_INVALID;
   const int layout = actor->layout;
-  if (layout != MDR_ACTOR_FRAG16 && layout != MDR_ACTOR_BF16X3) return MDR_ERR_UNSUPPORTED;
+  if (layout != MDR_ACTOR_FRAG16 && layout != MDR_ACTOR_BF16X3 && layout != MDR_ACTOR_FRAG16T) return MDR_ERR_UNSUPPORTED;
+  if (layout == MDR_ACTOR_FRAG16T && !tail_shape_ok(actor)) return MDR_ERR_UNSUPPORTED;
   if (actor->feature_order != 1 || actor->num_state != 4 * OBS_C + 11) return MDR_ERR_UNSUPPORTED;
   if (actor->hidden1 <= 0 || actor->hidden2 <= 0 || actor->hidden1 > MDR_ACTOR_MAX_HIDDEN || actor->hidden2 > MDR_ACTOR_MAX_HIDDEN) return MDR_ERR_INVALID;
   const bool lbf = layout == MDR_ACTOR_BF16X3;
@@ -1116,11 +1152,16 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
     return hipGetLastError() == hipSuccess ? MDR_OK : MDR_ERR_HIP;
   };
   const int mb = blocks16(actor->hidden1, actor->hidden2);
-#define MDR_OBSERVE_VARIANT(KERNEL, MBV)                                                     \
-  (rows_out ? (gen ? launch(KERNEL<MBV, true, true>) : launch(KERNEL<MBV, true, false>))   \
-            : (gen ? launch(KERNEL<MBV, false, true>) : launch(KERNEL<MBV, false, false>)))
+#define MDR_OBSERVE_VARIANT(KERNEL, ...)                                                                     \
+  (rows_out ? (gen ? launch(KERNEL<__VA_ARGS__, true, true>) : launch(KERNEL<__VA_ARGS__, true, false>))   \
+            : (gen ? launch(KERNEL<__VA_ARGS__, false, true>) : launch(KERNEL<__VA_ARGS__, false, false>)))
+#define MDR_OBSERVE16_VARIANT(MBV, TAILV)                                                                                  \
+  (rows_out ? (gen ? launch(k_actor_observe16<MBV, true, true, TAILV>) : launch(k_actor_observe16<MBV, true, false, TAILV>))   \
+            : (gen ? launch(k_actor_observe16<MBV, false, true, TAILV>) : launch(k_actor_observe16<MBV, false, false, TAILV>)))
   if (lbf) return mb == 7 ? MDR_OBSERVE_VARIANT(k_actor_observe_bf16, 7) : MDR_OBSERVE_VARIANT(k_actor_observe_bf16, 8);
-  return mb == 7 ? MDR_OBSERVE_VARIANT(k_actor_observe16, 7) : MDR_OBSERVE_VARIANT(k_actor_observe16, 8);
+  if (layout == MDR_ACTOR_FRAG16T) return MDR_OBSERVE16_VARIANT(7, true);
+  return mb == 7 ? MDR_OBSERVE16_VARIANT(7, false) : MDR_OBSERVE16_VARIANT(8, false);
+#undef MDR_OBSERVE16_VARIANT
 #undef MDR_OBSERVE_VARIANT
 }
 
@@ -1150,7 +1191,8 @@ int mdr_actor_sample(const mdr_actor_t* actor, const float* obs, int64_t obs_pla
   if (nb_agents == 0) return MDR_OK;
   const int layout = actor->layout;
   const bool lbf = layout == MDR_ACTOR_BF16X3;
-  const bool l16 = layout == MDR_ACTOR_FRAG16 || lbf;             // 16 agents per wavefront
+  const bool l16 = layout == MDR_ACTOR_FRAG16 || layout == MDR_ACTOR_FRAG16T || lbf;             // 16 agents per wavefront
+  if (layout == MDR_ACTOR_FRAG16T && !tail_shape_ok(actor)) return MDR_ERR_UNSUPPORTED;
   if (l16 && actor->num_state > 64) return MDR_ERR_UNSUPPORTED;   // 16 features per lane: pack FRAG32 instead
   ActorArgs a{};
   a.frag1 = static_cast<const float*>(actor->frag1); a.frag2 = static_cast<const float*>(actor->frag2); a.wdiff = actor->wdiff;
@@ -1178,7 +1220,8 @@ int mdr_actor_sample(const mdr_actor_t* actor, const float* obs, int64_t obs_pla
   };
   const int mb = blocks16(actor->hidden1, actor->hidden2);
   if (lbf) return mb == 7 ? launch(k_actor_sample_bf16<7>) : launch(k_actor_sample_bf16<8>);
-  if (l16) return mb == 7 ? launch(k_actor_sample16<7>) : launch(k_actor_sample16<8>);
+  if (layout == MDR_ACTOR_FRAG16T) return launch(k_actor_sample16<7, true>);
+  if (l16) return mb == 7 ? launch(k_actor_sample16<7, false>) : launch(k_actor_sample16<8, false>);
   if (a.S1 <= 32 && a.S2 == 52) return launch(k_actor_sample<32, 52>);   // the reference's shape: num_state <= 62, layers [100, 100]
   if (a.S1 <= 32) return launch(k_actor_sample<32, 0>);
   return launch(k_actor_sample<0, 0>);

@@ -17,7 +17,7 @@ from . import _native as nat
 MAX_HIDDEN = 127
 
 
-FRAG32, FRAG16, BF16X3 = 0, 1, 2
+FRAG32, FRAG16, BF16X3, FRAG16T = 0, 1, 2, 3
 FEATURES_NORMSTATE, FEATURES_OBSERVE = 0, 1
 OBSERVE_NUM_STATE = 51      # the reference's default observation: 11 own features + 10 neighbours x 4 message fields
 
@@ -60,8 +60,10 @@ class FusedActor:
             raise ValueError("expected Linear(F,H1) - Linear(H1,H2) - Linear(H2,2)")
         if H1 > MAX_HIDDEN or H2 > MAX_HIDDEN:
             raise ValueError("hidden layers of at most %d units" % MAX_HIDDEN)
-        if layout is None:
-            layout = FRAG16 if F <= 64 else FRAG32
+        if layout is None:      # exact fp32; hidden layers of 97..100 units (the reference's [100, 100]) take the 4x4-tail form
+            layout = (FRAG16T if self._tail_shape(H1, H2) else FRAG16) if F <= 64 else FRAG32
+        if layout == FRAG16T and not self._tail_shape(H1, H2):
+            raise ValueError("FRAG16T needs hidden layers of 97..100 units")
         self.layout = int(layout)
         self.greedy = bool(greedy)      # argmax instead of a draw: the reference's DQNAgent.act on a DQN_network
         self.num_state, self.hidden1, self.hidden2 = int(F), int(H1), int(H2)
@@ -74,8 +76,9 @@ class FusedActor:
             self._pack_bf16x3(w1, b1, w2, b2, w3, b3, S1, S2)
             return
         lane = np.arange(64)
-        kw = 4 if self.layout == FRAG16 else 2                                  # k per MFMA step
-        bw = 16 if self.layout == FRAG16 else 32                                # rows per block
+        f16 = self.layout in (FRAG16, FRAG16T)
+        kw = 4 if f16 else 2                                                    # k per MFMA step
+        bw = 16 if f16 else 32                                                  # rows per block
         nb = 128 // bw                                                          # blocks stored per lane (8 | 4)
         r, g = lane & (bw - 1), lane // bw                                      # row in block, lane group (= k within a step)
         rows = bw * np.arange(nb)[:, None] + r[None, :]                         # [mb, lane] output row of the fragment
@@ -83,14 +86,21 @@ class FusedActor:
         w1e = torch.zeros((128, kw * S1))
         w2e = torch.zeros((128, 128))
         w3e = torch.zeros((2, 128))
-        w1e[:H1, :F], w2e[:H2, :H1], w3e[:, :H2] = w1, w2, w3
+        pos1 = torch.from_numpy(self._unit_rows(H1))                            # row of w1e / column of w2e that holds hidden-1 unit u
+        w1e[pos1, :F], w2e[:H2, pos1], w3e[:, :H2] = w1, w2, w3
         if self.layout == FRAG32:      # biases as a constant-1 input feature / hidden unit
             w1e[:H1, F], w1e[H1, F] = b1, 1.0
             w2e[:H2, H1], w2e[H2, H1] = b2, 1.0
             w3e[:, H2] = b3
         k1 = g[None, :] * S1 + np.arange(S1)[:, None]                           # [s, lane]
         q = np.arange(S2)
-        if self.layout == FRAG16:
+        rows1, rows2 = rows, rows.copy()                                        # rows of w1e (unit positions) / w2e (hidden-2 units)
+        if self.layout == FRAG16T:      # slot 6 feeds v_mfma_f32_4x4x1: lane -> unit 96 + (lane & 3) (row 127 is zero)
+            u = 96 + (lane & 3)
+            rows1, rows2 = rows.copy(), rows.copy()
+            rows1[6] = np.where(u < H1, 96 + 4 * (lane & 3), 127)      # position of unit u (see _unit_rows)
+            rows2[6] = np.where(u < H2, u, 127)
+        if f16:
             k2 = 16 * (q >> 2)[:, None] + 4 * g[None, :] + (q & 3)[:, None]     # [q, lane]: the accumulator row the lane holds
             reg = np.arange(4)
             row3 = 16 * np.arange(8)[:, None, None] + 4 * np.arange(4)[None, None, :] + reg[None, :, None]        # [mb, reg, g]
@@ -99,10 +109,12 @@ class FusedActor:
             reg = np.arange(16)
             row3 = 32 * np.arange(4)[:, None, None] + _acc_row(reg[None, :, None], np.arange(2)[None, None, :])   # [mb, reg, h]
         k2 = np.minimum(k2, 127)
-        frag1 = w1e[torch.from_numpy(rows)[None, :, :], torch.from_numpy(k1)[:, None, :]].permute(0, 2, 1)   # [S1, 64, nb]
-        frag2 = w2e[torch.from_numpy(rows)[None, :, :], torch.from_numpy(k2)[:, None, :]].permute(0, 2, 1)   # [S2, 64, nb]
+        if self.layout == FRAG16T:      # the tail's head weights count once: lane group 0 holds them
+            row3[6] = np.where(np.arange(4)[None, :] == 0, np.where(96 + reg < H2, 96 + reg, 127)[:, None], 127)
+        frag1 = w1e[torch.from_numpy(rows1)[None, :, :], torch.from_numpy(k1)[:, None, :]].permute(0, 2, 1)   # [S1, 64, nb]
+        frag2 = w2e[torch.from_numpy(rows2)[None, :, :], torch.from_numpy(k2)[:, None, :]].permute(0, 2, 1)   # [S2, 64, nb]
         wdiff = (w3e[0] - w3e[1])[torch.from_numpy(row3)].reshape(-1)
-        if self.layout == FRAG16:      # biases start the accumulators: appended behind the head weights
+        if f16:      # biases start the accumulators: appended behind the head weights
             wdiff = torch.cat([wdiff, self._bias_block(b1, b2, b3)])
         self._frag1 = frag1.contiguous().to(self.device)
         self._frag2 = frag2.contiguous().to(self.device)
@@ -113,14 +125,34 @@ class FusedActor:
         self._desc = MdrActor(C.sizeof(MdrActor), self.layout, F, H1, H2, int(self.greedy), self.feature_order, 0, self._frag1.data_ptr(), self._frag2.data_ptr(),
                               self._wdiff.data_ptr())
 
+    @staticmethod
+    def _tail_shape(h1: int, h2: int) -> bool:
+        return 97 <= h1 <= 100 and 97 <= h2 <= 100
+
+    def _unit_rows(self, hidden1: int) -> np.ndarray:
+        """Row that holds hidden-1 unit u.  MDR_ACTOR_FRAG16 stores the units of a partial last 16-row block transposed (unit
+        16 b + j at row 16 b + 4 (j % 4) + j // 4): k-step q of layer 2 feeds the rows 16 (q >> 2) + 4 g + (q & 3), so the block's
+        first ceil(rem / 4) k-steps then carry all of its units and the others are skipped (100 units: 25 k-steps, not 28)."""
+        u = np.arange(hidden1)
+        if self.layout not in (FRAG16, FRAG16T):
+            return u
+        j = u & 15
+        return np.where(u >= 16 * (hidden1 // 16), (u & ~15) + 4 * (j & 3) + (j >> 2), u)
+
     def _bias_block(self, b1, b2, b3) -> torch.Tensor:
         """b1[mb][g][reg] | b2[mb][g][reg] | b3[0] - b3[1] | 0 0 0  (row = 16 mb + 4 g + reg), 260 floats."""
         b1e, b2e = torch.zeros(128), torch.zeros(128)
-        b1e[:self.hidden1], b2e[:self.hidden2] = b1, b2
-        rowb = torch.from_numpy(16 * np.arange(8)[:, None, None] + 4 * np.arange(4)[None, :, None] + np.arange(4)[None, None, :])
+        b1e[torch.from_numpy(self._unit_rows(self.hidden1))], b2e[:self.hidden2] = b1, b2
+        rowb = 16 * np.arange(8)[:, None, None] + 4 * np.arange(4)[None, :, None] + np.arange(4)[None, None, :]      # [mb, g, reg]
+        rowb1, rowb2 = rowb.copy(), rowb.copy()
+        if self.layout == FRAG16T:      # the tail's biases count once: lane group 0 starts its accumulators with them
+            reg = np.arange(4)
+            rowb1[6] = np.where(np.arange(4)[:, None] == 0, np.where(96 + reg < self.hidden1, 96 + 4 * reg, 127)[None, :], 127)
+            rowb2[6] = np.where(np.arange(4)[:, None] == 0, np.where(96 + reg < self.hidden2, 96 + reg, 127)[None, :], 127)
+        rowb1, rowb2 = torch.from_numpy(rowb1), torch.from_numpy(rowb2)
         tail = torch.zeros(4)
         tail[0] = b3[0] - b3[1]
-        return torch.cat([b1e[rowb].reshape(-1), b2e[rowb].reshape(-1), tail])
+        return torch.cat([b1e[rowb1].reshape(-1), b2e[rowb2].reshape(-1), tail])
 
     def _pack_bf16x3(self, w1, b1, w2, b2, w3, b3, S1, S2):
         """MDR_ACTOR_BF16X3: every weight as a bf16 head + tail, fragments of 8 k-values per lane (include/mdr_policy.h)."""

@@ -73,14 +73,14 @@ def _discounted_returns_hip(reward, done, gamma, bootstrap):
 def _fused_policy(actor, dev, precision: str = "fp32", observe: bool = False):
     """FusedActor of `actor`, re-packed only when a parameter changed (torch bumps `_version` on in-place updates).
     ``observe``: packed for ``FusedActor.sample_env`` (W1's columns in the order the observe -> act kernels stage the features)."""
-    from .policy import BF16X3, FEATURES_NORMSTATE, FEATURES_OBSERVE, FRAG16, FusedActor
+    from .policy import BF16X3, FEATURES_NORMSTATE, FEATURES_OBSERVE, FusedActor
     if precision not in ("fp32", "bf16x3"):
         raise ValueError("policy_precision must be 'fp32' or 'bf16x3'")
     key = tuple((p.data_ptr(), p._version) for p in actor.parameters()) + (str(dev), precision)
     slot = "_mdr_fused_observe" if observe else "_mdr_fused"
     cached = getattr(actor, slot, None)
     if cached is None or cached[0] != key:
-        layout = BF16X3 if precision == "bf16x3" and actor.fc[0].in_features <= 64 else (FRAG16 if observe else None)
+        layout = BF16X3 if precision == "bf16x3" and actor.fc[0].in_features <= 64 else None      # None: the exact-fp32 form that fits
         cached = (key, FusedActor.from_module(actor, device=dev, layout=layout,
                                               feature_order=FEATURES_OBSERVE if observe else FEATURES_NORMSTATE))
         setattr(actor, slot, cached)

@@ -48,7 +48,7 @@ def _walk(env, steps, seed):
 @pytest.mark.parametrize("E,N", [(3, 32), (5, 64), (2, 1024), (33, 96), (1, 4096), (700, 160),
                                  # any cluster size: tiles that start inside an env, span up to four envs, end in a partial tile
                                  (100, 20), (37, 50), (5, 11), (3, 33), (9, 100), (1, 1000), (7, 31), (64, 12), (2, 4100), (1, 13)])
-@pytest.mark.parametrize("layout,layers", [(1, (100, 100)), (2, (100, 100)), (1, (127, 120)), (2, (64, 32))])
+@pytest.mark.parametrize("layout,layers", [(1, (100, 100)), (2, (100, 100)), (1, (127, 120)), (2, (64, 32)), (3, (100, 100)), (3, (97, 99))])
 def test_observe_act_equals_rows_then_actor(E, N, layout, layers):
     import mdr_amd
     from mdr_amd.policy import FEATURES_OBSERVE, FusedActor
@@ -201,7 +201,7 @@ for E, N in ((40, 64), (3, 1024), (9, 96)):
     _walk(env, 5, seed=1)
     rows = env.obs_vector("rows").view(E * N, 51)
     actor = _actor(seed=N)
-    for layout in (1, 2):
+    for layout in (1, 2, 3):
         a0, p0, probs0 = FusedActor.from_module(actor, layout=layout).sample(rows, 4, 1, want_probs=True)
         kept = torch.empty_like(rows)
         a1, p1, probs1 = FusedActor.from_module(actor, layout=layout, feature_order=FEATURES_OBSERVE).sample_env(env, 4, 1, want_probs=True, rows_out=kept)
@@ -230,7 +230,7 @@ def test_fuzz_observe_act_vs_rows(idx):
     _walk(env, int(rng.integers(0, 9)), seed=idx)
     rows = env.obs_vector("rows").view(E * N, 51)
     actor = _actor(seed=idx)
-    for layout in (1, 2):
+    for layout in (1, 2, 3):
         kept = torch.full((E * N, 51), float("nan"), device="cuda:0")
         a0, _, probs0 = FusedActor.from_module(actor, layout=layout).sample(rows, 3, idx, want_probs=True)
         a1, _, probs1 = FusedActor.from_module(actor, layout=layout, feature_order=FEATURES_OBSERVE).sample_env(env, 3, idx, want_probs=True, rows_out=kept)

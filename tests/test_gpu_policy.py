@@ -23,10 +23,15 @@ def _actor(F, layers, seed=0, scale=1.0):
 
 @pytest.mark.parametrize("A,F,layers", [(1, 51, (100, 100)), (31, 51, (100, 100)), (33, 51, (100, 100)), (1000, 51, (100, 100)),
                                         (4097, 47, (100, 100)), (777, 133, (100, 100)), (500, 11, (64, 32)), (300, 51, (127, 127)),
-                                        (300, 50, (1, 1)), (300000, 51, (100, 100))])
-@pytest.mark.parametrize("layout", [0, 1, 2])
+                                        (300, 50, (1, 1)), (300000, 51, (100, 100)), (1000, 51, (97, 100)), (999, 33, (100, 98)),
+                                        (50, 64, (99, 97))])
+@pytest.mark.parametrize("layout", [0, 1, 2, 3])
 def test_fused_actor_matches_torch_forward(A, F, layers, layout):
     from mdr_amd.policy import FusedActor
+    if layout == 3 and not all(97 <= h <= 100 for h in layers):      # the 4x4-tail form: hidden layers of 6 x 16 + (1..4) units
+        with pytest.raises(ValueError):
+            FusedActor.from_module(_actor(min(F, 64), layers), layout=3)
+        return
     if layout >= 1 and F > 64:
         with pytest.raises(RuntimeError):
             FusedActor.from_module(_actor(F, layers), layout=1).sample(torch.zeros((4, F), device="cuda:0"), 0, 0)
@@ -48,12 +53,13 @@ def test_fused_actor_matches_torch_forward(A, F, layers, layout):
     assert float((probs.sum(1) - 1).abs().max()) < 1e-6
 
 
-@pytest.mark.parametrize("layout", [0, 1, 2])
-def test_weight_layout_is_checked_with_asymmetric_integer_data(layout):
+@pytest.mark.parametrize("layout,H1,H2", [(0, 100, 100), (1, 100, 100), (2, 100, 100), (3, 100, 100), (3, 98, 99), (3, 97, 100), (1, 98, 99),
+                                          (1, 101, 37)])
+def test_weight_layout_is_checked_with_asymmetric_integer_data(layout, H1, H2):
     """Exact small-integer weights and inputs (every product and sum exact in fp32): the logits' difference must be exact,
     which a swapped A/B operand, a wrong k order between the layers or a transposed block would not survive."""
     from mdr_amd.policy import FusedActor
-    F, H1, H2, A = 51, 100, 100, 257
+    F, A = 51, 257
     rng = np.random.default_rng(0)
     w1 = rng.integers(-2, 3, (H1, F)).astype(np.float32)
     b1 = rng.integers(-3, 4, H1).astype(np.float32)
@@ -61,6 +67,10 @@ def test_weight_layout_is_checked_with_asymmetric_integer_data(layout):
     b2 = rng.integers(-3, 4, H2).astype(np.float32)
     w3 = rng.integers(-1, 2, (2, H2)).astype(np.float32) * (rng.random((2, H2)) < 0.3)
     b3 = np.array([1.0, -2.0], dtype=np.float32)
+    if H1 > 96 and H2 > 96:      # the units of the partial last block count, every one differently
+        w2[:, 96:H1] = rng.integers(1, 3, (H2, H1 - 96)) * np.array([1, -1, 1, -1])[:H1 - 96]
+        w3[0, 96:H2] = np.arange(1, H2 - 95)
+        w3[1, 96:H2] = -1
     x = rng.integers(-2, 3, (A, F)).astype(np.float32)
     h1 = np.maximum(x.astype(np.float64) @ w1.T + b1, 0)
     h2 = np.maximum(h1 @ w2.T + b2, 0)
@@ -115,7 +125,7 @@ def test_fused_actor_argument_checks():
         fused.sample(torch.zeros((4, 51), device="cuda:0", dtype=torch.float64), 0, 0)
 
 
-@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("layout", [0, 1, 2, 3])
 @pytest.mark.parametrize("A,F", [(1000, 51), (4097, 47), (33, 11)])
 def test_feature_plane_input_gives_the_same_bits_as_rows(A, F, layout):
     """obs as feature planes [F][stride] (what mdr_env_obs_vector MDR_OBS_PLANES writes) instead of rows [A][F]."""
@@ -138,7 +148,7 @@ def test_feature_plane_input_gives_the_same_bits_as_rows(A, F, layout):
     assert torch.equal(a0, a4)
 
 
-@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("layout", [0, 1, 2, 3])
 def test_greedy_mode_is_the_argmax_of_a_dqn_network(layout):
     """DQNAgent.act (agents/rl_controllers.py:53-60): the same Linear/ReLU stack, action = argmax of its two outputs."""
     from mdr_amd.policy import FusedActor
@@ -158,15 +168,17 @@ def test_greedy_mode_is_the_argmax_of_a_dqn_network(layout):
     assert torch.equal(a[clear].long(), q.argmax(1)[clear])
 
 
-@pytest.mark.parametrize("idx", range(48))
+@pytest.mark.parametrize("idx", range(64))
 def test_fuzz_random_network_shapes(idx):
-    """Random (F, H1, H2, A) at every padding edge of the three layouts against the torch forward."""
+    """Random (F, H1, H2, A) at every padding edge of the four layouts against the torch forward."""
     from mdr_amd.policy import FusedActor
     rng = np.random.default_rng(100 + idx)
-    layout = idx % 3
+    layout = idx % 4
     F = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 47, 50, 51, 52, 62, 63, 64] + ([65, 100, 133] if layout == 0 else [])))
     H1 = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 95, 96, 97, 100, 111, 112, 113, 126, 127]))
     H2 = int(rng.choice([1, 3, 16, 17, 32, 48, 64, 99, 100, 111, 112, 113, 127]))
+    if layout == 3:
+        H1, H2 = int(rng.integers(97, 101)), int(rng.integers(97, 101))
     A = int(rng.choice([1, 15, 16, 17, 31, 32, 33, 63, 64, 65, 1000, 4099]))
     actor = _actor(F, (H1, H2), seed=idx, scale=2.0)
     fused = FusedActor.from_module(actor, layout=layout)
