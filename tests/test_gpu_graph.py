@@ -313,13 +313,16 @@ def test_capture_of_a_step_that_lands_on_an_update_is_refused():
             a.step_bangbang()
 
 
-def test_one_graph_may_hold_several_steps_but_not_more_than_the_tables_cover():
+@pytest.mark.parametrize("E,N", [(5, 64), (4096, 1), (300, 1024), (2, 9000), (100, 20)])
+def test_one_graph_may_hold_several_steps_but_not_more_than_the_tables_cover(E, N):
     """A capture may record up to graph_room() steps (each replay then counts as that many); the call that would record one more is
-    refused - a replay would walk the device cursor past the time tables."""
+    refused - a replay would walk the device cursor past the time tables.  The shapes walk every way the cursor is advanced: by the
+    last workgroup of a small one-kernel step (group and single-house kernels), by a launch of its own behind a big one (300
+    workgroups), by the finish kernel of the split pair."""
     import mdr_amd
-    cfg = _cfg(64)
-    a = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=5, device="cuda:0", seed=9, table_steps=8, graph_mode=True)
-    b = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=5, device="cuda:0", seed=9, table_steps=8)
+    cfg = _cfg(N)
+    a = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=9, table_steps=8, graph_mode=True)
+    b = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=9, table_steps=8)
     a.reset(episode=0)
     b.reset(episode=0)
     side = torch.cuda.Stream()
@@ -352,6 +355,7 @@ def test_one_graph_may_hold_several_steps_but_not_more_than_the_tables_cover():
     assert a.steps_taken == b.steps_taken == 7
     for k in ("Ta", "Tm", "sso", "flags", "reward", "obs", "P"):
         assert torch.equal(a.t[k], b.t[k]), k
+    assert a.t["cursor"][:2].tolist() == [7, 7] and int(a.t["cursor"][3]) == 0
 
 
 def test_load_state_dict_resyncs_the_device_cursor():
