@@ -166,6 +166,7 @@ class BatchedDemandResponseEnv:
             return
         self._partial_records = int(records)
         self.t["partials"] = torch.zeros((self.nb_envs, self._partial_records, 3), dtype=torch.float64, device=self.device)
+        self._shard_graph = None      # captured steps hold the old buffer
         self._bind()
 
     def _bind(self):
