@@ -150,8 +150,8 @@ typedef struct mdr_buffers {
   /* scratch for the split (multi-workgroup per env) path: [E][mdr_partials_per_env()][3] */
   double *partials;
   double *base_power;              /* [E] PowerGrid.base_power (written in interpolation mode) */
-  /* Optional (NULL = off): graph mode.  int32 [4] = {table row, time index, the split pair's row note, arrival counter} kept on
-   * the device: the step and observation kernels then take their table rows from it instead of from launch arguments, and the
+  /* Optional (NULL = off): graph mode.  int32 [8] = {table row, time index, row note 0 of the split kernels, arrival counter,
+   * row note 1, reserved x 3} kept on the device: the step and observation kernels then take their table rows from it instead of from launch arguments, and the
    * step's last kernel advances it (small grids and the split pair; a big one-kernel step is followed by a one-thread launch)
    * - so a captured mdr_env_step / mdr_env_obs_vector (hipGraph, torch.cuda.CUDAGraph) keeps walking through the episode when
    * it is replayed.  See mdr_env_graph_room / mdr_env_graph_replayed. */
@@ -159,6 +159,10 @@ typedef struct mdr_buffers {
   /* Optional (NULL = off): [(table_steps+1)][E] what PowerGrid.step adds to cumulated_abs_noise at that time index,
    * |base_power * amplitude * perlin| (env 1301); 0 for the signal families without noise. */
   double *tab_abs_noise;
+  /* Optional (NULL = the reward array serves): float [E][N], where the split path's partial kernel leaves each house's own
+   * temperature penalty for the finish.  With a buffer of its own the rewards of a step stay readable while the next step is
+   * begun - what mdr_env_step_end_begin_records needs. */
+  float *pen_stash;
 } mdr_buffers_t;
 
 /* Raw episode parameters for mdr_env_load_episode (replay of an episode sampled elsewhere).
@@ -296,6 +300,15 @@ int mdr_env_step_end_gathered(mdr_env_t *env, const double *gathered, int32_t wo
  * records == NULL: this device's own `partials`, world = 1 (the unsharded split path of mdr_env_step for N > 4096). */
 int mdr_env_step_begin_records(mdr_env_t *env, uint8_t *actions, int action_source, int32_t records_per_env, void *stream);
 int mdr_env_step_end_records(mdr_env_t *env, const double *records, int32_t world, void *stream);
+/* Inside a rollout: step_end_records of the pending step and step_begin_records of the next one in ONE launch (the finish needs the
+ * gathered records, the partial only the state the pending step left; a house's two halves run in the same thread).  A rollout of
+ * T steps is then begin, (all-gather, end_begin) x (T - 1), all-gather, end: T + 1 launches and T collectives instead of 2 T + T.
+ * The next step writes its records into `partials` again (same records_per_env).  Returns MDR_ERR_UNSUPPORTED (-4), nothing
+ * launched, where the two halves cannot share a launch - the next step leaves the time tables (un-captured calls: the refill is
+ * host work), base_power_mode "interpolation", pen_stash not bound: take step_end_records + step_begin_records there.
+ * Capturable like the pair (graph mode): the table row travels in two notes of mdr_buffers_t.cursor, the closing step_end_records
+ * moves the cursor on by every step begun. */
+int mdr_env_step_end_begin_records(mdr_env_t *env, const double *records, int32_t world, uint8_t *actions, int action_source, void *stream);
 
 /* Sharded houses with base_power_mode "interpolation": PowerGrid.interpolatePower (env 1195-1234) averages up to
  * interp_nb_agents houses drawn from the WHOLE env (env 1209-1215), so the update at episode start and every

@@ -69,6 +69,7 @@ class MdrBuffers(C.Structure):
         ("P", _f64p), ("tot_sum", _f64p), ("tot_max", _f64p),
         ("tab_od", _f32p), ("tab_solar", _f32p), ("tab_signal", _f64p),
         ("partials", _f64p), ("base_power", _f64p), ("cursor", C.c_void_p), ("tab_abs_noise", _f64p),
+        ("pen_stash", _f32p),
     ]
 
 
@@ -123,7 +124,7 @@ EXPORTS = (
     "mdr_abi_version", "mdr_status_string", "mdr_last_error", "mdr_partials_per_env", "mdr_env_partial_records",
     "mdr_env_create", "mdr_env_destroy", "mdr_env_bind", "mdr_env_reset", "mdr_env_load_episode",
     "mdr_env_set_od_table", "mdr_env_set_interp_grid", "mdr_env_begin_episode", "mdr_env_step", "mdr_env_rollout", "mdr_env_rollout_fused",
-    "mdr_env_step_begin", "mdr_env_step_end", "mdr_env_step_end_gathered", "mdr_env_step_begin_records", "mdr_env_step_end_records",
+    "mdr_env_step_begin", "mdr_env_step_end", "mdr_env_step_end_gathered", "mdr_env_step_begin_records", "mdr_env_step_end_records", "mdr_env_step_end_begin_records",
     "mdr_env_interp_due", "mdr_env_interp_local", "mdr_env_interp_apply", "mdr_obs_vector_length", "mdr_env_obs_vector",
     "mdr_obs_message_fields", "mdr_env_obs_messages", "mdr_env_obs_vector_ext", "mdr_env_comm_draws",
     "mdr_env_graph_room", "mdr_env_graph_replayed", "mdr_env_pack", "mdr_env_cursor", "mdr_env_set_cursor",
@@ -180,6 +181,7 @@ def load():
         "mdr_env_step_end_gathered": (C.c_int, [vp, vp, i32, vp]),
         "mdr_env_step_begin_records": (C.c_int, [vp, vp, C.c_int, i32, vp]),
         "mdr_env_step_end_records": (C.c_int, [vp, vp, i32, vp]),
+        "mdr_env_step_end_begin_records": (C.c_int, [vp, vp, i32, vp, C.c_int, vp]),
         "mdr_env_interp_due": (C.c_int, [vp]),
         "mdr_env_interp_local": (C.c_int, [vp, vp]),
         "mdr_env_interp_apply": (C.c_int, [vp, vp]),

@@ -140,7 +140,9 @@ class BatchedDemandResponseEnv:
         items += [("tab_od", torch.float32, (K1, E)), ("tab_solar", torch.float32, (K1, E)), ("tab_signal", torch.float64, (K1, E)),
                   ("tab_abs_noise", torch.float64, (K1, E))]
         items += [("partials", torch.float64, (E, nblk, 3))]
-        items += [("cursor", torch.int32, (4,))]      # graph mode: {table row, time index, arrival counter, -} kept on the device
+        items += [("cursor", torch.int32, (8,))]      # graph mode: {table row, time index, row note 0, arrival counter, row note 1, -} on the device
+        # split path (sharded houses, N > 4096): the houses' own penalties between the partial and the finish kernel; else NULL
+        items += [("pen_stash", torch.float32, (E, N) if (self.sharded or N > 4096) else (0,))]
         return items
 
     def _allocate(self):
@@ -177,7 +179,7 @@ class BatchedDemandResponseEnv:
                 continue
             if fname == "cursor" and not self.graph_mode:
                 continue                                    # NULL: launch arguments carry the table rows
-            setattr(b, fname, self.t[fname].data_ptr())
+            setattr(b, fname, self.t[fname].data_ptr() if self.t[fname].numel() else None)      # an empty optional buffer is NULL
         self._buffers = b
         nat.check(self._lib, self._handle, self._lib.mdr_env_bind(self._handle, C.byref(b)), "mdr_env_bind")
 
@@ -385,6 +387,34 @@ class BatchedDemandResponseEnv:
             rc = self._lib.mdr_env_step_end_records(self._handle, C.c_void_p(records.data_ptr()), int(world), self._stream())
             nat.check(self._lib, self._handle, rc, "mdr_env_step_end_records")
 
+    def _step_end_begin(self, records: torch.Tensor, world: int, ptr, source) -> bool:
+        """Finish of the pending step and begin of the next one in ONE launch (mdr_env_step_end_begin_records).  False, nothing
+        launched, where the library asks for the separate calls (the next step leaves the time tables, interpolated base power)."""
+        with torch.cuda.device(self.device):
+            rc = self._lib.mdr_env_step_end_begin_records(self._handle, C.c_void_p(records.data_ptr()), int(world), C.c_void_p(ptr), source,
+                                                          self._stream())
+            if rc == nat.MDR_ERR_UNSUPPORTED:
+                return False
+            nat.check(self._lib, self._handle, rc, "mdr_env_step_end_begin_records")
+        return True
+
+    def _steps_sharded(self, n: int, ptr, source) -> None:
+        """n consecutive steps of sharded houses: begin, (all-gather, end + begin in one launch) x (n - 1), all-gather, end - one
+        launch and one collective per step instead of two launches.  Every step's rewards are written as they are by _step."""
+        if n <= 0:
+            return
+        ex = self._exchange()
+        self._step_begin(ptr, source)
+        for _ in range(n - 1):
+            records, world = ex.gather_partials(self)
+            if not self._step_end_begin(records, world, ptr, source):
+                self._step_end(records, world)
+                self._interp_exchange()
+                self._step_begin(ptr, source)
+        records, world = ex.gather_partials(self)
+        self._step_end(records, world)
+        self._interp_exchange()
+
     def step(self, actions: torch.Tensor):
         """MADemandResponseEnv.step (env 174-210).  Returns (obs [7,E,N], reward [E,N], done [E,N], info)."""
         self._step(self._actions_ptr(actions), nat.ACTIONS_EXTERNAL)
@@ -426,10 +456,7 @@ class BatchedDemandResponseEnv:
                 side.wait_stream(torch.cuda.current_stream(self.device))
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=side):
-                    for _ in range(unroll):
-                        self._step_begin(ptr, source)
-                        records, world = self._exchange().gather_partials(self)
-                        self._step_end(records, world)
+                    self._steps_sharded(unroll, ptr, source)      # begin, (all-gather, end + begin) x (unroll - 1), all-gather, end
                 torch.cuda.current_stream(self.device).wait_stream(side)
                 cached[1][unroll] = g
             reps = n // unroll
@@ -444,8 +471,7 @@ class BatchedDemandResponseEnv:
             source = nat.ACTIONS_EXTERNAL if actions is not None else nat.ACTIONS_BANGBANG
             if self.graph_mode and self.spec.base_power_mode != 1 and getattr(self._exchange(), "capturable", False):
                 return self._rollout_sharded_graph(int(nb_steps), self._actions_ptr(actions), source)
-            for _ in range(nb_steps):
-                self._step(self._actions_ptr(actions), source)
+            self._steps_sharded(int(nb_steps), self._actions_ptr(actions), source)
             return
         src = nat.ACTIONS_EXTERNAL if actions is not None else nat.ACTIONS_BANGBANG
         with torch.cuda.device(self.device):

@@ -18,6 +18,8 @@ struct mdr_env {
   bool has_tables = false;    // begin_episode done
   bool split_pending = false; // step_begin issued, step_end outstanding
   int64_t captured = 0;       // graph mode: steps recorded into the capture in progress (one graph may hold several; each replay runs them all)
+  int32_t snap_slot = 0;      // records path: which row note (mdr_buffers_t.cursor[2] | [4]) holds the pending step's table row
+  int32_t pending_adv = 0;    // records path: steps begun since the device cursor last moved (the finish moves it by that many)
   bool interp_due = false;    // sharded houses, interpolation mode: the base power of the current time index awaits its exchange
   int64_t dev_row = -1, dev_k = -1;   // graph mode: what the device-resident cursor holds (as far as the host knows)
   uint64_t seed = 0;
@@ -110,6 +112,7 @@ std::string check_buffers(const mdr_buffers_t& b, bool need_partials) {
   for (const void* p : aligned16)
     if (((uintptr_t)p & 15u) != 0) return "per-house float/int buffers must be 16-byte aligned";
   if (((uintptr_t)b.flags & 3u) != 0) return "flags must be 4-byte aligned";
+  if (((uintptr_t)b.pen_stash & 15u) != 0) return "pen_stash must be 16-byte aligned";
   return "";
 }
 
@@ -314,6 +317,7 @@ int step_args(mdr_env* env, uint8_t* actions, int action_source, hipStream_t s, 
   a.c_sig = c.alpha_sig / c.norm_sig_penalty;
   a.inv_n_total = 1.0 / (double)c.nb_houses_total;
   a.inv_obs_norm = 1.0 / c.obs_power_norm;
+  a.stash = b.pen_stash ? b.pen_stash : b.reward;   // split path: each house's own penalty between the partial and the finish kernel
   *out = a;
   return MDR_OK;
 }
@@ -506,7 +510,10 @@ int mdr_env_step(mdr_env_t* env, uint8_t* actions, int action_source, void* stre
   if (recording && mdr_env_graph_room(env) - env->captured < 1)
     return fail(env, MDR_ERR_INVALID, "graph mode: the next step lands on an interpolatePower update or past the time tables (mdr_env_graph_room() steps were recorded): run it un-captured");
   if (!recording) env->captured = 0;
-  if (graph) a.cursor_adv = env->buf.cursor;   // the step's last kernel moves the cursor on
+  if (graph) {
+    a.cursor_adv = env->buf.cursor;   // the step's last kernel moves the cursor on
+    a.cursor_steps = 1;
+  }
   hipError_t e = mdr::launch_step(a, env->plan, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "step");
   if (graph) {
@@ -663,12 +670,59 @@ int mdr_env_step_begin_records(mdr_env_t* env, uint8_t* actions, int action_sour
     rc = sync_cursor(env, (hipStream_t)stream);
     if (rc != MDR_OK) return rc;
     graph_rows(env, &a);
-    a.cursor_adv = env->buf.cursor;   // k_step_partial notes the row for k_step_finish, which moves the cursor on
+    a.cursor_adv = env->buf.cursor;   // k_step_partial notes the row for the finish, which moves the cursor on
+    a.snap_wr = 0;
+    if (capturing((hipStream_t)stream)) env->captured += 1;   // a step recorded: mdr_env_graph_replayed accounts for every replay
   }
   hipError_t e = mdr::launch_step_begin_split(a, false, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "step_begin_records");
   env->split_pending = true;
   env->records_stride = records_per_env;
+  env->snap_slot = 0;
+  env->pending_adv = 1;
+  return MDR_OK;
+}
+
+// Finish of the pending step and partial of the next one in ONE launch: between two exchanges of a rollout there is then one
+// launch instead of two.  MDR_ERR_UNSUPPORTED where the two halves cannot share a launch (the next step leaves the time tables,
+// interpolated base power, no pen_stash bound): the caller then takes mdr_env_step_end_records + mdr_env_step_begin_records.
+int mdr_env_step_end_begin_records(mdr_env_t* env, const double* records, int32_t world, uint8_t* actions, int action_source, void* stream) {
+  if (!env || !records) return MDR_ERR_INVALID;
+  if (!env->split_pending || env->records_stride <= 0) return fail(env, MDR_ERR_INVALID, "no mdr_env_step_begin_records is pending");
+  if (world < 1) return fail(env, MDR_ERR_INVALID, "world must be >= 1");
+  if (!env->buf.pen_stash) return fail(env, MDR_ERR_UNSUPPORTED, "buffer 'pen_stash' is not bound");
+  if (interp_mode(env)) return fail(env, MDR_ERR_UNSUPPORTED, "interpolated base power: every step may end in an update");
+  const bool graph = graph_mode(env);
+  const bool recording = graph && capturing((hipStream_t)stream);
+  if (recording) {
+    if (mdr_env_graph_room(env) - env->captured < 1)
+      return fail(env, MDR_ERR_INVALID, "graph mode: no room to replay a step here (mdr_env_graph_room() steps were recorded): run it un-captured");
+  } else if (env->k + 1 - env->j0 >= env->cfg.table_steps) {
+    return fail(env, MDR_ERR_UNSUPPORTED, "the next step leaves the time tables: finish, then begin");
+  }
+  mdr::StepArgs f, p;
+  int rc = step_args(env, nullptr, MDR_ACTIONS_BANGBANG, (hipStream_t)stream, &f);   // rows of the pending step k
+  if (rc != MDR_OK) return rc;
+  f.records = records;
+  f.nblk = (int)env->records_stride;
+  f.world = world;
+  if (!recording) env->k += 1;                                                          // step k is finished by this launch
+  rc = step_args(env, actions, action_source, (hipStream_t)stream, &p);                  // rows of step k + 1 (no refill: checked above)
+  if (rc != MDR_OK) return rc;
+  p.nblk = (int)env->records_stride;
+  if (graph) {   // rows from the notes on the device (k_step_finish_partial)
+    graph_rows(env, &f);
+    graph_rows(env, &p);
+    p.cursor_adv = env->buf.cursor;
+    p.snap_rd = env->snap_slot;
+    p.snap_wr = 1 - env->snap_slot;
+    if (recording) env->captured += 1;
+    else env->captured = 0;
+  }
+  hipError_t e = mdr::launch_step_end_begin_split(f, p, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(env, e, "step_end_begin_records");
+  env->snap_slot = 1 - env->snap_slot;
+  env->pending_adv += 1;
   return MDR_OK;
 }
 
@@ -688,17 +742,21 @@ static int step_end_impl(mdr_env_t* env, const double* gathered, const double* r
   a.world = world;
   const bool graph = graph_mode(env) && records != nullptr;      // the records pair is the graph-capable one
   const bool recording = graph && capturing((hipStream_t)stream);
+  const int adv = env->pending_adv > 0 ? env->pending_adv : 1;
   if (graph) {
     graph_rows(env, &a);
-    a.cursor_adv = env->buf.cursor;   // k_step_finish moves the cursor on
+    a.cursor_adv = env->buf.cursor;   // k_step_finish moves the cursor on: by every step begun since it last moved
+    a.snap_rd = env->snap_slot;
+    a.cursor_steps = adv;
   }
   hipError_t e = mdr::launch_step_end_split(a, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "step_end");
   env->split_pending = false;
+  env->pending_adv = 0;
   if (graph) {
-    if (recording) { env->captured += 1; return MDR_OK; }   // recorded, not run: mdr_env_graph_replayed accounts for every replay
-    env->dev_row += 1;
-    env->dev_k += 1;
+    if (recording) return MDR_OK;   // recorded, not run: mdr_env_graph_replayed accounts for every replay
+    env->dev_row += adv;
+    env->dev_k += adv;
   }
   env->k += 1;
   if (interp_mode(env) && env->k % env->interp_steps == 0) {

@@ -91,7 +91,10 @@ struct StepArgs {
   // so that a captured launch keeps stepping through the tables when it is replayed; nullptr = host-computed rows
   const int32_t* cursor;
   int32_t cursor_max;                  // last valid row (table_steps - 1): a graph replayed too often re-reads it instead of running off the tables
-  int32_t* cursor_adv;                 // graph mode: the step's LAST kernel moves the cursor on when its last workgroup retires (cursor[2] counts arrivals); else nullptr
+  int32_t* cursor_adv;                 // graph mode: the step's LAST kernel moves the cursor on (see cursor_done / the split pair's row notes); else nullptr
+  int32_t snap_rd, snap_wr;            // graph mode, split kernels: which row note (0 | 1) the kernel reads / writes
+  int32_t cursor_steps;                // graph mode, k_step_finish: steps the cursor moves on by (the steps begun since it last moved)
+  float* stash;                        // where k_step_partial leaves each house's own temperature penalty for the finish (`reward`, or mdr_buffers_t.pen_stash)
   int64_t plane;                       // E * N: stride between observation planes
   int E, N, dt, penalty_mode, action_source, nblk;
   float c_temp;                        // alpha_temp / norm_temp_penalty
@@ -185,6 +188,7 @@ hipError_t launch_cursor_set(int32_t* cursor, int32_t row, int32_t k, hipStream_
 hipError_t launch_signal_error(const StepArgs& a, double* sq_signal_error_sum, hipStream_t s);   // += (sig_old - P)^2
 hipError_t launch_reset_obs(const StepArgs& a, hipStream_t s);  // uses sig_old = table row 0
 hipError_t launch_step(const StepArgs& a, const StepPlan& p, hipStream_t s);
+hipError_t launch_step_end_begin_split(const StepArgs& finish, const StepArgs& begin, hipStream_t s);   // finish of step k and partial of step k + 1 in ONE launch
 bool rollout_fused_supported(const StepPlan& p);
 hipError_t launch_rollout_accumulate(const StepArgs& a, const RolloutArgs& ro, hipStream_t s);   // after ONE single step
 hipError_t launch_rollout_fused(const StepArgs& a, const RolloutArgs& r, const StepPlan& p, hipStream_t s);

@@ -328,11 +328,14 @@ __device__ __forceinline__ void cursor_done(const StepArgs& a) {
   }
 }
 
-// The split pair needs no counting: k_step_partial notes the row in cursor[2], k_step_finish reads it from THERE - so nobody in
-// the finish launch reads cursor[0] / [1], and one of its threads moves them on whenever it likes.
+// The split kernels need no counting: a partial kernel notes its table row in a slot (cursor[2] | cursor[4]) that nobody in its
+// launch reads, the finish takes the row from there - so nobody in the finish launch reads cursor[0] / [1] and one of its
+// threads moves them on.  k_step_finish_partial (finish of step k + partial of step k + 1) reads one slot and writes the other.
+__device__ __forceinline__ int snap_index(int slot) { return slot ? 4 : 2; }
+
 __device__ __forceinline__ void rebase_finish(StepArgs& a) {
   if (a.cursor == nullptr) return;
-  const int64_t off = (int64_t)min(a.cursor_adv != nullptr ? a.cursor[2] : a.cursor[0], a.cursor_max) * a.E;
+  const int64_t off = (int64_t)min(a.cursor_adv != nullptr ? a.cursor[snap_index(a.snap_rd)] : a.cursor[0], a.cursor_max) * a.E;
   a.sig_old += off;
   a.sig_new += off;
 }
@@ -345,8 +348,9 @@ __global__ void k_cursor_advance(int32_t* cursor) {
 __global__ void k_cursor_set(int32_t* cursor, int32_t row, int32_t k) {
   cursor[0] = row;
   cursor[1] = k;
-  cursor[2] = row;   // k_step_partial's note for k_step_finish
+  cursor[2] = row;   // the split kernels' row notes
   cursor[3] = 0;     // arrival counter of cursor_done
+  cursor[4] = row;
 }
 
 // Everything the dict adapter shows of env e after a step, as one fp64 vector (ONE launch + ONE device->host copy):
@@ -1061,10 +1065,7 @@ __global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs r
 // the launch would otherwise have fewer workgroups than CUs to spread over (a 125,000-house shard is 123 workgroups of 1024
 // houses: half the CUs idle and each busy one limited by what a single CU can stream).
 template <int VEC, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_step_partial(StepArgs a) {
-  if (a.cursor_adv != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.cursor_adv[2] = a.cursor[0];
-  rebase(a);
-  __shared__ double lds[3 * 4];
+__device__ __forceinline__ void partial_block(const StepArgs& a, double* lds) {
   const int e = blockIdx.y;
   const int h = ((int)blockIdx.x * THREADS + (int)threadIdx.x) * VEC;
   const int64_t base = (int64_t)e * a.N;
@@ -1083,12 +1084,12 @@ __global__ __launch_bounds__(THREADS) void k_step_partial(StepArgs a) {
     acc.sum_p = (double)p;
     acc.sum_pen = (double)ps;
     store_obs_local<VEC>(a, base + h, o, lockout);
-    // the house's own temperature penalty waits in the reward array for the finish kernel (which then needs neither the
-    // temperature nor the target / deadband again: 4 B written + 4 B read per house instead of 12 B re-read)
+    // the house's own temperature penalty waits for the finish kernel (which then needs neither the temperature nor the
+    // target / deadband again: 4 B written + 4 B read per house instead of 12 B re-read) - in the reward array, or in pen_stash
     float pen[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) pen[v] = o[v].pen;
-    store_vec<VEC>(a.reward, base + h, pen);
+    store_vec<VEC>(a.stash, base + h, pen);
   }
   const Red3 tot = block_reduce<THREADS>(acc, lds);
   if (threadIdx.x == 0) {
@@ -1097,6 +1098,14 @@ __global__ __launch_bounds__(THREADS) void k_step_partial(StepArgs a) {
     rec[1] = tot.sum_pen;
     rec[2] = (double)tot.max_pen;
   }
+}
+
+template <int VEC, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_step_partial(StepArgs a) {
+  if (a.cursor_adv != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.cursor_adv[snap_index(a.snap_wr)] = a.cursor[0];
+  rebase(a);
+  __shared__ double lds[3 * 4];
+  partial_block<VEC, THREADS>(a, lds);
 }
 
 // one workgroup per env: fixed-order sum of the per-workgroup partial records -> tot_sum / tot_max
@@ -1126,9 +1135,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(StepArgs a) {
 //   gathered != nullptr [world][3][E] per-rank totals (mdr_env_step_end_gathered): summed in rank order;
 //   else                tot_sum / tot_max as the caller left them (mdr_env_step_end).
 template <int VEC, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_step_finish(StepArgs a) {
-  rebase_finish(a);
-  __shared__ double lds[3 * 4];
+__device__ __forceinline__ void finish_block(const StepArgs& a, double* lds) {
   const int e = blockIdx.y;
   const int h = ((int)blockIdx.x * THREADS + (int)threadIdx.x) * VEC;
   double P, sum_pen;
@@ -1162,21 +1169,46 @@ __global__ __launch_bounds__(THREADS) void k_step_finish(StepArgs a) {
     sum_pen = a.tot_sum[a.E + e];
     max_pen = (float)a.tot_max[e];
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    a.P[e] = P;
-    if (a.cursor_adv != nullptr && e == 0) {   // see rebase_finish
-      a.cursor_adv[0] = a.cursor_adv[2] + 1;
-      a.cursor_adv[1] += 1;
-    }
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.P[e] = P;
+  if (h < a.N) {
+    const int64_t i = (int64_t)e * a.N + h;
+    float pen[VEC];
+    load_vec<VEC>(a.stash, i, pen);   // left there by the partial kernel
+    store_reward_power<VEC>(a, i, pen, sum_pen, max_pen, signal_term(a, P, a.sig_old[e]),
+                            (float)(a.sig_new[e] * a.inv_obs_norm), (float)(P * a.inv_obs_norm));
   }
-  if (h >= a.N) return;
-  const int64_t i = (int64_t)e * a.N + h;
-  float pen[VEC];
-  load_vec<VEC>(a.reward, i, pen);   // left there by k_step_partial
-  store_reward_power<VEC>(a, i, pen, sum_pen, max_pen, signal_term(a, P, a.sig_old[e]),
-                          (float)(a.sig_new[e] * a.inv_obs_norm), (float)(P * a.inv_obs_norm));
 }
 
+template <int VEC, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_step_finish(StepArgs a) {
+  rebase_finish(a);
+  __shared__ double lds[3 * 4];
+  finish_block<VEC, THREADS>(a, lds);
+  if (a.cursor_adv != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // see rebase_finish
+    a.cursor_adv[0] = a.cursor_adv[snap_index(a.snap_rd)] + 1;
+    a.cursor_adv[1] += a.cursor_steps;
+  }
+}
+
+// Finish of step k and partial of step k + 1 in ONE launch (mdr_env_step_end_begin_records): between two exchanges of a rollout
+// there is then one launch, not two - the finish needs the gathered records of step k, the partial nothing but the state step k
+// left, and a house's two halves run in the same thread (its stashed penalty is read before the next one is written).
+template <int VEC, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_step_finish_partial(StepArgs f, StepArgs p) {
+  if (p.cursor != nullptr) {   // graph mode: the row of step k is in one note, this launch leaves the row of step k + 1 in the other
+    const int row = p.cursor[snap_index(p.snap_rd)];
+    const int64_t off_f = (int64_t)min(row, p.cursor_max) * p.E, off_p = (int64_t)min(row + 1, p.cursor_max) * p.E;
+    f.sig_old += off_f;
+    f.sig_new += off_f;
+    p.od_old += off_p;
+    p.solar_new += off_p;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.cursor_adv[snap_index(p.snap_wr)] = row + 1;
+  }
+  __shared__ double lds[3 * 4];
+  finish_block<VEC, THREADS>(f, lds);
+  __syncthreads();
+  partial_block<VEC, THREADS>(p, lds);
+}
 
 // =================================================================================================
 // Full flat observation: utils.normStateDict (utils.py:740-880) for every house, messages included.
@@ -2203,6 +2235,18 @@ hipError_t launch_step_end_split(const StepArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((k_step_finish<4, 64>), g, b, 0, s, a);
   else
     hipLaunchKernelGGL((k_step_finish<4, 256>), g, b, 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_step_end_begin_split(const StepArgs& f, const StepArgs& p, hipStream_t s) {
+  const int th = split_threads(p.N, p.E);
+  const dim3 g((unsigned)split_blocks(p.N, th), (unsigned)p.E), b(th);
+  if (p.N % 4 != 0)
+    hipLaunchKernelGGL((k_step_finish_partial<1, 256>), g, b, 0, s, f, p);
+  else if (th == 64)
+    hipLaunchKernelGGL((k_step_finish_partial<4, 64>), g, b, 0, s, f, p);
+  else
+    hipLaunchKernelGGL((k_step_finish_partial<4, 256>), g, b, 0, s, f, p);
   return hipGetLastError();
 }
 
