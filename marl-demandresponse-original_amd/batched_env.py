@@ -425,10 +425,10 @@ class BatchedDemandResponseEnv:
         self._step(self.t["actions"].data_ptr(), nat.ACTIONS_BANGBANG)
         return self.t["obs"], self.t["reward"], self.done, {"cluster_hvac_power": self.t["P"]}
 
-    SHARD_GRAPH_UNROLL = 16      # steps per captured graph: a graph launch costs ~10 us, a node-to-node hop inside one ~2 us
+    SHARD_GRAPH_UNROLLS = (16, 4)      # steps per captured graph (a graph launch costs ~10 us, a hop between its nodes ~2 us); leftovers before a table refill go 4 at a time, then singly
 
     def _rollout_sharded_graph(self, nb_steps: int, ptr: int, source: int) -> None:
-        """Sharded houses in graph mode: begin, the all-gather of the records, end - SHARD_GRAPH_UNROLL steps of it - are captured
+        """Sharded houses in graph mode: begin, the all-gather of the records, end - SHARD_GRAPH_UNROLLS[0] steps of it - are captured
         in a hipGraph (RCCL collectives are capturable) and replayed; the device cursor walks the time tables, the host only comes
         back when they run out.  The per-step work is unchanged (every step still exchanges), the per-step host cost - three
         Python -> C calls and a torch.distributed dispatch, ~30 us against 8-19 us of kernels - is gone.  Every rank captures and
@@ -449,7 +449,7 @@ class BatchedDemandResponseEnv:
                 self._step(ptr, source)
                 done += 1
                 continue
-            unroll = self.SHARD_GRAPH_UNROLL if n >= self.SHARD_GRAPH_UNROLL else 1
+            unroll = next((u for u in self.SHARD_GRAPH_UNROLLS if n >= u), 1)
             g = cached[1].get(unroll)
             if g is None:
                 side = torch.cuda.Stream(device=self.device)

@@ -20,7 +20,7 @@ for share in (1_000_000, 500_000, 250_000, 125_000):
         env = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=1, device=dev, seed=2024, house_shard=(0, share), exchange_always=True,
                                                table_steps=64, graph_mode=graph)
         if unroll:
-            env.SHARD_GRAPH_UNROLL = unroll if unroll > 1 else 10**9
+            env.SHARD_GRAPH_UNROLLS = (unroll,) if unroll > 1 else ()
         env.reset(episode=0)
         env.rollout(128)
         torch.cuda.synchronize()
