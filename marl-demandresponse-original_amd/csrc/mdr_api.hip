@@ -708,7 +708,10 @@ int mdr_env_step_end_begin_records(mdr_env_t* env, const double* records, int32_
   f.world = world;
   if (!recording) env->k += 1;                                                          // step k is finished by this launch
   rc = step_args(env, actions, action_source, (hipStream_t)stream, &p);                  // rows of step k + 1 (no refill: checked above)
-  if (rc != MDR_OK) return rc;
+  if (rc != MDR_OK) {
+    if (!recording) env->k -= 1;   // nothing was launched: the step stays pending
+    return rc;
+  }
   p.nblk = (int)env->records_stride;
   if (graph) {   // rows from the notes on the device (k_step_finish_partial)
     graph_rows(env, &f);
@@ -720,7 +723,10 @@ int mdr_env_step_end_begin_records(mdr_env_t* env, const double* records, int32_
     else env->captured = 0;
   }
   hipError_t e = mdr::launch_step_end_begin_split(f, p, (hipStream_t)stream);
-  if (e != hipSuccess) return hip_fail(env, e, "step_end_begin_records");
+  if (e != hipSuccess) {
+    if (!recording) env->k -= 1;
+    return hip_fail(env, e, "step_end_begin_records");
+  }
   env->snap_slot = 1 - env->snap_slot;
   env->pending_adv += 1;
   return MDR_OK;

@@ -291,3 +291,47 @@ def test_fuzz_sharded_group_vs_unsharded(idx):
             assert torch.equal(group.gather(name), whole.t[name]), name
         torch.testing.assert_close(group.shards[0].reg_signal(), whole.reg_signal(), rtol=1e-12, atol=0)
         torch.testing.assert_close(group.gather("reward"), whole.t["reward"], rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("N,E,table_steps,graph", [(9000, 2, 8, False), (125000, 1, 16, False), (40, 3, 8, False), (9000, 2, 8, True)])
+def test_end_and_begin_in_one_launch_equals_the_separate_calls(N, E, table_steps, graph):
+    """mdr_env_step_end_begin_records: the finish of step k and the partial of step k + 1 share a launch inside a rollout; where
+    the next step leaves the time tables the library asks for the separate calls (False, nothing launched)."""
+    import mdr_amd
+    from mdr_amd import _native as nat
+    cfg = _cfg("mixture")
+    cfg["default_env_prop"]["cluster_prop"]["nb_agents"] = N
+    whole = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=12, table_steps=table_steps)
+    shard = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=12, table_steps=table_steps, house_shard=(0, N),
+                                             exchange_always=True, graph_mode=graph)
+    whole.reset(episode=0)
+    shard._reset_local(episode=0)          # no exchange object: the records below stand in for the all-gather of a world of one
+    shard._begin_episode_local()
+    ptr, src = shard.t["actions"].data_ptr(), nat.ACTIONS_BANGBANG
+
+    def gathered():
+        return shard.t["partials"].clone()[None]
+
+    with pytest.raises(ValueError, match="pending"):
+        shard._step_end_begin(gathered(), 1, ptr, src)
+    T, fused, separate = 3 * table_steps + 5, 0, 0
+    shard._step_begin(ptr, src)
+    for _ in range(T - 1):
+        rec = gathered()
+        if shard._step_end_begin(rec, 1, ptr, src):
+            fused += 1
+        else:
+            shard._step_end(rec, 1)
+            shard._step_begin(ptr, src)
+            separate += 1
+    shard._step_end(gathered(), 1)
+    whole.rollout(T)
+    torch.cuda.synchronize()
+    assert separate == 3 and fused == T - 1 - separate          # one refill per table_steps steps
+    assert shard.steps_taken == whole.steps_taken == T
+    for k in ("Ta", "Tm", "sso", "flags", "obs", "P", "actions"):
+        assert torch.equal(shard.t[k], whole.t[k]), k
+    if N > 4096:
+        assert torch.equal(shard.t["reward"], whole.t["reward"])
+    else:
+        torch.testing.assert_close(shard.t["reward"], whole.t["reward"], rtol=1e-6, atol=1e-6)
