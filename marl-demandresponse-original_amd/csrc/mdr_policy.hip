@@ -54,6 +54,14 @@ struct ActorArgs {
   float* rows_out;           // observe -> act only, optional: the observation rows [A][51] in normStateDict order (the transition buffer's `state`)
 };
 
+// The Philox key of a draw, hidden from loop-invariant code motion: hipcc otherwise keeps the ten round keys (k + n W) of both
+// words in 20 scalar registers for the whole kernel - beyond the scalar file, so they are parked in the lanes of a vector
+// register and fetched back one v_readlane at a time.  Re-deriving them where a draw is made is 20 scalar adds.
+__device__ __forceinline__ uint32_t loop_local(uint32_t x) {
+  asm volatile("" : "+s"(x));
+  return x;
+}
+
 // max(x, 0) in ONE instruction: on the bit pattern, as a signed integer (v_max_i32) - every negative float, -0 included, is a
 // negative integer, every non-negative float keeps its bits.  fmaxf costs a canonicalising v_max_f32 x, x before the v_max_f32
 // x, 0, and hipcc folds v_med3_f32(x, 0, inf) into that very pair (r02: 2442 relus of this file compiled to 4884 v_max_f32).
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_actor_sample(ActorArgs a) {
     const float p0 = 1.0f / (1.0f + expf(-d));
     const float p1 = 1.0f / (1.0f + expf(d));
     if (h == 0 && valid) {
-      const u32x4 rnd = philox4x32_10((uint32_t)agent, (uint32_t)((uint64_t)agent >> 32), a.step_lo + (a.step_dev ? (uint32_t)*a.step_dev : 0u), TAG_ACTION ^ a.step_hi, a.k0, a.k1);
+      const u32x4 rnd = philox4x32_10((uint32_t)agent, (uint32_t)((uint64_t)agent >> 32), a.step_lo + (a.step_dev ? (uint32_t)*a.step_dev : 0u), TAG_ACTION ^ a.step_hi, loop_local(a.k0), loop_local(a.k1));
       const float u = ((float)(rnd.x >> 8) + 0.5f) * (1.0f / 16777216.0f);
       const int act = a.greedy ? (d >= 0.0f ? 0 : 1) : (u < p0 ? 0 : 1);   // argmax keeps the first maximum, as torch.argmax
       a.action[agent] = (uint8_t)act;
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
     const bool valid = agent < a.A;
     if ((it & 3) == 0) {
       const int64_t ag = (t + g * nwaves) * 16 + r;
-      rnd = philox4x32_10((uint32_t)ag, (uint32_t)((uint64_t)ag >> 32), a.step_lo + (a.step_dev ? (uint32_t)*a.step_dev : 0u), TAG_ACTION ^ a.step_hi, a.k0, a.k1).x;
+      rnd = philox4x32_10((uint32_t)ag, (uint32_t)((uint64_t)ag >> 32), a.step_lo + (a.step_dev ? (uint32_t)*a.step_dev : 0u), TAG_ACTION ^ a.step_hi, loop_local(a.k0), loop_local(a.k1)).x;
     }
     f32x4 acc[MB];
 #pragma unroll
@@ -409,7 +417,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) 
       for (int c = 0; c < NCB; ++c) {
         const int64_t ag = ((t + g * nwaves) * NCB + c) * 16 + r;
         rnd[c] = philox4x32_10((uint32_t)ag, (uint32_t)((uint64_t)ag >> 32), a.step_lo + (a.step_dev ? (uint32_t)*a.step_dev : 0u),
-                               TAG_ACTION ^ a.step_hi, a.k0, a.k1).x;
+                               TAG_ACTION ^ a.step_hi, loop_local(a.k0), loop_local(a.k1)).x;
       }
     }
     f32x4 acc[NCB][MB];
@@ -817,7 +825,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
       for (int c = 0; c < NCB; ++c) {
         const int64_t ag = ((t + g * nwaves) * NCB + c) * 16 + r;
         rnd[c] = philox4x32_10((uint32_t)ag, (uint32_t)((uint64_t)ag >> 32), a.step_lo + (a.step_dev ? (uint32_t)*a.step_dev : 0u),
-                               TAG_ACTION ^ a.step_hi, a.k0, a.k1).x;
+                               TAG_ACTION ^ a.step_hi, loop_local(a.k0), loop_local(a.k1)).x;
       }
     }
     // the next tile's compact state: issued now, consumed between the k-steps of layer 2
@@ -990,7 +998,7 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_observe16(ActorArgs a, m
     const bool valid = agent < a.A;
     if ((it & 3) == 0) {
       const int64_t ag = (t + g * nwaves) * 16 + r;
-      rnd = philox4x32_10((uint32_t)ag, (uint32_t)((uint64_t)ag >> 32), a.step_lo + (a.step_dev ? (uint32_t)*a.step_dev : 0u), TAG_ACTION ^ a.step_hi, a.k0, a.k1).x;
+      rnd = philox4x32_10((uint32_t)ag, (uint32_t)((uint64_t)ag >> 32), a.step_lo + (a.step_dev ? (uint32_t)*a.step_dev : 0u), TAG_ACTION ^ a.step_hi, loop_local(a.k0), loop_local(a.k1)).x;
     }
     const bool more = t + nwaves < a.ntiles;
     tc.next();
