@@ -455,7 +455,8 @@ class BatchedDemandResponseEnv:
                 side = torch.cuda.Stream(device=self.device)
                 side.wait_stream(torch.cuda.current_stream(self.device))
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
+                # thread-local capture: the communicator's own threads (watchdog, proxies) keep making runtime calls meanwhile
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                     self._steps_sharded(unroll, ptr, source)      # begin, (all-gather, end + begin) x (unroll - 1), all-gather, end
                 torch.cuda.current_stream(self.device).wait_stream(side)
                 cached[1][unroll] = g
