@@ -23,11 +23,14 @@ def client(tmp_path_factory):
     return str(exe)
 
 
-@pytest.mark.parametrize("E,N,steps", [(4, 64, 100), (3, 1024, 70), (2, 5000, 40), (50, 20, 130)])
-def test_c_client_matches_python_host(client, E, N, steps):
+@pytest.mark.parametrize("E,N,steps,mode", [(4, 64, 100, ""), (3, 1024, 70, ""), (2, 5000, 40, ""), (50, 20, 130, ""),
+                                            (2, 5000, 150, "records"), (1, 125000, 70, "records")])
+def test_c_client_matches_python_host(client, E, N, steps, mode):
     import mdr_amd
-    out = subprocess.run([client, str(E), str(N), "7", str(steps)], check=True, capture_output=True, text=True).stdout
+    out = subprocess.run([client, str(E), str(N), "7", str(steps)] + ([mode] if mode else []), check=True, capture_output=True, text=True).stdout
     got = json.loads(out.strip().splitlines()[-1])
+    if mode == "records":      # one launch per step between the exchanges, except where the 64-row time tables are refilled
+        assert got["fused"] == steps - 1 - (steps - 1) // 64
 
     cfg = mdr_amd.default_config()
     cfg["default_env_prop"]["cluster_prop"]["nb_agents"] = N

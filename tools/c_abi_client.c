@@ -3,10 +3,13 @@
  *
  *   hipcc -x c tools/c_abi_client.c -Iinclude -Lmarl-demandresponse-original_amd/csrc -lmdr_hip \
  *         -Wl,-rpath,$PWD/marl-demandresponse-original_amd/csrc -o /tmp/c_abi_client
- *   /tmp/c_abi_client <nb_envs> <nb_houses> <seed> <steps>
+ *   /tmp/c_abi_client <nb_envs> <nb_houses> <seed> <steps> [records]
  *
  * Allocates every buffer with hipMalloc, samples an episode on the device, takes `steps` bang-bang steps and
- * prints checksums of the final state.  tests/test_gpu_c_client.py runs it and compares the numbers with the
+ * prints checksums of the final state.  With `records` the steps go through the sharded-houses entry points as a rank
+ * of a world of one would drive them - mdr_env_step_begin_records, then per step a device copy of the partial records
+ * (what the all-gather delivers) and mdr_env_step_end_begin_records (or, where the library asks for it, the separate
+ * end and begin), mdr_env_step_end_records at the end - and must land on the same numbers.  tests/test_gpu_c_client.py runs it and compares the numbers with the
  * Python host's run of the same configuration and seed: the boundary carries no Python / torch state.
  */
 #include <hip/hip_runtime_api.h>
@@ -46,6 +49,7 @@ int main(int argc, char **argv) {
   const int N = argc > 2 ? atoi(argv[2]) : 64;
   const uint64_t seed = argc > 3 ? strtoull(argv[3], NULL, 10) : 7;
   const int steps = argc > 4 ? atoi(argv[4]) : 100;
+  const int use_records = argc > 5 && strcmp(argv[5], "records") == 0;
 
   /* the reference's defaults (config.py), with noise_house_prop "big_noise", noise_hvac_prop "big_noise",
    * signal_mode "sinusoidals", base_power_mode "constant" - the same dict tests/test_gpu_c_client.py builds */
@@ -95,6 +99,7 @@ int main(int argc, char **argv) {
   b.tot_sum = (double *)dev_alloc((size_t)E * 8 * 3); b.tot_max = b.tot_sum + 2 * (size_t)E;
   b.tab_od = (float *)dev_alloc(K1 * E * 4); b.tab_solar = (float *)dev_alloc(K1 * E * 4); b.tab_signal = (double *)dev_alloc(K1 * E * 8);
   b.partials = (double *)dev_alloc((size_t)E * (size_t)mdr_partials_per_env(N) * 3 * 8);
+  if (use_records) b.pen_stash = (float *)dev_alloc(H * 4);
   uint8_t *actions = (uint8_t *)dev_alloc(H);
 
   hipStream_t stream;
@@ -102,7 +107,28 @@ int main(int argc, char **argv) {
   CHECK_MDR(mdr_env_bind(env, &b));
   CHECK_MDR(mdr_env_reset(env, seed, 0, stream));
   CHECK_MDR(mdr_env_begin_episode(env, stream));
-  CHECK_MDR(mdr_env_rollout(env, actions, MDR_ACTIONS_BANGBANG, steps, stream));
+  int fused = 0;
+  if (use_records && steps > 0) {
+    const int32_t R = (int32_t)mdr_env_partial_records(env);
+    const size_t bytes = (size_t)E * (size_t)R * 3 * sizeof(double);
+    double *records = (double *)dev_alloc(bytes);   /* [world = 1][E][R][3] */
+    CHECK_MDR(mdr_env_step_begin_records(env, actions, MDR_ACTIONS_BANGBANG, R, stream));
+    for (int i = 1; i < steps; ++i) {
+      CHECK_HIP(hipMemcpyAsync(records, b.partials, bytes, hipMemcpyDeviceToDevice, stream));
+      rc = mdr_env_step_end_begin_records(env, records, 1, actions, MDR_ACTIONS_BANGBANG, stream);
+      if (rc == MDR_ERR_UNSUPPORTED) {   /* the next step leaves the time tables: the refill is host work */
+        CHECK_MDR(mdr_env_step_end_records(env, records, 1, stream));
+        CHECK_MDR(mdr_env_step_begin_records(env, actions, MDR_ACTIONS_BANGBANG, R, stream));
+      } else {
+        CHECK_MDR(rc);
+        ++fused;
+      }
+    }
+    CHECK_HIP(hipMemcpyAsync(records, b.partials, bytes, hipMemcpyDeviceToDevice, stream));
+    CHECK_MDR(mdr_env_step_end_records(env, records, 1, stream));
+  } else {
+    CHECK_MDR(mdr_env_rollout(env, actions, MDR_ACTIONS_BANGBANG, steps, stream));
+  }
   CHECK_HIP(hipStreamSynchronize(stream));
 
   float *Ta = (float *)malloc(H * 4), *reward = (float *)malloc(H * 4);
@@ -118,8 +144,8 @@ int main(int argc, char **argv) {
   for (int e = 0; e < E; ++e) sP += P[e];
   int64_t k = 0, j0 = 0;
   mdr_env_cursor(env, &k, &j0);
-  printf("{\"steps\": %lld, \"sum_Ta\": %.9e, \"sum_reward\": %.9e, \"sum_sso\": %lld, \"sum_P\": %.9e, \"Ta0\": %.9e, \"TaLast\": %.9e}\n",
-         (long long)k, sTa, sR, sS, sP, (double)Ta[0], (double)Ta[H - 1]);
+  printf("{\"fused\": %d, \"steps\": %lld, \"sum_Ta\": %.9e, \"sum_reward\": %.9e, \"sum_sso\": %lld, \"sum_P\": %.9e, \"Ta0\": %.9e, \"TaLast\": %.9e}\n",
+         fused, (long long)k, sTa, sR, sS, sP, (double)Ta[0], (double)Ta[H - 1]);
   mdr_env_destroy(env);
   return 0;
 }
