@@ -420,6 +420,8 @@ def run_rank(args):
         watchdog.start()
         for name, leg in leg_list:
             try:
+                if os.environ.get("MDR_BENCH_FAIL_LEG") == "%s:%d" % (name, rk.rank):      # test hook: a leg that dies on one rank
+                    raise RuntimeError("injected failure (MDR_BENCH_FAIL_LEG)")
                 legs[name] = leg()
             except Exception as exc:
                 legs[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}

@@ -59,3 +59,22 @@ def test_a_leg_that_does_not_return_never_costs_the_headline():
     assert line["value"] > 1e9 and line["roofline"]["frac"] > 0
     assert "did not finish" in line["c5_graph"]["error"]                      # the last leg cannot have made it in 0.2 s
     assert "value" in line["ppo_rollout"] or "did not finish" in line["ppo_rollout"]["error"]
+
+
+@pytest.mark.gpu
+def test_a_leg_that_dies_on_one_rank_costs_neither_the_line_nor_the_exit_code():
+    """Rank 1 raises inside the c5 leg while rank 0 enters its collectives: rank 1 skips the remaining legs and leaves through the
+    watchdog (its close() barrier never completes), rank 0's watchdog prints the line with the leg marked; exit code 0."""
+    line = _run({"MDR_BENCH_BACKEND": "gloo", "MDR_BENCH_ENVS": "256", "MDR_BENCH_FAIL_LEG": "c5:1"}, "--gpus", "2", "--steps", "20",
+                "--warmup", "5", "--ppo-steps", "2", "--c5-steps", "10", "--leg-timeout", "25", timeout=300)
+    assert line["n_gpus"] == 2 and line["value"] > 1e8
+    assert "value" in line["ppo_rollout"]                          # finished before the failure
+    assert "error" in line["c5"] and "error" in line["c5_graph"]
+
+
+@pytest.mark.gpu
+def test_a_leg_that_dies_on_rank_0_is_reported_and_the_rest_skipped():
+    line = _run({"MDR_BENCH_ENVS": "256", "MDR_BENCH_FAIL_LEG": "ppo_rollout:0"}, "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+                "--c5-steps", "10")
+    assert "injected failure" in line["ppo_rollout"]["error"]
+    assert "value" in line["c5"] and "value" in line["c5_graph"]   # a world of one: the other legs still run
