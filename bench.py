@@ -185,6 +185,7 @@ class Ranks:
             self.device = torch.device("cuda", idx)
         # a process group also for a world of one when asked (MDR_BENCH_FORCE_DIST=1) or for the C5 leg (see c5_leg)
         self.group_ready = False
+        self.backend_note = None
         if self.world > 1 or os.environ.get("MDR_BENCH_FORCE_DIST", "") not in ("", "0"):
             self.init_group()
 
@@ -199,7 +200,18 @@ class Ranks:
         os.dup2(2, 1)
         try:
             if self.backend == "nccl" and not self.dry:
-                self.dist.init_process_group("nccl", device_id=self.device)
+                try:
+                    if os.environ.get("MDR_BENCH_BREAK_NCCL"):      # test hook
+                        raise RuntimeError("injected failure (MDR_BENCH_BREAK_NCCL)")
+                    self.dist.init_process_group("nccl", device_id=self.device)
+                    self.dist.barrier()
+                except Exception as exc:      # the env replicas of the headline need a fence, not RCCL: keep the scaling curve
+                    self.backend_note = "RCCL did not come up (%s: %s): fence over gloo" % (type(exc).__name__, str(exc)[:200])
+                    print("bench.py: " + self.backend_note, file=sys.stderr)
+                    if self.dist.is_initialized():
+                        self.dist.destroy_process_group()
+                    self.backend = "gloo"
+                    self.dist.init_process_group("gloo")
             else:
                 self.dist.init_process_group("gloo")
             self.dist.barrier()
@@ -389,6 +401,8 @@ def run_rank(args):
                          "cache_note": "C3 re-reads 53 B/house = 222 MB per step, below the 256 MiB Infinity Cache: part of this rate is "
                                        "cache-assisted; the size sweep in profiles/ (r02_size_sweep.jsonl) gives the rate with the re-read set at 2-8x the cache"},
         }
+        if rk.backend_note:
+            line["backend_note"] = rk.backend_note
         line.update(legs)
         return line
 

@@ -78,3 +78,12 @@ def test_a_leg_that_dies_on_rank_0_is_reported_and_the_rest_skipped():
                 "--c5-steps", "10")
     assert "injected failure" in line["ppo_rollout"]["error"]
     assert "value" in line["c5"] and "value" in line["c5_graph"]   # a world of one: the other legs still run
+
+
+@pytest.mark.gpu
+def test_the_fence_falls_back_to_gloo_when_rccl_does_not_come_up():
+    """The env replicas of the headline need a fence, not RCCL: a communicator that fails to initialise must not cost the line."""
+    line = _run({"MDR_BENCH_ENVS": "256", "MDR_BENCH_FORCE_DIST": "1", "MDR_BENCH_BREAK_NCCL": "1"}, "--steps", "20", "--warmup", "5",
+                "--no-cpu-baseline", "--ppo-steps", "2", "--c5-steps", "10")
+    assert line["value"] > 1e9 and "fence over gloo" in line["backend_note"]
+    assert line["c5"]["backend"] == "gloo" and line["c5_graph"]["captured"] is False
