@@ -147,7 +147,8 @@ typedef struct mdr_buffers {
   float *tab_od;                   /* outdoor temperature minus temp_ref */
   float *tab_solar;                /* window_area * shading_coeff * SCL, W */
   double *tab_signal;              /* regulation signal, W */
-  /* scratch for the split (multi-workgroup per env) path: [E][mdr_partials_per_env()][3] */
+  /* scratch for the split (multi-workgroup per env) path: [E][mdr_partials_per_env()][3] - all of it: mdr_env_rollout keeps two
+   * sets of records in it (the records path takes the stride it is given, records_per_env) */
   double *partials;
   double *base_power;              /* [E] PowerGrid.base_power (written in interpolation mode) */
   /* Optional (NULL = off): graph mode.  int32 [8] = {table row, time index, row note 0 of the split kernels, arrival counter,

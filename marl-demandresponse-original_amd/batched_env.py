@@ -131,6 +131,8 @@ class BatchedDemandResponseEnv:
         if self._partial_records is not None and self._partial_records < nblk:
             raise ValueError("partial_records smaller than the %d workgroups this shard needs" % nblk)
         nblk = self._partial_records = max(nblk, self._partial_records or 0)
+        if not self.sharded:      # the documented size: mdr_env_rollout keeps two sets of records in it (sharded houses: the stride the ranks agreed on)
+            nblk = max(nblk, int(self._lib.mdr_partials_per_env(N)))
         items = [(n, torch.float32, (E, N)) for n in _HOUSE_F32]
         items += [(n, torch.int32, (E, N)) for n in _HOUSE_I32]
         items += [(n, torch.uint8, (E, N)) for n in _HOUSE_U8]

@@ -573,9 +573,62 @@ int mdr_env_graph_replayed(mdr_env_t* env, int64_t n, void* stream) {
   return sync_cursor(env, (hipStream_t)stream);
 }
 
+// Unsharded envs on the split path (more than 4096 houses): inside a rollout the finish of step k and the partial of step k + 1
+// share a launch (k_step_finish_partial), as they do for sharded houses - n + 1 launches instead of 2 n.  The finish re-sums the
+// records of step k while the same launch writes those of step k + 1, so the two alternate between the halves of `partials`
+// (its documented size, [E][mdr_partials_per_env()][3], holds two sets of records whenever nb_houses % 4 == 0).
+static int rollout_split(mdr_env_t* env, uint8_t* actions, int action_source, int32_t nb_steps, hipStream_t s) {
+  const int64_t half = (int64_t)env->cfg.nb_envs * env->nblk * 3;
+  double* slot[2] = {env->buf.partials, env->buf.partials + half};
+  mdr::StepArgs f, p;
+  int q = 0;
+  int rc = step_args(env, actions, action_source, s, &p);   // refills used-up tables
+  if (rc != MDR_OK) return rc;
+  p.partials = slot[q];
+  hipError_t e = mdr::launch_step_begin_split(p, false, s);
+  if (e != hipSuccess) return hip_fail(env, e, "rollout (begin)");
+  for (int32_t i = 1; i < nb_steps; ++i) {
+    rc = step_args(env, nullptr, MDR_ACTIONS_BANGBANG, s, &f);   // rows of the step begun last
+    if (rc != MDR_OK) return rc;
+    f.records = slot[q];
+    f.world = 1;
+    if (env->k + 1 - env->j0 >= env->cfg.table_steps) {   // the next step leaves the time tables: finish, refill, begin
+      e = mdr::launch_step_end_split(f, s);
+      if (e != hipSuccess) return hip_fail(env, e, "rollout (end)");
+      env->k += 1;
+      rc = step_args(env, actions, action_source, s, &p);
+      if (rc != MDR_OK) return rc;
+      p.partials = slot[q];
+      e = mdr::launch_step_begin_split(p, false, s);
+      if (e != hipSuccess) return hip_fail(env, e, "rollout (begin)");
+      continue;
+    }
+    env->k += 1;
+    rc = step_args(env, actions, action_source, s, &p);
+    if (rc != MDR_OK) return rc;
+    p.partials = slot[1 - q];
+    e = mdr::launch_step_end_begin_split(f, p, s);
+    if (e != hipSuccess) return hip_fail(env, e, "rollout (end + begin)");
+    q = 1 - q;
+  }
+  rc = step_args(env, nullptr, MDR_ACTIONS_BANGBANG, s, &f);
+  if (rc != MDR_OK) return rc;
+  f.records = slot[q];
+  f.world = 1;
+  e = mdr::launch_step_end_split(f, s);
+  if (e != hipSuccess) return hip_fail(env, e, "rollout (end)");
+  env->k += 1;
+  return MDR_OK;
+}
+
 int mdr_env_rollout(mdr_env_t* env, uint8_t* actions, int action_source, int32_t nb_steps, void* stream) {
   if (!env) return MDR_ERR_INVALID;
   if (nb_steps < 0) return fail(env, MDR_ERR_INVALID, "nb_steps must be >= 0");
+  static const bool fuse_split = [] { const char* t = getenv("MDR_ROLLOUT_SPLIT_FUSED"); return !(t && t[0] == '0'); }();   // experiment knob
+  if (fuse_split && nb_steps > 1 && env->bound && env->has_tables && env->plan.kind == mdr::STEP_SPLIT && env->buf.pen_stash && env->buf.partials &&
+      !sharded(env) && !env->split_pending && !interp_mode(env) && !graph_mode(env) &&
+      mdr_partials_per_env(env->cfg.nb_houses) >= 2 * env->nblk)
+    return rollout_split(env, actions, action_source, nb_steps, (hipStream_t)stream);
   for (int32_t i = 0; i < nb_steps; ++i) {
     int rc = mdr_env_step(env, actions, action_source, stream);
     if (rc != MDR_OK) return rc;

@@ -99,7 +99,7 @@ int main(int argc, char **argv) {
   b.tot_sum = (double *)dev_alloc((size_t)E * 8 * 3); b.tot_max = b.tot_sum + 2 * (size_t)E;
   b.tab_od = (float *)dev_alloc(K1 * E * 4); b.tab_solar = (float *)dev_alloc(K1 * E * 4); b.tab_signal = (double *)dev_alloc(K1 * E * 8);
   b.partials = (double *)dev_alloc((size_t)E * (size_t)mdr_partials_per_env(N) * 3 * 8);
-  if (use_records) b.pen_stash = (float *)dev_alloc(H * 4);
+  b.pen_stash = (float *)dev_alloc(H * 4);   /* optional: lets rollouts of the split path (and the records path) take one launch per step */
   uint8_t *actions = (uint8_t *)dev_alloc(H);
 
   hipStream_t stream;
