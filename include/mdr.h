@@ -28,12 +28,13 @@
 extern "C" {
 #endif
 
-#define MDR_ABI_VERSION 3
+#define MDR_ABI_VERSION 4
 #define MDR_MAX_SINUSOIDS 8
 #define MDR_MAX_CAPACITIES 16
 #define MDR_OBS_COLUMNS 7
 #define MDR_INTERP_AXES 10
 #define MDR_INTERP_MAX_AXIS 16
+#define MDR_MAX_SHARDS 8
 
 typedef struct mdr_env mdr_env_t; /* opaque handle */
 
@@ -310,6 +311,64 @@ int mdr_env_step_end_records(mdr_env_t *env, const double *records, int32_t worl
  * Capturable like the pair (graph mode): the table row travels in two notes of mdr_buffers_t.cursor, the closing step_end_records
  * moves the cursor on by every step begun. */
 int mdr_env_step_end_begin_records(mdr_env_t *env, const double *records, int32_t world, uint8_t *actions, int action_source, void *stream);
+
+/* Sharded houses WITHOUT a kernel boundary or a collective per step: the persistent rollout.  The bang-bang closed loop of
+ * main-deploy.py:99-148 for an env whose houses span several workgroups and - sharded - several ranks, ONE launch per time-table
+ * window.  The houses stay in registers across steps (as in mdr_env_rollout_fused); what the houses of one env share per step -
+ * the cluster power sum (env/MA_DemandResponse.py:1042-1050) and the temperature-penalty sum / max of the common penalty modes
+ * (274-321) - travels through a MAILBOX: every house workgroup (1024 houses) pushes its (power sum, penalty sum, penalty max)
+ * record - the record mdr_env_step_begin_records writes - into the mailbox of every rank as self-validating 8-byte
+ * {step tag, 32 data bits} granules; one reducer workgroup per env and rank re-sums the world * records records in the fixed
+ * order of mdr_env_step_end_records (bit-identical totals on every rank and to the records path) and hands the totals to the
+ * house workgroups, which run up to three steps ahead (the state never depends on the totals, only the rewards do).
+ *
+ * The mailbox is caller-owned device memory of mdr_mailbox_bytes() bytes per rank, ZERO-FILLED ONCE when it is created and
+ * from then on written only by these launches (step tags count over the life of the env handle; there is no per-launch
+ * re-initialisation, a peer may already be pushing when a launch begins).  `boxes[r]` is rank r's mailbox as THIS device
+ * addresses it: the same allocation for shards driven on one device, a peer mapping (hipIpcOpenMemHandle / peer access;
+ * mdr_mailbox_alloc / _export / _open below) across devices - then system_scope = 1 and the memory must be fine-grained.
+ * All ranks call in lockstep with the same nb_steps (as they would a collective).
+ *
+ * Guards.  Every workgroup of the launch - and of the `co_resident` launches sharing the device - must be resident at once:
+ * the call checks the grid against the occupancy of the kernel and returns MDR_ERR_UNSUPPORTED (nothing launched) otherwise.
+ * Every spin in the kernel is bounded by `spin_limit` polls (0 = the default, 2^20: about a second); on expiry the workgroup
+ * writes {tag, kind << 28 | workgroup} (kind 1: a house workgroup waiting for totals, 2: a reducer waiting for records) into
+ * word 0 of every rank's mailbox and leaves, every other workgroup sees the word and leaves too, and NOTHING is written back:
+ * the bound buffers then still hold the state before the launch.  The caller reads word 0 of its mailbox after the stream
+ * has drained (0 = ok); a non-zero word means the handle's step count no longer matches its buffers - rebuild both.
+ *
+ * Results: state, last reward / observation planes / actions, P and the accumulators of mdr_rollout_out_t exactly as
+ * nb_steps of mdr_env_step_begin_records / all-gather / mdr_env_step_end_records with MDR_ACTIONS_BANGBANG leave them (state,
+ * P, rewards and reward_sum bit for bit; sq_temp_error_sum is summed per workgroup first).  base_power_mode "interpolation"
+ * returns MDR_ERR_UNSUPPORTED (its update is host work). */
+typedef struct mdr_mailbox {
+  uint32_t struct_size;
+  int32_t world;                          /* shards of the env (1 = unsharded, or a world of one) */
+  int32_t rank;                           /* this shard */
+  int32_t records_per_env;                /* record slots per env and rank in every mailbox: >= every records[r] */
+  int32_t records[MDR_MAX_SHARDS];        /* mdr_env_partial_records() of every rank's handle */
+  int32_t system_scope;                   /* 0: every mailbox is memory of this device; 1: peers are other devices */
+  int32_t co_resident;                    /* persistent launches sharing this device at the same time (>= 1) */
+  uint32_t spin_limit;                    /* polls before a wait gives up; 0 = default */
+  uint32_t reserved0;
+  uint64_t *boxes[MDR_MAX_SHARDS];
+} mdr_mailbox_t;
+int64_t mdr_mailbox_bytes(int32_t nb_envs, int32_t world, int32_t records_per_env);
+/* records a handle of `nb_houses` local houses pushes per env and step (what mdr_mailbox_t.records[] holds for that rank) */
+int64_t mdr_persist_records(int32_t nb_houses);
+int mdr_env_rollout_persistent(mdr_env_t *env, uint8_t *actions, int32_t nb_steps, const mdr_rollout_out_t *out,
+                               const mdr_mailbox_t *mailbox, void *stream);
+/* Mailbox memory other processes / devices can push into: a zero-filled allocation (fine-grained when asked, so that
+ * stores of a peer device become visible inside a running kernel), its 64-byte inter-process handle, and the mapping of a
+ * peer's handle into this process.  Free / close with the matching call.  Plain hipMalloc'ed (or torch) memory serves when
+ * every shard runs on the one device of one process. */
+int mdr_mailbox_alloc(int64_t bytes, int32_t fine_grained, uint64_t **out);
+int mdr_mailbox_free(uint64_t *box);
+int mdr_mailbox_export(uint64_t *box, uint8_t handle[64]);
+int mdr_mailbox_open(const uint8_t handle[64], uint64_t **out);
+int mdr_mailbox_close(uint64_t *box);
+/* Word 0 of a mailbox (the error word) copied to the host: a SYNCHRONOUS 8-byte copy - call it when the stream has drained. */
+int mdr_mailbox_peek(const uint64_t *box, uint64_t *word0);
 
 /* Sharded houses with base_power_mode "interpolation": PowerGrid.interpolatePower (env 1195-1234) averages up to
  * interp_nb_agents houses drawn from the WHOLE env (env 1209-1215), so the update at episode start and every

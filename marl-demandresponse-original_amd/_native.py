@@ -12,10 +12,11 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDR_HIP_LIB") or os.path.join(HERE, "csrc", "libmdr_hip.so")   # MDR_HIP_LIB: experiment builds
 
-MDR_ABI_VERSION = 3
+MDR_ABI_VERSION = 4
 MDR_MAX_SINUSOIDS = 8
 MDR_MAX_CAPACITIES = 16
 MDR_OBS_COLUMNS = 7
+MDR_MAX_SHARDS = 8
 
 MDR_OK, MDR_ERR_INVALID, MDR_ERR_UNBOUND, MDR_ERR_HIP, MDR_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 ACTIONS_EXTERNAL, ACTIONS_BANGBANG = 0, 1
@@ -118,6 +119,15 @@ class MdrRolloutOut(C.Structure):
     ]
 
 
+class MdrMailbox(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("world", C.c_int32), ("rank", C.c_int32), ("records_per_env", C.c_int32),
+        ("records", C.c_int32 * MDR_MAX_SHARDS),
+        ("system_scope", C.c_int32), ("co_resident", C.c_int32), ("spin_limit", C.c_uint32), ("reserved0", C.c_uint32),
+        ("boxes", C.c_void_p * MDR_MAX_SHARDS),
+    ]
+
+
 OBS_PLANES, OBS_ROWS = 0, 1
 
 EXPORTS = (
@@ -128,6 +138,8 @@ EXPORTS = (
     "mdr_env_interp_due", "mdr_env_interp_local", "mdr_env_interp_apply", "mdr_obs_vector_length", "mdr_env_obs_vector",
     "mdr_obs_message_fields", "mdr_env_obs_messages", "mdr_env_obs_vector_ext", "mdr_env_comm_draws",
     "mdr_env_graph_room", "mdr_env_graph_replayed", "mdr_env_pack", "mdr_env_cursor", "mdr_env_set_cursor",
+    "mdr_mailbox_bytes", "mdr_persist_records", "mdr_env_rollout_persistent",
+    "mdr_mailbox_alloc", "mdr_mailbox_free", "mdr_mailbox_export", "mdr_mailbox_open", "mdr_mailbox_close", "mdr_mailbox_peek",
     # include/mdr_policy.h
     "mdr_actor_steps1", "mdr_actor_steps2", "mdr_actor_frag1_floats", "mdr_actor_frag2_floats", "mdr_actor_sample", "mdr_env_actor_sample",
     "mdr_discounted_returns",
@@ -203,6 +215,15 @@ def load():
         "mdr_env_pack": (C.c_int, [vp, i32, vp, vp]),
         "mdr_env_graph_room": (i64, [vp]),
         "mdr_env_graph_replayed": (C.c_int, [vp, i64, vp]),
+        "mdr_mailbox_bytes": (i64, [i32, i32, i32]),
+        "mdr_persist_records": (i64, [i32]),
+        "mdr_env_rollout_persistent": (C.c_int, [vp, vp, i32, C.POINTER(MdrRolloutOut), C.POINTER(MdrMailbox), vp]),
+        "mdr_mailbox_alloc": (C.c_int, [i64, i32, C.POINTER(vp)]),
+        "mdr_mailbox_free": (C.c_int, [vp]),
+        "mdr_mailbox_export": (C.c_int, [vp, C.c_char_p]),
+        "mdr_mailbox_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+        "mdr_mailbox_close": (C.c_int, [vp]),
+        "mdr_mailbox_peek": (C.c_int, [vp, C.POINTER(u64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

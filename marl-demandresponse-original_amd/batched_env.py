@@ -511,6 +511,91 @@ class BatchedDemandResponseEnv:
             nat.check(self._lib, self._handle, rc, "mdr_env_rollout_fused")
         return res
 
+    # ------------------------------------------------------------------ persistent rollout (mailbox exchange, no kernel boundary per step)
+    PERSIST_ERRORS = {1: "a house workgroup waited too long for the totals of a step", 2: "a reducer waited too long for a step's records"}
+
+    def persist_records(self, nb_houses: Optional[int] = None) -> int:
+        """Records one shard of `nb_houses` houses pushes per env and step (one per 1024-house workgroup)."""
+        return int(self._lib.mdr_persist_records(int(self.nb_houses if nb_houses is None else nb_houses)))
+
+    def _persist_mailbox(self, world: int, stride: int) -> torch.Tensor:
+        """This shard's mailbox: zero-filled ONCE, from then on written by the persistent launches only."""
+        box = getattr(self, "_mailbox", None)
+        size = int(self._lib.mdr_mailbox_bytes(self.nb_envs, world, stride)) // 8
+        if box is None or box.numel() != size:
+            box = self._mailbox = torch.zeros(size, dtype=torch.int64, device=self.device)
+        return box
+
+    def persist_status(self) -> int:
+        """Word 0 of the mailbox after the stream has drained: 0 = every persistent launch so far ran to its end."""
+        addr = getattr(self, "_mailbox_addr", None)
+        if addr is None:
+            box = getattr(self, "_mailbox", None)
+            if box is None:
+                return 0
+            addr = box.data_ptr()
+        word = C.c_uint64()
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)
+            nat.check(self._lib, None, self._lib.mdr_mailbox_peek(C.c_void_p(addr), C.byref(word)), "mdr_mailbox_peek")
+        return int(word.value)
+
+    def _persist_raise(self, word: int):
+        kind = (word >> 28) & 0xF
+        raise RuntimeError("persistent rollout gave up at step tag %d (workgroup %d): %s; the buffers hold the state before the launch, "
+                           "the handle's step count does not - rebuild the env" % ((word >> 32) & 0xFFFFFFFF, word & 0x0FFFFFFF,
+                                                                                  self.PERSIST_ERRORS.get(kind, "kind %d" % kind)))
+
+    def _persist_call(self, nb_steps: int, mailbox: "nat.MdrMailbox", power_trace: bool, accumulate: bool, stream=None):
+        E, N = self.nb_envs, self.nb_houses
+        out = nat.MdrRolloutOut()
+        out.struct_size = C.sizeof(nat.MdrRolloutOut)
+        res = {}
+        with torch.cuda.device(self.device):
+            if accumulate:
+                res["reward_sum"] = torch.zeros((E, N), dtype=torch.float32, device=self.device)
+                res["sq_temp_error_sum"] = torch.zeros(E, dtype=torch.float64, device=self.device)
+                res["sq_signal_error_sum"] = torch.zeros(E, dtype=torch.float64, device=self.device)
+                out.reward_sum = res["reward_sum"].data_ptr()
+                out.sq_temp_error_sum = res["sq_temp_error_sum"].data_ptr()
+                out.sq_signal_error_sum = res["sq_signal_error_sum"].data_ptr()
+            if power_trace:
+                res["power_trace"] = torch.zeros((nb_steps, E), dtype=torch.float64, device=self.device)
+                out.power_trace = res["power_trace"].data_ptr()
+            if stream is not None:      # a side stream (LocalShardGroup): behind the accumulators' zero fills
+                stream.wait_stream(torch.cuda.current_stream(self.device))
+            st = self._stream() if stream is None else C.c_void_p(stream.cuda_stream)
+            rc = self._lib.mdr_env_rollout_persistent(self._handle, C.c_void_p(self.t["actions"].data_ptr()), int(nb_steps), C.byref(out),
+                                                      C.byref(mailbox), st)
+            nat.check(self._lib, self._handle, rc, "mdr_env_rollout_persistent")
+        return res
+
+    def rollout_persistent(self, nb_steps: int, power_trace: bool = False, accumulate: bool = True, check: bool = True,
+                           spin_limit: int = 0):
+        """`nb_steps` bang-bang steps in ONE launch per time-table window with the houses resident in registers and the per-step
+        exchange of (cluster power, penalty sum / max) through a mailbox (mdr_env_rollout_persistent): any cluster size on one
+        device - the split path's 1 env x 1,000,000 houses included - and, over torch.distributed, the sharded-houses layout
+        with peer mailboxes instead of the per-step all-gather.  Same results and accumulators as `rollout_fused`; `check`
+        synchronises and raises if a wait inside the kernel gave up (check=False: poll `persist_status()` yourself)."""
+        if self.sharded and hasattr(self._exchange(), "persist_mailbox"):
+            mb, self._mailbox_addr = self._exchange().persist_mailbox(self, spin_limit)
+        else:
+            if self.sharded and not self._exchange_always:
+                raise RuntimeError("rollout_persistent over sharded houses needs an exchange that hands out peer mailboxes")
+            n = self.persist_records()
+            box = self._persist_mailbox(1, n)
+            mb = nat.MdrMailbox()
+            mb.struct_size = C.sizeof(nat.MdrMailbox)
+            mb.world, mb.rank, mb.records_per_env, mb.co_resident, mb.spin_limit = 1, 0, n, 1, int(spin_limit)
+            mb.records[0] = n
+            mb.boxes[0] = box.data_ptr()
+        res = self._persist_call(int(nb_steps), mb, power_trace, accumulate)
+        if check:
+            word = self.persist_status()
+            if word:
+                self._persist_raise(word)
+        return res
+
     def pack_env(self, env_index: int = 0) -> np.ndarray:
         """Host copy of what the dict surface shows of one env (mdr_env_pack): float64 [5 N + 7], one launch + one copy."""
         n = self.nb_houses

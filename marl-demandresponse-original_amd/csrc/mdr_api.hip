@@ -35,6 +35,7 @@ struct mdr_env {
   mdr_interp_grid_t interp{};   // base_power_mode == 1
   bool has_interp = false;
   int64_t interp_steps = 0;     // U: env steps between two interpolatePower calls = ceil(update_period / time_step)
+  uint32_t mailbox_tag = 1;     // persistent rollout: tag of the next step pushed through the mailbox (counts over the handle's life; 0 = never written)
   std::string err;
 };
 
@@ -689,6 +690,126 @@ int mdr_env_rollout_fused(mdr_env_t* env, uint8_t* actions, int32_t nb_steps, co
   }
   return MDR_OK;
 }
+
+int64_t mdr_mailbox_bytes(int32_t nb_envs, int32_t world, int32_t records_per_env) {
+  if (nb_envs < 1 || world < 1 || world > MDR_MAX_SHARDS || records_per_env < 1) return 0;
+  return mdr::persist_mailbox_granules(nb_envs, world, records_per_env) * 8;
+}
+
+int64_t mdr_persist_records(int32_t nb_houses) { return nb_houses < 1 ? 0 : mdr::split_blocks(nb_houses, 256); }
+
+int mdr_env_rollout_persistent(mdr_env_t* env, uint8_t* actions, int32_t nb_steps, const mdr_rollout_out_t* out, const mdr_mailbox_t* mb,
+                               void* stream) {
+  if (!env) return MDR_ERR_INVALID;
+  if (!mb) return fail(env, MDR_ERR_INVALID, "mailbox is NULL");
+  if (mb->struct_size != sizeof(mdr_mailbox_t)) return fail(env, MDR_ERR_INVALID, "mdr_mailbox_t size mismatch (ABI)");
+  if (out && out->struct_size != sizeof(mdr_rollout_out_t)) return fail(env, MDR_ERR_INVALID, "mdr_rollout_out_t size mismatch (ABI)");
+  if (nb_steps < 0) return fail(env, MDR_ERR_INVALID, "nb_steps must be >= 0");
+  if (!env->bound || !env->has_tables) return fail(env, MDR_ERR_UNBOUND, "no episode: call reset/load_episode and begin_episode first");
+  if (env->split_pending) return fail(env, MDR_ERR_INVALID, "step_begin without step_end");
+  if (interp_mode(env)) return fail(env, MDR_ERR_UNSUPPORTED, "interpolated base power: the update is host work between steps");
+  const mdr_config_t& c = env->cfg;
+  if (c.nb_envs > 65535) return fail(env, MDR_ERR_UNSUPPORTED, "the persistent rollout puts the env index on grid.y: nb_envs must be <= 65535");
+  if (mb->world < 1 || mb->world > MDR_MAX_SHARDS || mb->rank < 0 || mb->rank >= mb->world)
+    return fail(env, MDR_ERR_INVALID, "mailbox: need 0 <= rank < world <= MDR_MAX_SHARDS");
+  if (mb->world == 1 && sharded(env)) return fail(env, MDR_ERR_INVALID, "mailbox: a shard of the env needs its peers (world > 1)");
+  if (mb->co_resident < 1) return fail(env, MDR_ERR_INVALID, "mailbox: co_resident must be >= 1");
+  const int64_t mine = mdr::split_blocks(c.nb_houses, 256);   // one record per 256-thread workgroup: 1024 houses, 256 when nb_houses % 4 != 0
+  if (mb->records[mb->rank] != mine) return fail(env, MDR_ERR_INVALID, "mailbox: records[rank] is not this handle's workgroup count");
+  for (int r = 0; r < mb->world; ++r) {
+    if (mb->records[r] < 1 || mb->records[r] > mb->records_per_env) return fail(env, MDR_ERR_INVALID, "mailbox: records[r] must be in [1, records_per_env]");
+    if (!mb->boxes[r] || ((uintptr_t)mb->boxes[r] & 7u) != 0) return fail(env, MDR_ERR_INVALID, "mailbox: boxes[r] is NULL or not 8-byte aligned");
+  }
+  if (nb_steps == 0) return MDR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (capturing(s)) return fail(env, MDR_ERR_INVALID, "the persistent rollout counts its steps on the host: it cannot be captured");
+  const bool sys = mb->system_scope != 0;
+  int64_t resident = 0;
+  hipError_t e = mdr::persist_resident_blocks(c.nb_houses % 4 == 0 ? 4 : 1, sys, &resident);
+  if (e != hipSuccess) return hip_fail(env, e, "occupancy query");
+  const int64_t grid = (mine + 1) * c.nb_envs;
+  if (grid * mb->co_resident > resident) {
+    char msg[200];
+    snprintf(msg, sizeof msg, "persistent rollout: %lld workgroups x %d co-resident launches exceed the %lld the device holds at once",
+             (long long)grid, (int)mb->co_resident, (long long)resident);
+    return fail(env, MDR_ERR_UNSUPPORTED, msg);
+  }
+  int32_t done = 0;
+  while (done < nb_steps) {
+    mdr::StepArgs a;
+    int rc = step_args(env, actions, MDR_ACTIONS_BANGBANG, s, &a);   // refills the tables if the cursor left them
+    if (rc != MDR_OK) return rc;
+    const int64_t room = c.table_steps - (env->k - env->j0);
+    mdr::RolloutArgs r{};
+    r.nsteps = (int)std::min<int64_t>(room, nb_steps - done);
+    if (out) {
+      r.power_trace = out->power_trace ? out->power_trace + (int64_t)done * c.nb_envs : nullptr;
+      r.reward_sum = out->reward_sum;
+      r.sq_temp_error_sum = out->sq_temp_error_sum;
+      r.sq_signal_error_sum = out->sq_signal_error_sum;
+    }
+    mdr::PersistArgs m{};
+    for (int q = 0; q < mb->world; ++q) {
+      m.box[q] = mb->boxes[q];
+      m.nrec[q] = mb->records[q];
+    }
+    m.world = mb->world;
+    m.rank = mb->rank;
+    m.stride = mb->records_per_env;
+    m.tag_base = env->mailbox_tag;
+    m.spin_limit = mb->spin_limit ? mb->spin_limit : (1u << 20);
+    e = mdr::launch_rollout_persist(a, r, m, sys, s);
+    if (e != hipSuccess) return hip_fail(env, e, "rollout_persist");
+    env->mailbox_tag += (uint32_t)r.nsteps + 1u;   // + the pseudo-step that carries the squared temperature errors
+    env->k += r.nsteps;
+    done += r.nsteps;
+  }
+  env->dev_row = env->dev_k = -1;   // graph mode: the device cursor did not move
+  return MDR_OK;
+}
+
+int mdr_mailbox_alloc(int64_t bytes, int32_t fine_grained, uint64_t** out) {
+  if (!out || bytes < 8) return MDR_ERR_INVALID;
+  void* p = nullptr;
+  hipError_t e = fine_grained ? hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained) : hipMalloc(&p, (size_t)bytes);
+  if (e != hipSuccess) return MDR_ERR_HIP;
+  e = hipMemset(p, 0, (size_t)bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    return MDR_ERR_HIP;
+  }
+  *out = (uint64_t*)p;
+  return MDR_OK;
+}
+
+int mdr_mailbox_free(uint64_t* box) { return (!box || hipFree(box) == hipSuccess) ? MDR_OK : MDR_ERR_HIP; }
+
+int mdr_mailbox_export(uint64_t* box, uint8_t handle[64]) {
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  if (!box || !handle) return MDR_ERR_INVALID;
+  hipIpcMemHandle_t h;
+  if (hipIpcGetMemHandle(&h, box) != hipSuccess) return MDR_ERR_HIP;
+  memcpy(handle, &h, 64);
+  return MDR_OK;
+}
+
+int mdr_mailbox_open(const uint8_t handle[64], uint64_t** out) {
+  if (!handle || !out) return MDR_ERR_INVALID;
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, 64);
+  void* p = nullptr;
+  if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) return MDR_ERR_HIP;
+  *out = (uint64_t*)p;
+  return MDR_OK;
+}
+
+int mdr_mailbox_peek(const uint64_t* box, uint64_t* word0) {
+  if (!box || !word0) return MDR_ERR_INVALID;
+  return hipMemcpy(word0, box, 8, hipMemcpyDeviceToHost) == hipSuccess ? MDR_OK : MDR_ERR_HIP;
+}
+
+int mdr_mailbox_close(uint64_t* box) { return (!box || hipIpcCloseMemHandle(box) == hipSuccess) ? MDR_OK : MDR_ERR_HIP; }
 
 int mdr_env_step_begin(mdr_env_t* env, uint8_t* actions, int action_source, void* stream) {
   if (!env) return MDR_ERR_INVALID;

@@ -167,6 +167,24 @@ struct ObserveArgs {
   double inv_obs_norm;
 };
 
+// Persistent sharded rollout (mdr_persist.hip): the mailboxes of every rank, laid out in 8-byte granules as
+//   [PERSIST_HDR header | SLOTS x E x world x stride x PERSIST_G record granules | SLOTS x E x PERSIST_TOT totals granules]
+constexpr int PERSIST_SLOTS = 8;    // mailbox slots a stream of records / totals cycles through (slot = tag mod SLOTS)
+constexpr int PERSIST_DEPTH = 3;    // steps a house workgroup runs ahead of the totals; a peer rank may be another DEPTH + 1 ahead of this rank's reducer: 2 * DEPTH + 2 <= SLOTS
+constexpr int PERSIST_G = 5;        // granules per record: power sum lo / hi, penalty sum lo / hi, penalty max
+constexpr int PERSIST_TOT = 8;      // granules per totals slot (5 used; 64 bytes)
+constexpr int PERSIST_HDR = 16;     // header granules (128 bytes); granule 0 = error word
+struct PersistArgs {
+  uint64_t* box[MDR_MAX_SHARDS];    // every rank's mailbox as this device sees it (box[rank] = this rank's own)
+  int32_t nrec[MDR_MAX_SHARDS];     // records (house workgroups) per env of every rank
+  int32_t world, rank, stride;      // stride = record slots per env and rank (>= every nrec)
+  uint32_t tag_base;                // tag of this launch's step 0 (steps are counted over the life of the handle)
+  uint32_t spin_limit;
+};
+int64_t persist_mailbox_granules(int E, int world, int stride);
+hipError_t persist_resident_blocks(int vec, bool system_scope, int64_t* blocks);   // workgroups of the kernel the device holds at once
+hipError_t launch_rollout_persist(const StepArgs& a, const RolloutArgs& r, const PersistArgs& m, bool system_scope, hipStream_t s);
+
 enum StepKind { STEP_FUSED = 0, STEP_GROUP = 1, STEP_SPLIT = 2, STEP_SINGLE = 3 };
 struct StepPlan {
   int kind, vec, threads, tiles;

@@ -7,6 +7,7 @@
 
 #include "mdr_device.h"
 #include "mdr_kernels.h"
+#include "mdr_step_common.h"
 
 namespace mdr {
 
@@ -388,223 +389,8 @@ hipError_t launch_cursor_set(int32_t* cursor, int32_t row, int32_t k, hipStream_
   return hipGetLastError();
 }
 
-__device__ __forceinline__ float temp_penalty(const StepArgs& a, float pen, double sum_pen, float max_pen) {
-  if (a.penalty_mode == MDR_PENALTY_INDIVIDUAL_L2) return pen;
-  const float common = (float)(sum_pen * a.inv_n_total);
-  if (a.penalty_mode == MDR_PENALTY_COMMON_L2) return common;
-  if (a.penalty_mode == MDR_PENALTY_COMMON_MAX) return max_pen;
-  return __fmaf_rn(a.mix_i, pen, __fmaf_rn(a.mix_c, common, a.mix_m * max_pen));   // explicit: no context-dependent contraction
-}
-
-// r_i = -(alpha_temp * pen_i / norm_T + alpha_sig * sig / norm_S)  (env 364-372); one explicit fma so that every
-// kernel rounds it identically
-__device__ __forceinline__ float reward_value(const StepArgs& a, float pen, double sum_pen, float max_pen, float sig_term) {
-  return -__fmaf_rn(a.c_temp, temp_penalty(a, pen, sum_pen, max_pen), sig_term);
-}
-
-// signal part of the reward with the OLD signal (env 196, 234-251), fp64 per env
-__device__ __forceinline__ float signal_term(const StepArgs& a, double P, double S_old) {
-  const double d = (P - S_old) * a.inv_n_total;
-  return (float)(a.c_sig * d * d);
-}
-
-// ---- (1) one workgroup per env, VEC houses per thread per tile ---------------------------------
-template <typename T, typename V>
-__device__ __forceinline__ void unpack(const V& v, T* out);
-template <>
-__device__ __forceinline__ void unpack<float, float4>(const float4& v, float* o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
-template <>
-__device__ __forceinline__ void unpack<int, int4>(const int4& v, int* o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
-template <>
-__device__ __forceinline__ void unpack<unsigned, uchar4>(const uchar4& v, unsigned* o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
-template <>
-__device__ __forceinline__ void unpack<float, float>(const float& v, float* o) { o[0] = v; }
-template <>
-__device__ __forceinline__ void unpack<int, int>(const int& v, int* o) { o[0] = v; }
-template <>
-__device__ __forceinline__ void unpack<unsigned, unsigned char>(const unsigned char& v, unsigned* o) { o[0] = v; }
-
-template <>
-__device__ __forceinline__ void unpack<float, float2>(const float2& v, float* o) { o[0] = v.x; o[1] = v.y; }
-template <>
-__device__ __forceinline__ void unpack<int, int2>(const int2& v, int* o) { o[0] = v.x; o[1] = v.y; }
-template <>
-__device__ __forceinline__ void unpack<unsigned, uchar2>(const uchar2& v, unsigned* o) { o[0] = v.x; o[1] = v.y; }
-__device__ __forceinline__ float2 pack2(const float* v) { return make_float2(v[0], v[1]); }
-__device__ __forceinline__ int2 pack2(const int* v) { return make_int2(v[0], v[1]); }
-__device__ __forceinline__ uchar2 pack2(const unsigned* v) { return make_uchar2((unsigned char)v[0], (unsigned char)v[1]); }
-
-__device__ __forceinline__ float4 pack4(const float* v) { return make_float4(v[0], v[1], v[2], v[3]); }
-__device__ __forceinline__ int4 pack4(const int* v) { return make_int4(v[0], v[1], v[2], v[3]); }
-__device__ __forceinline__ uchar4 pack4(const unsigned* v) {
-  return make_uchar4((unsigned char)v[0], (unsigned char)v[1], (unsigned char)v[2], (unsigned char)v[3]);
-}
-
-template <int VEC, typename T>
-__device__ __forceinline__ void load_vec(const T* __restrict__ p, int64_t i, T* out) {
-  if constexpr (VEC == 4) {
-    using V = typename std::conditional<std::is_same<T, float>::value, float4, int4>::type;
-    unpack<T, V>(*reinterpret_cast<const V*>(p + i), out);
-  } else if constexpr (VEC == 2) {
-    using V = typename std::conditional<std::is_same<T, float>::value, float2, int2>::type;
-    unpack<T, V>(*reinterpret_cast<const V*>(p + i), out);
-  } else {
-    out[0] = p[i];
-  }
-}
-template <int VEC>
-__device__ __forceinline__ void load_bytes(const uint8_t* __restrict__ p, int64_t i, unsigned* out) {
-  if constexpr (VEC == 4) {
-    unpack<unsigned, uchar4>(*reinterpret_cast<const uchar4*>(p + i), out);
-  } else if constexpr (VEC == 2) {
-    unpack<unsigned, uchar2>(*reinterpret_cast<const uchar2*>(p + i), out);
-  } else {
-    out[0] = p[i];
-  }
-}
-template <int VEC, typename T>
-__device__ __forceinline__ void store_vec(T* __restrict__ p, int64_t i, const T* v) {
-  if constexpr (VEC == 4) {
-    *reinterpret_cast<decltype(pack4(v))*>(p + i) = pack4(v);
-  } else if constexpr (VEC == 2) {
-    *reinterpret_cast<decltype(pack2(v))*>(p + i) = pack2(v);
-  } else {
-    p[i] = v[0];
-  }
-}
-// Output-only streams (reward, observation planes) are never re-read by this library: non-temporal stores keep them
-// from displacing the state/parameter lines in L2/MALL (measured at C3: 66.0 -> 60.3 us per step).  Non-temporal
-// LOADS of the parameters (+3.5 % alone, no gain on top of the stores) and non-temporal STATE stores (-3 %) lose:
-// build with -DMDR_NT_STORES=0 / -DMDR_NT_LOADS=1 / -DMDR_NT_STATE=1 to reproduce.
-#ifndef MDR_NT_STORES
-#define MDR_NT_STORES 1
-#endif
-typedef float v4f_t __attribute__((ext_vector_type(4)));
-typedef float v2f_t __attribute__((ext_vector_type(2)));
-template <int VEC>
-__device__ __forceinline__ void store_out(float* __restrict__ p, int64_t i, const float* v) {
-#if defined(MDR_NT_STORES) && MDR_NT_STORES
-  if constexpr (VEC == 4) {
-    v4f_t x = {v[0], v[1], v[2], v[3]};
-    __builtin_nontemporal_store(x, reinterpret_cast<v4f_t*>(p + i));
-  } else if constexpr (VEC == 2) {
-    v2f_t x = {v[0], v[1]};
-    __builtin_nontemporal_store(x, reinterpret_cast<v2f_t*>(p + i));
-  } else {
-    __builtin_nontemporal_store(v[0], p + i);
-  }
-#else
-  store_vec<VEC>(p, i, v);
-#endif
-}
-template <int VEC>
-__device__ __forceinline__ void load_param(const float* __restrict__ p, int64_t i, float* out) {
-#if defined(MDR_NT_LOADS) && MDR_NT_LOADS
-  if constexpr (VEC == 4) {
-    const v4f_t x = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(p + i));
-    out[0] = x.x; out[1] = x.y; out[2] = x.z; out[3] = x.w;
-  } else if constexpr (VEC == 2) {
-    const v2f_t x = __builtin_nontemporal_load(reinterpret_cast<const v2f_t*>(p + i));
-    out[0] = x.x; out[1] = x.y;
-  } else {
-    out[0] = __builtin_nontemporal_load(p + i);
-  }
-#else
-  load_vec<VEC>(p, i, out);
-#endif
-}
-template <int VEC>
-__device__ __forceinline__ void store_bytes(uint8_t* __restrict__ p, int64_t i, const unsigned* v) {
-  if constexpr (VEC == 4) {
-    *reinterpret_cast<uchar4*>(p + i) = pack4(v);
-  } else if constexpr (VEC == 2) {
-    *reinterpret_cast<uchar2*>(p + i) = pack2(v);
-  } else {
-    p[i] = (uint8_t)v[0];
-  }
-}
-
-// Loads VEC houses starting at flat index i, steps them, stores the new state, returns outputs.
-template <int VEC>
-__device__ __forceinline__ void step_vec(const StepArgs& a, int64_t i, float od_old, float solar, HouseOut* out, int* lockout) {
-  float Ta[VEC], Tm[VEC], k01[VEC], s0[VEC], k10[VEC], s1[VEC], iu[VEC], q[VEC], pm[VEC], tg[VEC], db[VEC];
-  int sso[VEC];
-  unsigned fl[VEC], act[VEC];
-  load_vec<VEC>(a.Ta, i, Ta);
-  load_vec<VEC>(a.Tm, i, Tm);
-  load_vec<VEC>(a.sso, i, sso);
-  load_bytes<VEC>(a.flags, i, fl);
-  if (a.action_source == MDR_ACTIONS_EXTERNAL) load_bytes<VEC>(a.actions, i, act);
-  load_param<VEC>(a.k01, i, k01);
-  load_param<VEC>(a.s0, i, s0);
-  load_param<VEC>(a.k10, i, k10);
-  load_param<VEC>(a.s1, i, s1);
-  load_param<VEC>(a.inv_Ua, i, iu);
-  load_param<VEC>(a.Q_hvac, i, q);
-  load_param<VEC>(a.P_max, i, pm);
-  load_param<VEC>(a.target, i, tg);
-  load_param<VEC>(a.deadband, i, db);
-  load_vec<VEC>(a.lockout, i, lockout);
-  float nTa[VEC], nTm[VEC];
-  int nsso[VEC];
-  unsigned nfl[VEC];
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) {
-    HouseIn h{Ta[v], Tm[v], sso[v], fl[v], k01[v], s0[v], k10[v], s1[v], iu[v], q[v], pm[v], tg[v], db[v], lockout[v]};
-    // BangBangController.act (agents/bangbang_controllers.py:49-59) on the pre-step observation
-    const bool cmd = (a.action_source == MDR_ACTIONS_BANGBANG) ? (Ta[v] > tg[v]) : (act[v] != 0u);
-    if (a.action_source == MDR_ACTIONS_BANGBANG) act[v] = cmd ? 1u : 0u;
-    out[v] = house_step(h, cmd, od_old, solar, a.dt);
-    nTa[v] = out[v].Ta;
-    nTm[v] = out[v].Tm;
-    nsso[v] = out[v].sso;
-    nfl[v] = out[v].flags;
-  }
-#if defined(MDR_NT_STATE) && MDR_NT_STATE
-  store_out<VEC>(a.Ta, i, nTa);
-  store_out<VEC>(a.Tm, i, nTm);
-#else
-  store_vec<VEC>(a.Ta, i, nTa);
-  store_vec<VEC>(a.Tm, i, nTm);
-#endif
-  store_vec<VEC>(a.sso, i, nsso);
-  store_bytes<VEC>(a.flags, i, nfl);
-  if (a.action_source == MDR_ACTIONS_BANGBANG && a.actions != nullptr) store_bytes<VEC>(a.actions, i, act);
-}
-
-// The five observation columns that do not depend on the env-wide reductions.
-template <int VEC>
-__device__ __forceinline__ void store_obs_local(const StepArgs& a, int64_t i, const HouseOut* o, const int* lockout) {
-  float c0[VEC], c1[VEC], c2[VEC], c3[VEC], c4[VEC];
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) {
-    c0[v] = (o[v].Ta + a.obs_tshift) * 0.2f;  // (house_temp - 20) / 5, utils.py:800-802
-    c1[v] = (o[v].Tm + a.obs_tshift) * 0.2f;
-    c2[v] = (o[v].flags & 1u) ? 1.0f : 0.0f;  // utils.py:823
-    c3[v] = (o[v].flags & 2u) ? 1.0f : 0.0f;  // utils.py:824
-    c4[v] = (float)o[v].sso / (float)lockout[v];  // utils.py:826-828
-  }
-  store_out<VEC>(a.obs + 0 * a.plane, i, c0);
-  store_out<VEC>(a.obs + 1 * a.plane, i, c1);
-  store_out<VEC>(a.obs + 2 * a.plane, i, c2);
-  store_out<VEC>(a.obs + 3 * a.plane, i, c3);
-  store_out<VEC>(a.obs + 4 * a.plane, i, c4);
-}
-
-template <int VEC>
-__device__ __forceinline__ void store_reward_power(const StepArgs& a, int64_t i, const float* pen, double sum_pen,
-                                                   float max_pen, float sig_term, float o_sig, float o_pow) {
-  float r[VEC], c5[VEC], c6[VEC];
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) {
-    r[v] = reward_value(a, pen[v], sum_pen, max_pen, sig_term);
-    c5[v] = o_sig;
-    c6[v] = o_pow;
-  }
-  store_out<VEC>(a.reward, i, r);
-  store_out<VEC>(a.obs + 5 * a.plane, i, c5);
-  store_out<VEC>(a.obs + 6 * a.plane, i, c6);
-}
+// temp_penalty / reward_value / signal_term, load_vec / store_vec / store_out, step_vec, store_obs_local, store_reward_power:
+// mdr_step_common.h (shared with mdr_persist.hip)
 
 template <int VEC, int TILES, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_step_fused(StepArgs a) {

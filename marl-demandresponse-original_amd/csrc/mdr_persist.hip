@@ -1,0 +1,390 @@
+// Persistent sharded rollout for MI355X (gfx950, wave64): the bang-bang closed loop of one env whose houses span several
+// workgroups - and several ranks - in ONE launch per time-table window, the houses resident in registers across steps, the
+// per-step exchange (cluster power sum, env 1042-1050; penalty sum / max, env 274-321) through a MAILBOX instead of a
+// kernel boundary and a collective.
+//
+//   house workgroup b of env e   steps its 1024 houses (VEC = 4; 256 when nb_houses % 4 != 0), reduces them to the very
+//                                (power sum, penalty sum, penalty max) record k_step_partial writes, and publishes the record
+//                                into the mailbox of EVERY rank (its own included) - 8-byte granules {tag, 32 data bits}, each
+//                                written by ONE write-through store (sc1; sc0 sc1 towards a peer device), so a granule is its
+//                                own flag and needs no fence (cdna_hip_programming.md Guideline 16, R2);
+//   reducer workgroup of env e   (one per env and rank, blockIdx.x == nblk) polls the world * records granule sets of the
+//                                step, re-sums them in the fixed order of k_step_finish (thread t: ranks in order, records
+//                                t, t + 256, ...; then the workgroup tree) - the totals are bit-identical on every rank and
+//                                to the records path - and publishes the totals as granules; it also keeps the per-env
+//                                accumulators (power trace, squared signal error);
+//   house workgroups             pick the totals up DEPTH steps later (the state does not depend on them - only the
+//                                rewards do - so the houses run ahead and the exchange latency is overlapped) and add the
+//                                step's rewards to the running sums in step order.
+//
+// Tags count steps over the life of the env handle (never reset, never a per-launch memset: a peer may already be pushing
+// into this rank's mailbox when the launch begins); slot = tag mod SLOTS.  Every spin is bounded: on expiry the workgroup
+// writes an error word into the mailbox header of every rank and leaves; the others see the word and leave too; nothing
+// is written back (the state lives in registers), so a failed launch leaves the buffers as they were.
+//
+// Reference: env/MA_DemandResponse.py:1005-1055 (ClusterHouses.step), 234-373 (rewards); main-deploy.py:99-148 (the loop).
+#include <algorithm>
+
+#include "mdr_device.h"
+#include "mdr_kernels.h"
+#include "mdr_step_common.h"
+
+namespace mdr {
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+template <bool SYS>
+__device__ __forceinline__ void granule_store(gu64* p, uint32_t tag, uint32_t value) {
+  const unsigned long long x = ((unsigned long long)tag << 32) | value;
+  if (SYS) __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  else __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool SYS>
+__device__ __forceinline__ unsigned long long granule_load(const gu64* p) {
+  if (SYS) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ int64_t rec_offset(const PersistArgs& m, int E, int slot, int e, int r, int b) {
+  return PERSIST_HDR + ((((int64_t)slot * E + e) * m.world + r) * m.stride + b) * PERSIST_G;
+}
+__device__ __forceinline__ int64_t tot_offset(const PersistArgs& m, int E, int slot, int e) {
+  return PERSIST_HDR + (int64_t)PERSIST_SLOTS * E * m.world * m.stride * PERSIST_G + ((int64_t)slot * E + e) * PERSIST_TOT;
+}
+
+enum : uint32_t { PERSIST_FAIL_TOTALS = 1, PERSIST_FAIL_RECORDS = 2 };
+
+// error word (granule 0 of every rank's header): {tag | kind << 28 | workgroup}; a spinner that finds it set leaves as well
+template <bool SYS>
+__device__ __forceinline__ void raise_abort(const PersistArgs& m, uint32_t tag, uint32_t kind) {
+#pragma unroll
+  for (int r = 0; r < MDR_MAX_SHARDS; ++r)
+    if (r < m.world) granule_store<SYS>((gu64*)m.box[r], tag, (kind << 28) | (blockIdx.x & 0x0FFFFFFFu));
+}
+template <bool SYS>
+__device__ __forceinline__ bool abort_raised(const PersistArgs& m) {
+  return granule_load<SYS>((const gu64*)m.box[m.rank]) != 0ull;
+}
+
+template <int VEC, bool SYS>
+__global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutArgs ro, PersistArgs m) {
+  constexpr int D = PERSIST_DEPTH;
+  __shared__ double lds_part[2][3 * 4];
+  __shared__ double lds_tot[2][3];
+  __shared__ int lds_fail[2];
+  __shared__ int s_nrec[MDR_MAX_SHARDS];
+  const bool need_pen = a.penalty_mode != MDR_PENALTY_INDIVIDUAL_L2;
+  const int ng = need_pen ? PERSIST_G : 2;   // granules that travel: the power sum alone unless a common penalty mode needs the rest
+  const int e = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nblk = m.nrec[m.rank];
+  const int T = ro.nsteps;
+  const bool want_terr = ro.sq_temp_error_sum != nullptr;
+  gu64* const own = (gu64*)m.box[m.rank];
+  if (tid < MDR_MAX_SHARDS) s_nrec[tid] = tid < m.world ? m.nrec[tid] : 0;
+  if (tid < 2) lds_fail[tid] = 0;
+  __syncthreads();
+
+  if (blk == nblk) {
+    // ---------------------------------------------------------------- reducer of env e on this rank
+    double serr = 0.0, P_last = 0.0;
+    Red3 tot{0.0, 0.0, 0.0f};
+    const int last = want_terr ? T : T - 1;   // the pseudo-step T carries the workgroups' squared temperature errors
+    for (int s = 0; s <= last; ++s) {
+      const uint32_t tag = m.tag_base + (uint32_t)s;
+      const int slot = (int)(tag % PERSIST_SLOTS);
+      const int g_now = (s == T) ? 2 : ng;
+      Red3 acc{0.0, 0.0, 0.0f};
+      bool failed = false;
+      for (uint32_t spins = 0;;) {
+        acc = Red3{0.0, 0.0, 0.0f};
+        bool ok = true;
+        // thread t: ranks in order, records t, t + 256, ... - the order of finish_block (mdr_kernels.hip); up to four records'
+        // granules are in flight before the first is looked at
+        int r = 0, b = tid;
+        while (r < m.world) {
+          unsigned long long x[4][PERSIST_G];
+          bool have[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            while (r < m.world && b >= s_nrec[r]) { ++r; b = tid; }
+            have[k] = r < m.world;
+            if (have[k]) {
+              const gu64* rec = own + rec_offset(m, a.E, slot, e, r, b);
+#pragma unroll
+              for (int g = 0; g < PERSIST_G; ++g) x[k][g] = (g < g_now) ? granule_load<SYS>(rec + g) : ((unsigned long long)tag << 32);
+              b += 256;
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (!have[k]) continue;
+#pragma unroll
+            for (int g = 0; g < PERSIST_G; ++g) ok &= (uint32_t)(x[k][g] >> 32) == tag;
+            acc.sum_p += __hiloint2double((int)(uint32_t)x[k][1], (int)(uint32_t)x[k][0]);
+            acc.sum_pen += __hiloint2double((int)(uint32_t)x[k][3], (int)(uint32_t)x[k][2]);
+            acc.max_pen = fmaxf(acc.max_pen, __uint_as_float((uint32_t)x[k][4]));
+          }
+        }
+        if (ok) break;
+        ++spins;
+        if (spins > m.spin_limit || ((spins & 63u) == 0u && abort_raised<SYS>(m))) {
+          failed = true;
+          if (spins > m.spin_limit) raise_abort<SYS>(m, tag, PERSIST_FAIL_RECORDS);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (failed) lds_fail[s & 1] = 1;
+      tot = block_reduce<256>(acc, lds_part[s & 1]);   // one barrier: the failure flag rides on it
+      if (lds_fail[s & 1]) return;
+      if (s == T) {
+        if (tid == 0) ro.sq_temp_error_sum[e] += tot.sum_p;
+        break;
+      }
+      if (tid < ng) {   // the totals, one granule per lane
+        const uint32_t v = tid == 0 ? (uint32_t)__double2loint(tot.sum_p) : tid == 1 ? (uint32_t)__double2hiint(tot.sum_p)
+                         : tid == 2 ? (uint32_t)__double2loint(tot.sum_pen) : tid == 3 ? (uint32_t)__double2hiint(tot.sum_pen)
+                                    : __float_as_uint(tot.max_pen);
+        granule_store<SYS>(own + tot_offset(m, a.E, slot, e) + tid, tag, v);
+      }
+      if (tid == 0) {
+        const int64_t row = (int64_t)s * a.E + e;
+        if (ro.power_trace) ro.power_trace[row] = tot.sum_p;
+        const double d = a.sig_new[row] - tot.sum_p;
+        serr += d * d;
+        P_last = tot.sum_p;
+      }
+    }
+    if (tid == 0 && T > 0) {
+      a.P[e] = P_last;
+      if (ro.sq_signal_error_sum) ro.sq_signal_error_sum[e] += serr;
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ house workgroup
+  const int h = (blk * 256 + tid) * VEC;
+  const bool live = h < a.N;
+  const int64_t i = (int64_t)e * a.N + h;
+  HouseIn hs[VEC];
+  float rsum[VEC], hist[D + 1][VEC];
+  unsigned act[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    hs[v] = HouseIn{};
+    hs[v].lockout = 1;
+    rsum[v] = 0.0f;
+    act[v] = 0u;
+#pragma unroll
+    for (int d = 0; d <= D; ++d) hist[d][v] = 0.0f;
+  }
+  if (live) {
+    float Ta[VEC], Tm[VEC], k01[VEC], s0[VEC], k10[VEC], s1[VEC], iu[VEC], q[VEC], pm[VEC], tg[VEC], db[VEC];
+    int sso[VEC], lk[VEC];
+    unsigned fl[VEC];
+    load_vec<VEC>(a.Ta, i, Ta);
+    load_vec<VEC>(a.Tm, i, Tm);
+    load_vec<VEC>(a.sso, i, sso);
+    load_bytes<VEC>(a.flags, i, fl);
+    load_vec<VEC>(a.k01, i, k01);
+    load_vec<VEC>(a.s0, i, s0);
+    load_vec<VEC>(a.k10, i, k10);
+    load_vec<VEC>(a.s1, i, s1);
+    load_vec<VEC>(a.inv_Ua, i, iu);
+    load_vec<VEC>(a.Q_hvac, i, q);
+    load_vec<VEC>(a.P_max, i, pm);
+    load_vec<VEC>(a.target, i, tg);
+    load_vec<VEC>(a.deadband, i, db);
+    load_vec<VEC>(a.lockout, i, lk);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+      hs[v] = HouseIn{Ta[v], Tm[v], sso[v], fl[v], k01[v], s0[v], k10[v], s1[v], iu[v], q[v], pm[v], tg[v], db[v], lk[v]};
+    if (ro.reward_sum) load_vec<VEC>(ro.reward_sum, i, rsum);   // continue the caller's running sum in step order
+  }
+  double terr = 0.0;
+  Red3 tot{0.0, 0.0, 0.0f};
+  float sig_term = 0.0f;
+  for (int it = 0; it < T + D; ++it) {
+    const int par = it & 1;
+    // the step `it` itself: needs nothing from the other workgroups
+    Red3 acc{0.0, 0.0, 0.0f};
+#pragma unroll
+    for (int d = D; d > 0; --d)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) hist[d][v] = hist[d - 1][v];
+    if (it < T) {
+      const int64_t row = (int64_t)it * a.E + e;
+      const float od_old = a.od_old[row], solar = a.solar_new[row];
+      if (live) {
+        float p = 0.0f, ps = 0.0f, te = 0.0f;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const bool cmd = hs[v].Ta > hs[v].target;   // agents/bangbang_controllers.py:49-59
+          act[v] = cmd ? 1u : 0u;
+          const HouseOut o = house_step(hs[v], cmd, od_old, solar, a.dt);
+          hs[v].Ta = o.Ta;
+          hs[v].Tm = o.Tm;
+          hs[v].sso = o.sso;
+          hs[v].flags = o.flags;
+          hist[0][v] = o.pen;
+          p += o.power;
+          ps += o.pen;
+          acc.max_pen = fmaxf(acc.max_pen, o.pen);
+          if (want_terr) {
+            const float d = o.Ta - hs[v].target;
+            te = fmaf(d, d, te);
+          }
+        }
+        acc.sum_p = (double)p;
+        acc.sum_pen = (double)ps;
+        terr += (double)te;
+      }
+      acc = lanes_reduce<64>(acc, need_pen);
+      if (lane == 0) {
+        lds_part[par][wave] = acc.sum_p;
+        lds_part[par][4 + wave] = acc.sum_pen;
+        lds_part[par][8 + wave] = (double)acc.max_pen;
+      }
+    }
+    // wave 0 fetches the totals of step it - D meanwhile (published by the reducer D steps of work ago)
+    if (wave == 0 && it >= D) {
+      const uint32_t tag = m.tag_base + (uint32_t)(it - D);
+      const gu64* src = own + tot_offset(m, a.E, (int)(tag % PERSIST_SLOTS), e) + lane;
+      uint32_t val = 0;
+      bool failed = false;
+      for (uint32_t spins = 0;;) {
+        const unsigned long long x = lane < ng ? granule_load<SYS>(src) : ((unsigned long long)tag << 32);
+        val = (uint32_t)x;
+        if (__all((uint32_t)(x >> 32) == tag)) break;
+        ++spins;
+        if (spins > m.spin_limit || ((spins & 63u) == 0u && abort_raised<SYS>(m))) {
+          failed = true;
+          if (spins > m.spin_limit && lane == 0) raise_abort<SYS>(m, tag, PERSIST_FAIL_TOTALS);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      const int v0 = __builtin_amdgcn_readlane((int)val, 0), v1 = __builtin_amdgcn_readlane((int)val, 1);
+      const int v2 = __builtin_amdgcn_readlane((int)val, 2), v3 = __builtin_amdgcn_readlane((int)val, 3);
+      const int v4 = __builtin_amdgcn_readlane((int)val, 4);
+      if (lane == 0) {
+        lds_tot[par][0] = __hiloint2double(v1, v0);
+        lds_tot[par][1] = __hiloint2double(v3, v2);
+        lds_tot[par][2] = (double)__int_as_float(v4);
+        if (failed) lds_fail[par] = 1;
+      }
+    }
+    __syncthreads();
+    if (lds_fail[par]) return;
+    if (it < T) {
+      // this workgroup's record: the same arithmetic as block_reduce (every thread re-adds the wave partials in order)
+      Red3 rec{0.0, 0.0, 0.0f};
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        rec.sum_p += lds_part[par][w];
+        rec.sum_pen += lds_part[par][4 + w];
+        rec.max_pen = fmaxf(rec.max_pen, (float)lds_part[par][8 + w]);
+      }
+      if (wave == 0 && lane < ng) {
+        const uint32_t tag = m.tag_base + (uint32_t)it;
+        const int slot = (int)(tag % PERSIST_SLOTS);
+        const uint32_t v = lane == 0 ? (uint32_t)__double2loint(rec.sum_p) : lane == 1 ? (uint32_t)__double2hiint(rec.sum_p)
+                         : lane == 2 ? (uint32_t)__double2loint(rec.sum_pen) : lane == 3 ? (uint32_t)__double2hiint(rec.sum_pen)
+                                     : __float_as_uint(rec.max_pen);
+        const int64_t off = rec_offset(m, a.E, slot, e, m.rank, blk) + lane;
+#pragma unroll
+        for (int r = 0; r < MDR_MAX_SHARDS; ++r)
+          if (r < m.world) granule_store<SYS>((gu64*)m.box[r] + off, tag, v);
+      }
+    }
+    if (it >= D) {   // rewards of step it - D, in step order
+      const int64_t row = (int64_t)(it - D) * a.E + e;
+      tot.sum_p = lds_tot[par][0];
+      tot.sum_pen = lds_tot[par][1];
+      tot.max_pen = (float)lds_tot[par][2];
+      sig_term = signal_term(a, tot.sum_p, a.sig_old[row]);
+      if (ro.reward_sum != nullptr && live) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) rsum[v] = __fadd_rn(rsum[v], reward_value(a, hist[D][v], tot.sum_pen, tot.max_pen, sig_term));
+      }
+    }
+  }
+  if (T <= 0) return;
+  if (want_terr) {   // pseudo-step T: this workgroup's squared temperature error travels as one more record
+    Red3 r{terr, 0.0, 0.0f};
+    r = block_reduce<256>(r, lds_part[(T + D) & 1]);
+    if (tid < 2) {
+      const uint32_t tag = m.tag_base + (uint32_t)T;
+      const uint32_t v = tid == 0 ? (uint32_t)__double2loint(r.sum_p) : (uint32_t)__double2hiint(r.sum_p);
+      const int64_t off = rec_offset(m, a.E, (int)(tag % PERSIST_SLOTS), e, m.rank, blk) + tid;
+#pragma unroll
+      for (int rr = 0; rr < MDR_MAX_SHARDS; ++rr)
+        if (rr < m.world) granule_store<SYS>((gu64*)m.box[rr] + off, tag, v);
+    }
+  }
+  if (!live) return;
+  // final state, and the last step's outputs exactly as the single-step kernels leave them
+  const int64_t row = (int64_t)(T - 1) * a.E + e;
+  const float o_sig = (float)(a.sig_new[row] * a.inv_obs_norm);
+  const float o_pow = (float)(tot.sum_p * a.inv_obs_norm);
+  float nTa[VEC], nTm[VEC], pen[VEC];
+  int nsso[VEC], lk[VEC];
+  unsigned nfl[VEC];
+  HouseOut o[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    nTa[v] = hs[v].Ta;
+    nTm[v] = hs[v].Tm;
+    nsso[v] = hs[v].sso;
+    nfl[v] = hs[v].flags;
+    lk[v] = hs[v].lockout;
+    pen[v] = hist[D][v];
+    o[v] = HouseOut{hs[v].Ta, hs[v].Tm, hs[v].sso, hs[v].flags, hist[D][v], 0.0f};
+  }
+  store_vec<VEC>(a.Ta, i, nTa);
+  store_vec<VEC>(a.Tm, i, nTm);
+  store_vec<VEC>(a.sso, i, nsso);
+  store_bytes<VEC>(a.flags, i, nfl);
+  if (a.actions != nullptr) store_bytes<VEC>(a.actions, i, act);
+  store_obs_local<VEC>(a, i, o, lk);
+  store_reward_power<VEC>(a, i, pen, tot.sum_pen, tot.max_pen, sig_term, o_sig, o_pow);
+  if (ro.reward_sum) store_vec<VEC>(ro.reward_sum, i, rsum);
+}
+
+int64_t persist_mailbox_granules(int E, int world, int stride) {
+  return PERSIST_HDR + (int64_t)PERSIST_SLOTS * E * world * stride * PERSIST_G + (int64_t)PERSIST_SLOTS * E * PERSIST_TOT;
+}
+
+template <typename K>
+static hipError_t persist_capacity(K kernel, int64_t* blocks) {
+  int dev = 0, per_cu = 0, cus = 0;
+  hipError_t err = hipGetDevice(&dev);
+  if (err != hipSuccess) return err;
+  err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0);
+  if (err != hipSuccess) return err;
+  err = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (err != hipSuccess) return err;
+  // the runtime's answer can be one workgroup per CU above what the hardware admits once a kernel needs more than 80 scalar
+  // registers (MI355X_MICROARCH.md, residency): this kernel is built for four workgroups per CU (launch bounds), count no more
+  *blocks = (int64_t)std::min(per_cu, 4) * cus;
+  return hipSuccess;
+}
+
+hipError_t persist_resident_blocks(int vec, bool sys, int64_t* blocks) {
+  if (vec == 4) return sys ? persist_capacity(k_rollout_persist<4, true>, blocks) : persist_capacity(k_rollout_persist<4, false>, blocks);
+  return sys ? persist_capacity(k_rollout_persist<1, true>, blocks) : persist_capacity(k_rollout_persist<1, false>, blocks);
+}
+
+hipError_t launch_rollout_persist(const StepArgs& a, const RolloutArgs& r, const PersistArgs& m, bool sys, hipStream_t s) {
+  const dim3 g((unsigned)(m.nrec[m.rank] + 1), (unsigned)a.E), b(256);
+  if (a.N % 4 == 0) {
+    if (sys) hipLaunchKernelGGL((k_rollout_persist<4, true>), g, b, 0, s, a, r, m);
+    else hipLaunchKernelGGL((k_rollout_persist<4, false>), g, b, 0, s, a, r, m);
+  } else {
+    if (sys) hipLaunchKernelGGL((k_rollout_persist<1, true>), g, b, 0, s, a, r, m);
+    else hipLaunchKernelGGL((k_rollout_persist<1, false>), g, b, 0, s, a, r, m);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace mdr

@@ -181,6 +181,59 @@ class TorchDistExchange:
         dist.all_gather_into_tensor(out.view(world * padded.shape[0], padded.shape[1], padded.shape[2]), padded, group=self.process_group)
         return out
 
+    def persist_mailbox(self, env, spin_limit: int = 0):
+        """The mailboxes of the persistent rollout (mdr_env_rollout_persistent) across processes: every rank allocates its own
+        (zero-filled, fine-grained so that a peer device's stores become visible inside the running kernel), the 64-byte
+        inter-process handles travel through one all_gather_object, and every rank maps its peers' boxes.  Done once per env;
+        returns (mdr_mailbox_t, address of this rank's box)."""
+        import ctypes as C
+        import os
+        import torch.distributed as dist
+        from . import _native as nat
+        cached = getattr(env, "_persist_dist", None)
+        if cached is not None:
+            cached[0].spin_limit = int(spin_limit)
+            return cached[0], cached[1]
+        lib = env._lib
+        world, rank = dist.get_world_size(self.process_group), dist.get_rank(self.process_group)
+        if world > nat.MDR_MAX_SHARDS:
+            raise ValueError("the mailbox exchange serves at most %d shards" % nat.MDR_MAX_SHARDS)
+        ranges, _ = self.ranges(env)
+        recs = [env.persist_records(cnt) for _, cnt in ranges]
+        stride = max(recs)
+        nbytes = int(lib.mdr_mailbox_bytes(env.nb_envs, world, stride))
+        own = C.c_void_p()
+        import torch
+        with torch.cuda.device(env.device):
+            fine = 0 if os.environ.get("MDR_MAILBOX_COARSE") == "1" else 1
+            nat.check(lib, None, lib.mdr_mailbox_alloc(nbytes, fine, C.byref(own)), "mdr_mailbox_alloc")
+            handle = C.create_string_buffer(64)
+            boxes = [None] * world
+            if world > 1:
+                nat.check(lib, None, lib.mdr_mailbox_export(own, handle), "mdr_mailbox_export")
+                handles = [None] * world
+                dist.all_gather_object(handles, bytes(handle.raw), group=self.process_group)
+                for r in range(world):
+                    if r == rank:
+                        continue
+                    peer = C.c_void_p()
+                    nat.check(lib, None, lib.mdr_mailbox_open(handles[r], C.byref(peer)), "mdr_mailbox_open")
+                    boxes[r] = peer.value
+            boxes[rank] = own.value
+        mb = nat.MdrMailbox()
+        mb.struct_size = C.sizeof(nat.MdrMailbox)
+        mb.world, mb.rank, mb.records_per_env, mb.co_resident, mb.spin_limit = world, rank, stride, 1, int(spin_limit)
+        # ranks of one device (the one-GPU rehearsal) crowd the same compute units: count them all for the residency check
+        mb.co_resident = int(os.environ.get("MDR_MAILBOX_CO_RESIDENT", "1"))
+        mb.system_scope = 1 if world > 1 else 0
+        for r in range(world):
+            mb.records[r] = recs[r]
+            mb.boxes[r] = boxes[r]
+        if world > 1:
+            dist.barrier(group=self.process_group)      # nobody pushes before every mapping exists
+        env._persist_dist = (mb, own.value, boxes)
+        return mb, own.value
+
     def gather_totals(self, env):
         import torch
         import torch.distributed as dist
@@ -287,6 +340,45 @@ class LocalShardGroup:
         if self.nb_shards > 1:
             self._finish()
         return [(e.t["obs"], e.t["reward"]) for e in self.shards]
+
+    def rollout_persistent(self, nb_steps: int, power_trace: bool = False, accumulate: bool = True, check: bool = True,
+                           spin_limit: int = 0):
+        """Every shard's persistent rollout (mdr_env_rollout_persistent) at once, the shards pushing their per-step records into
+        each other's mailboxes: the one-process rehearsal of the peer-to-peer exchange that replaces the per-step all-gather.
+        The launches go out on one stream per shard and must be resident TOGETHER (each call checks its grid x nb_shards against
+        the device); shards on several devices of one process are refused (peer mailboxes need fine-grained memory: one process
+        per GPU, TorchDistExchange.persist_mailbox).  Returns one accumulator dict per shard."""
+        import ctypes as C
+        import torch
+        from . import _native as nat
+        if len({e.device for e in self.shards}) != 1:
+            raise NotImplementedError("LocalShardGroup.rollout_persistent drives the shards of ONE device; across devices use one process per GPU")
+        dev = self.shards[0].device
+        W = self.nb_shards
+        recs = [e.persist_records() for e in self.shards]
+        stride = max(recs)
+        boxes = [e._persist_mailbox(W, stride) for e in self.shards]
+        streams = getattr(self, "_persist_streams", None)
+        if streams is None:
+            streams = self._persist_streams = [torch.cuda.Stream(device=dev) for _ in range(W)]
+        cur = torch.cuda.current_stream(dev)
+        results = []
+        for r, env in enumerate(self.shards):
+            mb = nat.MdrMailbox()
+            mb.struct_size = C.sizeof(nat.MdrMailbox)
+            mb.world, mb.rank, mb.records_per_env, mb.co_resident, mb.spin_limit = W, r, stride, W, int(spin_limit)
+            for q in range(W):
+                mb.records[q] = recs[q]
+                mb.boxes[q] = boxes[q].data_ptr()
+            results.append(env._persist_call(int(nb_steps), mb, power_trace, accumulate, stream=streams[r]))
+        for st in streams:
+            cur.wait_stream(st)
+        if check:
+            for env in self.shards:
+                word = env.persist_status()
+                if word:
+                    env._persist_raise(word)
+        return results
 
     def ranges(self, env):
         return [(e.house_offset, e.nb_houses) for e in self.shards], self.shards.index(env)

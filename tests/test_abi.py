@@ -49,6 +49,7 @@ def test_library_is_built_and_exports_header_symbols():
 
 @pytest.mark.parametrize("cname,cls", [("mdr_config", nat.MdrConfig), ("mdr_buffers", nat.MdrBuffers), ("mdr_episode", nat.MdrEpisode),
                                         ("mdr_obs_spec", nat.MdrObsSpec), ("mdr_rollout_out", nat.MdrRolloutOut), ("mdr_interp_grid", nat.MdrInterpGrid),
+                                        ("mdr_mailbox", nat.MdrMailbox),
                                         ("mdr_actor", None)])
 def test_ctypes_mirror_matches_header(cname, cls):
     if cls is None:
