@@ -28,7 +28,7 @@ def _struct_fields(text, name):
         decl = decl.strip()
         if not decl:
             continue
-        decl = re.sub(r"^(const\s+)?(uint32_t|int32_t|int64_t|uint8_t|double|float|void)\s+", "", decl)
+        decl = re.sub(r"^(const\s+)?(uint32_t|int32_t|int64_t|uint64_t|uint8_t|double|float|void)\s+", "", decl)
         for part in decl.split(","):
             fields.append(re.sub(r"[\s\*]|\[.*?\]|const", "", part))
     return fields
