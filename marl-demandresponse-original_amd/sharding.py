@@ -341,45 +341,6 @@ class LocalShardGroup:
             self._finish()
         return [(e.t["obs"], e.t["reward"]) for e in self.shards]
 
-    def rollout_persistent(self, nb_steps: int, power_trace: bool = False, accumulate: bool = True, check: bool = True,
-                           spin_limit: int = 0):
-        """Every shard's persistent rollout (mdr_env_rollout_persistent) at once, the shards pushing their per-step records into
-        each other's mailboxes: the one-process rehearsal of the peer-to-peer exchange that replaces the per-step all-gather.
-        The launches go out on one stream per shard and must be resident TOGETHER (each call checks its grid x nb_shards against
-        the device); shards on several devices of one process are refused (peer mailboxes need fine-grained memory: one process
-        per GPU, TorchDistExchange.persist_mailbox).  Returns one accumulator dict per shard."""
-        import ctypes as C
-        import torch
-        from . import _native as nat
-        if len({e.device for e in self.shards}) != 1:
-            raise NotImplementedError("LocalShardGroup.rollout_persistent drives the shards of ONE device; across devices use one process per GPU")
-        dev = self.shards[0].device
-        W = self.nb_shards
-        recs = [e.persist_records() for e in self.shards]
-        stride = max(recs)
-        boxes = [e._persist_mailbox(W, stride) for e in self.shards]
-        streams = getattr(self, "_persist_streams", None)
-        if streams is None:
-            streams = self._persist_streams = [torch.cuda.Stream(device=dev) for _ in range(W)]
-        cur = torch.cuda.current_stream(dev)
-        results = []
-        for r, env in enumerate(self.shards):
-            mb = nat.MdrMailbox()
-            mb.struct_size = C.sizeof(nat.MdrMailbox)
-            mb.world, mb.rank, mb.records_per_env, mb.co_resident, mb.spin_limit = W, r, stride, W, int(spin_limit)
-            for q in range(W):
-                mb.records[q] = recs[q]
-                mb.boxes[q] = boxes[q].data_ptr()
-            results.append(env._persist_call(int(nb_steps), mb, power_trace, accumulate, stream=streams[r]))
-        for st in streams:
-            cur.wait_stream(st)
-        if check:
-            for env in self.shards:
-                word = env.persist_status()
-                if word:
-                    env._persist_raise(word)
-        return results
-
     def ranges(self, env):
         return [(e.house_offset, e.nb_houses) for e in self.shards], self.shards.index(env)
 

@@ -98,35 +98,66 @@ class _OneShard:
         return env.t["partials"].unsqueeze(0), 1
 
 
-@pytest.mark.parametrize("N,shards,mode,E", [(20000, 2, "individual_L2", 1), (30000, 3, "mixture", 2), (9001, 4, "common_L2", 1)])
-def test_shards_on_one_gpu_exchange_through_mailboxes(N, shards, mode, E):
-    """>= 2 shards of the same env resident together on the one GPU (one stream each), pushing their records into each
-    other's mailboxes: state, P, signal, rewards and reward sums bit-identical to the records path over three table refills."""
-    from mdr_amd.sharding import LocalShardGroup
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _ipc_worker(rank, world, port, N, mode, E, T):
+    """One rank of `world` processes sharing the one GPU: its shard through the records path (gloo all-gather per step) and
+    through the persistent rollout with peer mailboxes mapped over hipIpc - the production layout of one process per GPU,
+    rehearsed on one device (the kernels of the ranks are resident together and push into each other's boxes)."""
+    import os
+    import torch.distributed as dist
+    import mdr_amd
+    from mdr_amd.sharding import house_shard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      MDR_MAILBOX_CO_RESIDENT=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
     cfg = _cfg(N, mode)
-    T = 40
-    rec = LocalShardGroup(cfg, nb_envs=E, nb_shards=shards, devices=("cuda:0",), seed=17, table_steps=16)
-    per = LocalShardGroup(cfg, nb_envs=E, nb_shards=shards, devices=("cuda:0",), seed=17, table_steps=16)
+    shard = house_shard(N, world, rank)
+    rec = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=17, table_steps=16, house_shard=shard)
+    per = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=17, table_steps=16, house_shard=shard)
     rec.reset(episode=1)
     per.reset(episode=1)
-    rsum = [torch.zeros_like(e.t["reward"]) for e in rec.shards]
-    trace = []
-    for _ in range(T):
-        rec.step_bangbang()
-        rsum = [a + e.t["reward"] for a, e in zip(rsum, rec.shards)]
-        trace.append(rec.cluster_hvac_power().clone())
+    want = _stepwise(rec, T)
     got = per.rollout_persistent(T, power_trace=True)
-    for r, (a, b) in enumerate(zip(per.shards, rec.shards)):
-        for name in STATE:
-            assert torch.equal(a.t[name], b.t[name]), (r, name)
-        assert torch.equal(a.reg_signal(), b.reg_signal())
-        assert torch.equal(got[r]["reward_sum"], rsum[r]), r
-        assert torch.equal(got[r]["power_trace"], torch.stack(trace)), r
-        assert a.persist_status() == 0
-    # every rank's reducer saw every rank's records: the env-wide accumulators are replicated
-    for r in range(1, shards):
-        assert torch.equal(got[r]["sq_temp_error_sum"], got[0]["sq_temp_error_sum"])
-        assert torch.equal(got[r]["sq_signal_error_sum"], got[0]["sq_signal_error_sum"])
+    assert per.persist_status() == 0
+    for name in STATE:
+        assert torch.equal(per.t[name], rec.t[name]), (rank, name)
+    assert torch.equal(per.reg_signal(), rec.reg_signal())
+    assert torch.equal(got["reward_sum"], want["reward_sum"])
+    assert torch.equal(got["power_trace"], want["power_trace"])
+    # every rank's reducer saw every rank's records: the env-wide accumulators are replicated bit for bit
+    for key in ("sq_temp_error_sum", "sq_signal_error_sum"):
+        mine = got[key].cpu()
+        both = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        assert all(torch.equal(both[0], b) for b in both), key
+    torch.testing.assert_close(got["sq_signal_error_sum"], want["sq_signal_error_sum"], rtol=1e-12, atol=0)
+    # a second call: tags keep counting across launches and ranks
+    want2 = _stepwise(rec, 7)
+    got2 = per.rollout_persistent(7)
+    for name in STATE:
+        assert torch.equal(per.t[name], rec.t[name]), (rank, name)
+    assert torch.equal(got2["reward_sum"], want2["reward_sum"])
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,world,mode,E", [(20000, 2, "individual_L2", 1), (30000, 3, "mixture", 2), (9001, 4, "common_L2", 1),
+                                            (500000, 4, "individual_L2", 1)])
+def test_ranks_on_one_gpu_exchange_through_ipc_mailboxes(N, world, mode, E):
+    """>= 2 ranks (one process each, as on an 8-GPU node) resident together on the one GPU, their mailboxes mapped into each other
+    over hipIpc: state, P, signal, rewards and reward sums bit-identical to the records path over three table refills."""
+    import torch.multiprocessing as mp
+    mp.spawn(_ipc_worker, args=(world, _free_port(), N, mode, E, 40), nprocs=world, join=True)
 
 
 def test_a_missing_peer_ends_in_an_error_word_not_a_hang():
