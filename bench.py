@@ -17,7 +17,12 @@ its own 4096 envs (independent replicas, env_offset = rank * 4096, no data-path 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects, plus two
 secondary legs measured after the timed region of the headline (BASELINE.json configs[3] and configs[4]):
   `ppo_rollout`  policy-in-the-loop rollout collection on the same per-rank batch (observation -> actor -> sample -> step);
-  `c5`           1 env x 1,000,000 houses sharded over the N ranks with the per-step exchange (kernel / collective split).
+  `c5`           1 env x 1,000,000 houses sharded over the N ranks with the per-step exchange (kernel / collective split);
+  `c5_graph`     the same step captured in a hipGraph;
+  `c5_persistent` the same env through the persistent rollout: houses resident in registers across steps, the per-step exchange
+                 through peer mailboxes instead of a collective (N > 1: measured in one child process per rank, so that a fault on
+                 the peer-to-peer path cannot cost the line).
+`degraded: true` at the top level whenever a leg carries `error` or an exchange did not run over RCCL.
 """
 from __future__ import annotations
 
@@ -127,6 +132,19 @@ def traffic_from_profiles():
     return (None, None) if best is None else (best.get("hbm_bytes_per_launch"), src)
 
 
+def out_of_cache_from_profiles():
+    """Rate of the step kernel with the re-read set at 8x the Infinity Cache (32768 envs x 1024 houses), from the newest committed
+    rocprofv3 + PMC passes (profiles/r*_traffic_32768envs.json): a profile constant, not a measurement of this run."""
+    best, src = None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic_32768envs.json"))):
+        try:
+            with open(path) as f:
+                best, src = json.load(f), os.path.relpath(path, ROOT)
+        except Exception:
+            pass
+    return (None, None) if best is None else (best.get("achieved_GBps_from_rocprof_avg"), src)
+
+
 def free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -159,6 +177,7 @@ def parse(argv):
     ap.add_argument("--leg-timeout", type=float, default=float(os.environ.get("MDR_BENCH_LEG_TIMEOUT", "240")),
                     help="seconds the secondary legs may take before the headline line is printed without them")
     ap.add_argument("--stagger", type=int, default=int(os.environ.get("MDR_STAGGER", "2304")))
+    ap.add_argument("--persist-child", action="store_true", help=argparse.SUPPRESS)      # one rank of the c5_persistent leg at N > 1
     return ap.parse_args(argv)
 
 
@@ -339,6 +358,109 @@ def c5_leg(rk: Ranks, mdr, args, graph=False):
                     "collective = the all-gather alone, back to back" % cnt}
 
 
+def persist_measure(env, K, fence, max_over_ranks):
+    """Warm-up (same step counts as the c5 legs: equal checksums), then K timed steps of the persistent rollout, with and
+    without the accumulators of main-deploy.py:124-152."""
+    import torch
+    out = {}
+    env.rollout_persistent(20, check=False)
+    env.rollout_persistent(K, check=False)
+    for key, acc in (("us_per_step", True), ("us_per_step_no_accumulators", False)):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fence()
+        t0 = time.perf_counter()
+        ev0.record()
+        env.rollout_persistent(K, accumulate=acc, check=False)
+        ev1.record()
+        fence()
+        wall = max_over_ranks(time.perf_counter() - t0)
+        out[key] = wall / K * 1e6
+        out["event_" + key + "_rank0"] = ev0.elapsed_time(ev1) / K * 1e3
+        if acc:
+            out["checksum_Ta"] = float(env.t["Ta"].double().sum())      # after 20 + 2 K steps, as the c5 legs
+    word = env.persist_status()
+    if word:
+        raise RuntimeError("a wait inside the persistent kernel gave up: error word 0x%x" % word)
+    return out
+
+
+PERSIST_NOTE = ("mdr_env_rollout_persistent: ONE launch per 64-step table window, each 1024-house workgroup keeps its houses in registers "
+                "and pushes its (power sum, penalty sum, max) record as tagged 8-byte granules into every rank's mailbox; one reducer "
+                "workgroup per rank re-sums them in the order of step_end_records (bit-identical totals); the houses run up to 7 steps ahead "
+                "of the totals. us_per_step includes the per-agent reward sums, squared temperature / signal errors; checksum_Ta equals the "
+                "c5 leg's")
+
+
+def c5_persistent_leg(rk: Ranks, mdr, args):
+    """BASELINE.json configs[4] without a kernel boundary or a collective per step ('compare RCCL vs a P2P mailbox')."""
+    K = args.c5_steps
+    base = {"metric": "house-steps/s, 1 env x 1,000,000 houses sharded over the ranks, persistent kernel + mailbox exchange",
+            "unit": "house-steps/s", "n_gpus": rk.world, "scaling": "strong", "steps": K, "note": PERSIST_NOTE}
+    if rk.world == 1:
+        cfg = c3_config(mdr)
+        cfg["default_env_prop"]["cluster_prop"]["nb_agents"] = C5_HOUSES
+        env = mdr.BatchedDemandResponseEnv(cfg, nb_envs=1, device=rk.device, seed=2024, table_steps=64)
+        env.reset(episode=0)
+        m = persist_measure(env, K, rk.fence, rk.max_over_ranks)
+        base.update(m)
+        base.update({"value": C5_HOUSES * K / (m["us_per_step"] * 1e-6 * K), "houses_per_rank": C5_HOUSES, "exchange": "mailbox on this device (a world of one)"})
+        return base
+    # N > 1: peer mailboxes over hipIpc / xGMI have never run on hardware before the driver's own scaling run - every rank measures
+    # in a child process of its own (own process group over gloo, no RCCL: the data path has no collective), so that whatever
+    # happens there the parent still prints its line
+    port = [free_port() if rk.rank == 0 else 0]
+    rk.dist.broadcast_object_list(port, src=0)
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port[0]), MDR_BENCH_CHILD_DEVICE=str(rk.device.index))
+    if rk.backend != "nccl":      # the one-GPU rehearsal (MDR_BENCH_BACKEND=gloo): every rank's launch must be resident on the same device
+        env["MDR_MAILBOX_CO_RESIDENT"] = str(rk.world)
+    res = subprocess.run([sys.executable, os.path.abspath(__file__), "--persist-child", "--gpus", str(rk.world), "--c5-steps", str(K)],
+                         env=env, capture_output=True, text=True, timeout=max(30.0, args.leg_timeout / 3))
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    if res.returncode != 0 or (rk.rank == 0 and not lines):
+        raise RuntimeError("child rc %d: %s" % (res.returncode, (res.stderr or res.stdout)[-400:]))
+    if rk.rank == 0:
+        base.update(json.loads(lines[-1]))
+    return base
+
+
+def persist_child(args):
+    """One rank of the c5_persistent leg at N > 1 (started by c5_persistent_leg): its shard of the 1,000,000 houses, peer mailboxes
+    mapped over hipIpc, fences over gloo.  Rank 0 prints the leg's numbers as one JSON line."""
+    import torch
+    import torch.distributed as dist
+    import mdr_amd
+    from mdr_amd.sharding import house_shard
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dev = torch.device("cuda", int(os.environ.get("MDR_BENCH_CHILD_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = c3_config(mdr_amd)
+    cfg["default_env_prop"]["cluster_prop"]["nb_agents"] = C5_HOUSES
+    off, cnt = house_shard(C5_HOUSES, world, rank)
+    env = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=1, device=dev, seed=2024, house_shard=(off, cnt), table_steps=64)
+    env.reset(episode=0)
+
+    def fence():
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def max_over_ranks(seconds):
+        t = torch.tensor([seconds], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    m = persist_measure(env, args.c5_steps, fence, max_over_ranks)
+    parts = [None] * world
+    dist.all_gather_object(parts, m["checksum_Ta"])
+    if rank == 0:
+        m.update({"value": C5_HOUSES / (m["us_per_step"] * 1e-6), "houses_per_rank": cnt, "checksum_Ta_ranks": parts,
+                  "exchange": "peer mailboxes mapped over hipIpc (fine-grained memory, system-scope granules); fences over gloo"})
+        emit(m)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def dry_rank(rk: Ranks, args):
     """MDR_BENCH_DRY=1: rehearse launcher, rendezvous, fence and max-over-ranks without a GPU (tests/test_bench_launch.py).
     No kernel runs and the line says so; it is never a result."""
@@ -401,9 +523,22 @@ def run_rank(args):
                          "cache_note": "C3 re-reads 53 B/house = 222 MB per step, below the 256 MiB Infinity Cache: part of this rate is "
                                        "cache-assisted; the size sweep in profiles/ (r02_size_sweep.jsonl) gives the rate with the re-read set at 2-8x the cache"},
         }
+        ooc, ooc_src = out_of_cache_from_profiles()
+        if ooc is not None:
+            line["roofline"]["frac_out_of_cache"] = ooc / HBM_PEAK_GBS
+            line["roofline"]["out_of_cache_source"] = "%s: %.0f GB/s at 32768 envs x 1024 houses (re-read set 8x the Infinity Cache), profile constant" % (ooc_src, ooc)
         if rk.backend_note:
             line["backend_note"] = rk.backend_note
         line.update(legs)
+        # rc 0 alone proves nothing (a failing leg never costs the line): say so in ONE place
+        reasons = ["%s: %s" % (n, v["error"]) for n, v in legs.items() if isinstance(v, dict) and "error" in v]
+        reasons += ["%s ran over %s, not RCCL" % (n, v["backend"]) for n, v in legs.items()
+                    if isinstance(v, dict) and v.get("backend") not in (None, "rccl")]
+        if rk.backend_note:
+            reasons.append(rk.backend_note)
+        line["degraded"] = bool(reasons)
+        if reasons:
+            line["degraded_reasons"] = reasons
         return line
 
     # The secondary legs never cost the headline: the headline is measured by now, and if a leg has not returned after
@@ -411,7 +546,7 @@ def run_rank(args):
     # rank leaves through os._exit - a hung leg would otherwise take the scaling curve with it.
     legs, lock, printed = {}, threading.Lock(), [False]
     leg_list = (("ppo_rollout", lambda: ppo_leg(rk, env, args)), ("c5", lambda: c5_leg(rk, mdr_amd, args)),
-                ("c5_graph", lambda: c5_leg(rk, mdr_amd, args, graph=True)))
+                ("c5_graph", lambda: c5_leg(rk, mdr_amd, args, graph=True)), ("c5_persistent", lambda: c5_persistent_leg(rk, mdr_amd, args)))
     baseline = None
     if rk.rank == 0 and rk.world == 1 and not args.no_cpu_baseline:      # before the legs: a leg that hangs must not cost the line its baseline
         baseline = cpu_baseline(cfg, args.cpu_seconds)
@@ -458,6 +593,8 @@ def run_rank(args):
 def main():
     argv = sys.argv[1:]
     args = parse(argv)
+    if args.persist_child:
+        return persist_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         sys.exit(launch_ranks(args, argv))
     run_rank(args)

@@ -320,7 +320,7 @@ int mdr_env_step_end_begin_records(mdr_env_t *env, const double *records, int32_
  * record - the record mdr_env_step_begin_records writes - into the mailbox of every rank as self-validating 8-byte
  * {step tag, 32 data bits} granules; one reducer workgroup per env and rank re-sums the world * records records in the fixed
  * order of mdr_env_step_end_records (bit-identical totals on every rank and to the records path) and hands the totals to the
- * house workgroups, which run up to three steps ahead (the state never depends on the totals, only the rewards do).
+ * house workgroups, which run up to seven steps ahead (the state never depends on the totals, only the rewards do).
  *
  * The mailbox is caller-owned device memory of mdr_mailbox_bytes() bytes per rank, ZERO-FILLED ONCE when it is created and
  * from then on written only by these launches (step tags count over the life of the env handle; there is no per-launch

@@ -724,8 +724,10 @@ int mdr_env_rollout_persistent(mdr_env_t* env, uint8_t* actions, int32_t nb_step
   hipStream_t s = (hipStream_t)stream;
   if (capturing(s)) return fail(env, MDR_ERR_INVALID, "the persistent rollout counts its steps on the host: it cannot be captured");
   const bool sys = mb->system_scope != 0;
+  // how far the houses run ahead of the totals: deeper hides more of the exchange latency (each level costs 4 KB of LDS per workgroup)
+  static const int depth = [] { const char* t = getenv("MDR_PERSIST_DEPTH"); const int v = t ? atoi(t) : mdr::PERSIST_MAX_DEPTH; return std::max(1, std::min(v, mdr::PERSIST_MAX_DEPTH)); }();
   int64_t resident = 0;
-  hipError_t e = mdr::persist_resident_blocks(c.nb_houses % 4 == 0 ? 4 : 1, sys, &resident);
+  hipError_t e = mdr::persist_resident_blocks(c.nb_houses % 4 == 0 ? 4 : 1, sys, depth, &resident);
   if (e != hipSuccess) return hip_fail(env, e, "occupancy query");
   const int64_t grid = (mine + 1) * c.nb_envs;
   if (grid * mb->co_resident > resident) {
@@ -741,7 +743,7 @@ int mdr_env_rollout_persistent(mdr_env_t* env, uint8_t* actions, int32_t nb_step
     if (rc != MDR_OK) return rc;
     const int64_t room = c.table_steps - (env->k - env->j0);
     mdr::RolloutArgs r{};
-    r.nsteps = (int)std::min<int64_t>(room, nb_steps - done);
+    r.nsteps = (int)std::min<int64_t>(std::min<int64_t>(room, mdr::PERSIST_MAX_STEPS), nb_steps - done);
     if (out) {
       r.power_trace = out->power_trace ? out->power_trace + (int64_t)done * c.nb_envs : nullptr;
       r.reward_sum = out->reward_sum;
@@ -758,6 +760,7 @@ int mdr_env_rollout_persistent(mdr_env_t* env, uint8_t* actions, int32_t nb_step
     m.stride = mb->records_per_env;
     m.tag_base = env->mailbox_tag;
     m.spin_limit = mb->spin_limit ? mb->spin_limit : (1u << 20);
+    m.depth = depth;
     e = mdr::launch_rollout_persist(a, r, m, sys, s);
     if (e != hipSuccess) return hip_fail(env, e, "rollout_persist");
     env->mailbox_tag += (uint32_t)r.nsteps + 1u;   // + the pseudo-step that carries the squared temperature errors

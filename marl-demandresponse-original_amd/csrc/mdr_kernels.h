@@ -169,8 +169,9 @@ struct ObserveArgs {
 
 // Persistent sharded rollout (mdr_persist.hip): the mailboxes of every rank, laid out in 8-byte granules as
 //   [PERSIST_HDR header | SLOTS x E x world x stride x PERSIST_G record granules | SLOTS x E x PERSIST_TOT totals granules]
-constexpr int PERSIST_SLOTS = 8;    // mailbox slots a stream of records / totals cycles through (slot = tag mod SLOTS)
-constexpr int PERSIST_DEPTH = 3;    // steps a house workgroup runs ahead of the totals; a peer rank may be another DEPTH + 1 ahead of this rank's reducer: 2 * DEPTH + 2 <= SLOTS
+constexpr int PERSIST_SLOTS = 16;      // mailbox slots a stream of records / totals cycles through (slot = tag mod SLOTS)
+constexpr int PERSIST_MAX_DEPTH = 7;   // steps a house workgroup may run ahead of the totals; a peer rank may be another depth + 1 ahead of this rank's reducer: 2 * depth + 2 <= SLOTS
+constexpr int PERSIST_MAX_STEPS = 128;  // steps per launch (their table rows are staged in LDS)
 constexpr int PERSIST_G = 5;        // granules per record: power sum lo / hi, penalty sum lo / hi, penalty max
 constexpr int PERSIST_TOT = 8;      // granules per totals slot (5 used; 64 bytes)
 constexpr int PERSIST_HDR = 16;     // header granules (128 bytes); granule 0 = error word
@@ -180,9 +181,10 @@ struct PersistArgs {
   int32_t world, rank, stride;      // stride = record slots per env and rank (>= every nrec)
   uint32_t tag_base;                // tag of this launch's step 0 (steps are counted over the life of the handle)
   uint32_t spin_limit;
+  int32_t depth;                    // steps the houses run ahead of the totals, 1 .. PERSIST_MAX_DEPTH
 };
 int64_t persist_mailbox_granules(int E, int world, int stride);
-hipError_t persist_resident_blocks(int vec, bool system_scope, int64_t* blocks);   // workgroups of the kernel the device holds at once
+hipError_t persist_resident_blocks(int vec, bool system_scope, int depth, int64_t* blocks);   // workgroups of the kernel the device holds at once
 hipError_t launch_rollout_persist(const StepArgs& a, const RolloutArgs& r, const PersistArgs& m, bool system_scope, hipStream_t s);
 
 enum StepKind { STEP_FUSED = 0, STEP_GROUP = 1, STEP_SPLIT = 2, STEP_SINGLE = 3 };

@@ -68,7 +68,16 @@ __device__ __forceinline__ bool abort_raised(const PersistArgs& m) {
 
 template <int VEC, bool SYS>
 __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutArgs ro, PersistArgs m) {
-  constexpr int D = PERSIST_DEPTH;
+  const int D = m.depth;   // steps the houses run ahead of the totals (<= PERSIST_MAX_DEPTH)
+  // dynamic LDS: [D + 1][256][VEC] floats - each house's own penalty of the steps in flight - then the env's table rows of this
+  // launch: sig_old[T], sig_new[T] (f64), od[T], solar[T] (f32).  The rows are wave-uniform, but with the granule stores in the loop
+  // hipcc would fetch them by VECTOR loads, and a wait for one of those also waits for the totals / records in flight behind it
+  // (vmcnt retires in order): from LDS they cost a broadcast read on the other counter.
+  extern __shared__ __attribute__((aligned(16))) float lds_hist[];
+  double* const row_sig_old = reinterpret_cast<double*>(lds_hist + (size_t)(D + 1) * 256 * VEC);
+  double* const row_sig_new = row_sig_old + ro.nsteps;
+  float* const row_od = reinterpret_cast<float*>(row_sig_new + ro.nsteps);
+  float* const row_solar = row_od + ro.nsteps;
   __shared__ double lds_part[2][3 * 4];
   __shared__ double lds_tot[2][3];
   __shared__ int lds_fail[2];
@@ -82,6 +91,13 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
   gu64* const own = (gu64*)m.box[m.rank];
   if (tid < MDR_MAX_SHARDS) s_nrec[tid] = tid < m.world ? m.nrec[tid] : 0;
   if (tid < 2) lds_fail[tid] = 0;
+  for (int t = tid; t < ro.nsteps; t += 256) {
+    const int64_t row = (int64_t)t * a.E + blockIdx.y;
+    row_sig_old[t] = a.sig_old[row];
+    row_sig_new[t] = a.sig_new[row];
+    row_od[t] = a.od_old[row];
+    row_solar[t] = a.solar_new[row];
+  }
   __syncthreads();
 
   if (blk == nblk) {
@@ -89,6 +105,37 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
     double serr = 0.0, P_last = 0.0;
     Red3 tot{0.0, 0.0, 0.0f};
     const int last = want_terr ? T : T - 1;   // the pseudo-step T carries the workgroups' squared temperature errors
+    // Thread t re-sums ranks in order, records t, t + 256, ... - the order of finish_block (mdr_kernels.hip).  Where its first
+    // four records sit (relative to the slot's base) never changes: worked out once; they are fetched for step s + 1 while
+    // step s is reduced and published, so a step of the reducer costs no load latency as long as the houses run ahead.
+    int64_t off[4];
+    bool have[4];
+    int r_more = 0, b_more = tid;   // where the fifth record would be (r_more == world: there is none - every practical shape)
+    {
+      int r = 0, b = tid;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        while (r < m.world && b >= s_nrec[r]) { ++r; b = tid; }
+        have[k] = r < m.world;
+        off[k] = have[k] ? ((int64_t)r * m.stride + b) * PERSIST_G : 0;
+        if (have[k]) b += 256;
+      }
+      while (r < m.world && b >= s_nrec[r]) { ++r; b = tid; }
+      r_more = r;
+      b_more = b;
+    }
+    unsigned long long x[4][PERSIST_G];
+    auto fetch = [&](int step) {
+      const uint32_t tag = m.tag_base + (uint32_t)step;
+      const gu64* base = own + rec_offset(m, a.E, (int)(tag % PERSIST_SLOTS), e, 0, 0);
+      const int g_now = (step == T) ? 2 : ng;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int g = 0; g < PERSIST_G; ++g)
+          x[k][g] = (have[k] && g < g_now) ? granule_load<SYS>(base + off[k] + g) : ((unsigned long long)tag << 32);
+    };
+    fetch(0);
     for (int s = 0; s <= last; ++s) {
       const uint32_t tag = m.tag_base + (uint32_t)s;
       const int slot = (int)(tag % PERSIST_SLOTS);
@@ -98,32 +145,28 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
       for (uint32_t spins = 0;;) {
         acc = Red3{0.0, 0.0, 0.0f};
         bool ok = true;
-        // thread t: ranks in order, records t, t + 256, ... - the order of finish_block (mdr_kernels.hip); up to four records'
-        // granules are in flight before the first is looked at
-        int r = 0, b = tid;
-        while (r < m.world) {
-          unsigned long long x[4][PERSIST_G];
-          bool have[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            while (r < m.world && b >= s_nrec[r]) { ++r; b = tid; }
-            have[k] = r < m.world;
-            if (have[k]) {
-              const gu64* rec = own + rec_offset(m, a.E, slot, e, r, b);
+        for (int k = 0; k < 4; ++k) {
 #pragma unroll
-              for (int g = 0; g < PERSIST_G; ++g) x[k][g] = (g < g_now) ? granule_load<SYS>(rec + g) : ((unsigned long long)tag << 32);
-              b += 256;
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            if (!have[k]) continue;
-#pragma unroll
-            for (int g = 0; g < PERSIST_G; ++g) ok &= (uint32_t)(x[k][g] >> 32) == tag;
+          for (int g = 0; g < PERSIST_G; ++g) ok &= (uint32_t)(x[k][g] >> 32) == tag;
+          if (have[k]) {
             acc.sum_p += __hiloint2double((int)(uint32_t)x[k][1], (int)(uint32_t)x[k][0]);
             acc.sum_pen += __hiloint2double((int)(uint32_t)x[k][3], (int)(uint32_t)x[k][2]);
             acc.max_pen = fmaxf(acc.max_pen, __uint_as_float((uint32_t)x[k][4]));
           }
+        }
+        for (int r = r_more, b = b_more; r < m.world;) {   // more than four records per thread: on demand, same order
+          const gu64* rec = own + rec_offset(m, a.E, slot, e, r, b);
+          unsigned long long y[PERSIST_G];
+#pragma unroll
+          for (int g = 0; g < PERSIST_G; ++g) y[g] = (g < g_now) ? granule_load<SYS>(rec + g) : ((unsigned long long)tag << 32);
+#pragma unroll
+          for (int g = 0; g < PERSIST_G; ++g) ok &= (uint32_t)(y[g] >> 32) == tag;
+          acc.sum_p += __hiloint2double((int)(uint32_t)y[1], (int)(uint32_t)y[0]);
+          acc.sum_pen += __hiloint2double((int)(uint32_t)y[3], (int)(uint32_t)y[2]);
+          acc.max_pen = fmaxf(acc.max_pen, __uint_as_float((uint32_t)y[4]));
+          b += 256;
+          while (r < m.world && b >= s_nrec[r]) { ++r; b = tid; }
         }
         if (ok) break;
         ++spins;
@@ -133,7 +176,9 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
           break;
         }
         __builtin_amdgcn_s_sleep(1);
+        fetch(s);
       }
+      if (s < last) fetch(s + 1);   // in flight across the reduction and the publication below
       if (failed) lds_fail[s & 1] = 1;
       tot = block_reduce<256>(acc, lds_part[s & 1]);   // one barrier: the failure flag rides on it
       if (lds_fail[s & 1]) return;
@@ -150,7 +195,7 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
       if (tid == 0) {
         const int64_t row = (int64_t)s * a.E + e;
         if (ro.power_trace) ro.power_trace[row] = tot.sum_p;
-        const double d = a.sig_new[row] - tot.sum_p;
+        const double d = row_sig_new[s] - tot.sum_p;
         serr += d * d;
         P_last = tot.sum_p;
       }
@@ -167,7 +212,7 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
   const bool live = h < a.N;
   const int64_t i = (int64_t)e * a.N + h;
   HouseIn hs[VEC];
-  float rsum[VEC], hist[D + 1][VEC];
+  float rsum[VEC], pen_now[VEC], pen_old[VEC];   // pen_old: the penalty of step it - D, back from LDS
   unsigned act[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
@@ -175,8 +220,7 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
     hs[v].lockout = 1;
     rsum[v] = 0.0f;
     act[v] = 0u;
-#pragma unroll
-    for (int d = 0; d <= D; ++d) hist[d][v] = 0.0f;
+    pen_now[v] = pen_old[v] = 0.0f;
   }
   if (live) {
     float Ta[VEC], Tm[VEC], k01[VEC], s0[VEC], k10[VEC], s1[VEC], iu[VEC], q[VEC], pm[VEC], tg[VEC], db[VEC];
@@ -204,17 +248,15 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
   double terr = 0.0;
   Red3 tot{0.0, 0.0, 0.0f};
   float sig_term = 0.0f;
-  for (int it = 0; it < T + D; ++it) {
+  unsigned long long pre = 0ull;   // wave 0: the totals granule of the NEXT step to pick up, in flight
+  bool have_pre = false;
+  for (int it = 0, ring = 0; it < T + D; ++it, ring = (ring == D ? 0 : ring + 1)) {   // ring = it mod (D + 1)
     const int par = it & 1;
     // the step `it` itself: needs nothing from the other workgroups
     Red3 acc{0.0, 0.0, 0.0f};
-#pragma unroll
-    for (int d = D; d > 0; --d)
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) hist[d][v] = hist[d - 1][v];
     if (it < T) {
       const int64_t row = (int64_t)it * a.E + e;
-      const float od_old = a.od_old[row], solar = a.solar_new[row];
+      const float od_old = row_od[it], solar = row_solar[it];
       if (live) {
         float p = 0.0f, ps = 0.0f, te = 0.0f;
 #pragma unroll
@@ -226,7 +268,7 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
           hs[v].Tm = o.Tm;
           hs[v].sso = o.sso;
           hs[v].flags = o.flags;
-          hist[0][v] = o.pen;
+          pen_now[v] = o.pen;
           p += o.power;
           ps += o.pen;
           acc.max_pen = fmaxf(acc.max_pen, o.pen);
@@ -238,6 +280,7 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
         acc.sum_p = (double)p;
         acc.sum_pen = (double)ps;
         terr += (double)te;
+        store_vec<VEC>(lds_hist, ((int64_t)ring * 256 + tid) * VEC, pen_now);   // read back by this very thread D iterations on
       }
       acc = lanes_reduce<64>(acc, need_pen);
       if (lane == 0) {
@@ -246,14 +289,15 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
         lds_part[par][8 + wave] = (double)acc.max_pen;
       }
     }
-    // wave 0 fetches the totals of step it - D meanwhile (published by the reducer D steps of work ago)
+    // wave 0 picks up the totals of step it - D (published by the reducer D steps of work ago); the load was issued an
+    // iteration earlier, so its latency lies behind that iteration's arithmetic and barrier
     if (wave == 0 && it >= D) {
       const uint32_t tag = m.tag_base + (uint32_t)(it - D);
       const gu64* src = own + tot_offset(m, a.E, (int)(tag % PERSIST_SLOTS), e) + lane;
       uint32_t val = 0;
       bool failed = false;
+      unsigned long long x = have_pre ? pre : (lane < ng ? granule_load<SYS>(src) : ((unsigned long long)tag << 32));
       for (uint32_t spins = 0;;) {
-        const unsigned long long x = lane < ng ? granule_load<SYS>(src) : ((unsigned long long)tag << 32);
         val = (uint32_t)x;
         if (__all((uint32_t)(x >> 32) == tag)) break;
         ++spins;
@@ -263,6 +307,12 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
           break;
         }
         __builtin_amdgcn_s_sleep(1);
+        x = lane < ng ? granule_load<SYS>(src) : ((unsigned long long)tag << 32);
+      }
+      have_pre = it + 1 < T + D;
+      if (have_pre) {
+        const uint32_t nxt = tag + 1u;
+        pre = lane < ng ? granule_load<SYS>(own + tot_offset(m, a.E, (int)(nxt % PERSIST_SLOTS), e) + lane) : ((unsigned long long)nxt << 32);
       }
       const int v0 = __builtin_amdgcn_readlane((int)val, 0), v1 = __builtin_amdgcn_readlane((int)val, 1);
       const int v2 = __builtin_amdgcn_readlane((int)val, 2), v3 = __builtin_amdgcn_readlane((int)val, 3);
@@ -302,10 +352,11 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
       tot.sum_p = lds_tot[par][0];
       tot.sum_pen = lds_tot[par][1];
       tot.max_pen = (float)lds_tot[par][2];
-      sig_term = signal_term(a, tot.sum_p, a.sig_old[row]);
+      sig_term = signal_term(a, tot.sum_p, row_sig_old[it - D]);
+      if (live) load_vec<VEC>(lds_hist, ((int64_t)(ring == D ? 0 : ring + 1) * 256 + tid) * VEC, pen_old);   // slot of step it - D
       if (ro.reward_sum != nullptr && live) {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) rsum[v] = __fadd_rn(rsum[v], reward_value(a, hist[D][v], tot.sum_pen, tot.max_pen, sig_term));
+        for (int v = 0; v < VEC; ++v) rsum[v] = __fadd_rn(rsum[v], reward_value(a, pen_old[v], tot.sum_pen, tot.max_pen, sig_term));
       }
     }
   }
@@ -325,7 +376,7 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
   if (!live) return;
   // final state, and the last step's outputs exactly as the single-step kernels leave them
   const int64_t row = (int64_t)(T - 1) * a.E + e;
-  const float o_sig = (float)(a.sig_new[row] * a.inv_obs_norm);
+  const float o_sig = (float)(row_sig_new[T - 1] * a.inv_obs_norm);
   const float o_pow = (float)(tot.sum_p * a.inv_obs_norm);
   float nTa[VEC], nTm[VEC], pen[VEC];
   int nsso[VEC], lk[VEC];
@@ -338,8 +389,8 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
     nsso[v] = hs[v].sso;
     nfl[v] = hs[v].flags;
     lk[v] = hs[v].lockout;
-    pen[v] = hist[D][v];
-    o[v] = HouseOut{hs[v].Ta, hs[v].Tm, hs[v].sso, hs[v].flags, hist[D][v], 0.0f};
+    pen[v] = pen_old[v];
+    o[v] = HouseOut{hs[v].Ta, hs[v].Tm, hs[v].sso, hs[v].flags, pen_old[v], 0.0f};
   }
   store_vec<VEC>(a.Ta, i, nTa);
   store_vec<VEC>(a.Tm, i, nTm);
@@ -355,12 +406,16 @@ int64_t persist_mailbox_granules(int E, int world, int stride) {
   return PERSIST_HDR + (int64_t)PERSIST_SLOTS * E * world * stride * PERSIST_G + (int64_t)PERSIST_SLOTS * E * PERSIST_TOT;
 }
 
+static size_t persist_lds_bytes(int vec, int depth, int nsteps = PERSIST_MAX_STEPS) {
+  return (size_t)(depth + 1) * 256 * vec * sizeof(float) + (size_t)nsteps * 24;
+}
+
 template <typename K>
-static hipError_t persist_capacity(K kernel, int64_t* blocks) {
+static hipError_t persist_capacity(K kernel, size_t lds, int64_t* blocks) {
   int dev = 0, per_cu = 0, cus = 0;
   hipError_t err = hipGetDevice(&dev);
   if (err != hipSuccess) return err;
-  err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0);
+  err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds);
   if (err != hipSuccess) return err;
   err = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (err != hipSuccess) return err;
@@ -370,19 +425,23 @@ static hipError_t persist_capacity(K kernel, int64_t* blocks) {
   return hipSuccess;
 }
 
-hipError_t persist_resident_blocks(int vec, bool sys, int64_t* blocks) {
-  if (vec == 4) return sys ? persist_capacity(k_rollout_persist<4, true>, blocks) : persist_capacity(k_rollout_persist<4, false>, blocks);
-  return sys ? persist_capacity(k_rollout_persist<1, true>, blocks) : persist_capacity(k_rollout_persist<1, false>, blocks);
+hipError_t persist_resident_blocks(int vec, bool sys, int depth, int64_t* blocks) {
+  const size_t lds = persist_lds_bytes(vec, depth);
+  if (vec == 4) return sys ? persist_capacity(k_rollout_persist<4, true>, lds, blocks) : persist_capacity(k_rollout_persist<4, false>, lds, blocks);
+  return sys ? persist_capacity(k_rollout_persist<1, true>, lds, blocks) : persist_capacity(k_rollout_persist<1, false>, lds, blocks);
 }
 
 hipError_t launch_rollout_persist(const StepArgs& a, const RolloutArgs& r, const PersistArgs& m, bool sys, hipStream_t s) {
+  if (m.depth < 1 || m.depth > PERSIST_MAX_DEPTH || r.nsteps < 1 || r.nsteps > PERSIST_MAX_STEPS) return hipErrorInvalidValue;
   const dim3 g((unsigned)(m.nrec[m.rank] + 1), (unsigned)a.E), b(256);
   if (a.N % 4 == 0) {
-    if (sys) hipLaunchKernelGGL((k_rollout_persist<4, true>), g, b, 0, s, a, r, m);
-    else hipLaunchKernelGGL((k_rollout_persist<4, false>), g, b, 0, s, a, r, m);
+    const size_t lds = persist_lds_bytes(4, m.depth, r.nsteps);
+    if (sys) hipLaunchKernelGGL((k_rollout_persist<4, true>), g, b, lds, s, a, r, m);
+    else hipLaunchKernelGGL((k_rollout_persist<4, false>), g, b, lds, s, a, r, m);
   } else {
-    if (sys) hipLaunchKernelGGL((k_rollout_persist<1, true>), g, b, 0, s, a, r, m);
-    else hipLaunchKernelGGL((k_rollout_persist<1, false>), g, b, 0, s, a, r, m);
+    const size_t lds = persist_lds_bytes(1, m.depth, r.nsteps);
+    if (sys) hipLaunchKernelGGL((k_rollout_persist<1, true>), g, b, lds, s, a, r, m);
+    else hipLaunchKernelGGL((k_rollout_persist<1, false>), g, b, lds, s, a, r, m);
   }
   return hipGetLastError();
 }

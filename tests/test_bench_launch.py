@@ -39,6 +39,15 @@ def test_gpus_2_launches_its_own_ranks_and_prints_one_json_line():
     assert line["ms_per_step"] >= 0.02 * 1e3 / 7 * 0.9      # max over ranks: rank 1 sleeps 20 ms
 
 
+def test_gpus_8_dry_launch_is_the_shape_the_driver_uses():
+    """Eight ranks on one node (the driver's scaling run): rendezvous on 127.0.0.1, fence, max over ranks, ONE line from rank 0."""
+    res = _run({"MDR_BENCH_DRY": "1", "OMP_NUM_THREADS": "1"}, "--gpus", "8", "--steps", "3", "--warmup", "1", timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = _json_lines(res.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 8 and lines[0]["dry_run"] is True
+    assert lines[0]["ms_per_step"] >= 0.08 * 1e3 / 3 * 0.9      # max over ranks: rank 7 sleeps 80 ms
+
+
 def test_a_failing_rank_fails_the_launch():
     res = _run({"MDR_BENCH_DRY": "fail1"}, "--gpus", "2", "--steps", "1", "--warmup", "0")
     assert res.returncode != 0

@@ -37,6 +37,12 @@ def test_single_gpu_line_with_legs_over_rccl():
     assert "error" not in g, g
     assert g["captured"] and g["backend"] == "rccl" and g["checksum_Ta"] == line["c5"]["checksum_Ta"]
     assert g["us_per_step"] < line["c5"]["us_per_step"]
+    p = line["c5_persistent"]                           # the same env without a kernel boundary or a collective per step
+    assert "error" not in p, p
+    assert p["checksum_Ta"] == line["c5"]["checksum_Ta"] and p["houses_per_rank"] == 1_000_000
+    assert p["us_per_step"] < g["us_per_step"] and p["us_per_step_no_accumulators"] <= p["us_per_step"] * 1.05
+    assert line["degraded"] is False and "degraded_reasons" not in line
+    assert 0.4 < line["roofline"]["frac_out_of_cache"] < line["roofline"]["frac"] + 0.2
 
 
 @pytest.mark.gpu
@@ -49,6 +55,10 @@ def test_two_ranks_self_launched_gloo_on_one_gpu():
     assert line["c5"]["n_gpus"] == 2 and line["c5"]["houses_per_rank"] == 500_000 and line["c5"]["backend"] == "gloo"
     assert line["c5_graph"]["captured"] is False and line["c5_graph"]["checksum_Ta"] == line["c5"]["checksum_Ta"]   # gloo: not capturable, stepped eagerly
     assert "cpu_baseline" not in line
+    p = line["c5_persistent"]      # one child process per rank, peer mailboxes over hipIpc between the two (both on the one GPU here)
+    assert "error" not in p, p
+    assert p["houses_per_rank"] == 500_000 and len(p["checksum_Ta_ranks"]) == 2 and "hipIpc" in p["exchange"]
+    assert line["degraded"] is True and any("gloo" in r for r in line["degraded_reasons"])
 
 
 @pytest.mark.gpu
