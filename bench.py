@@ -410,7 +410,8 @@ def c5_persistent_leg(rk: Ranks, mdr, args):
     # happens there the parent still prints its line
     port = [free_port() if rk.rank == 0 else 0]
     rk.dist.broadcast_object_list(port, src=0)
-    env = dict(os.environ)
+    # a rendezvous of their own: without the launcher's agent store (under torch.distributed.run rank 0 would otherwise not serve one)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port[0]), MDR_BENCH_CHILD_DEVICE=str(rk.device.index))
     if rk.backend != "nccl":      # the one-GPU rehearsal (MDR_BENCH_BACKEND=gloo): every rank's launch must be resident on the same device
         env["MDR_MAILBOX_CO_RESIDENT"] = str(rk.world)
