@@ -51,6 +51,7 @@ struct ActorArgs {
   uint32_t k0, k1, step_lo, step_hi;
   const int32_t* step_dev;   // optional: added to the step counter on the device (graph replays: the env's time index)
   int greedy;                // action = argmax instead of a draw (DQNAgent.act)
+  int64_t agent0;            // index of this launch's first agent in the whole batch (Philox counters stay functions of the batch index when a launch covers a slice)
   float* rows_out;           // observe -> act only, optional: the observation rows [A][51] in normStateDict order (the transition buffer's `state`)
 };
 
@@ -59,6 +60,14 @@ struct ActorArgs {
 // register and fetched back one v_readlane at a time.  Re-deriving them where a draw is made is 20 scalar adds.
 __device__ __forceinline__ uint32_t loop_local(uint32_t x) {
   asm volatile("" : "+s"(x));
+  return x;
+}
+
+// A lane-dependent value hidden from loop-invariant code motion: what is derived from it (LDS addresses of the row copy, 64-bit
+// products for the Philox counter) is then re-derived where it is used - one or two vector instructions - instead of being
+// hoisted out of the tile loop into registers the loop does not have (r02: those were the kernels' scratch spills).
+__device__ __forceinline__ int tile_local(int x) {
+  asm volatile("" : "+v"(x));
   return x;
 }
 
@@ -241,14 +250,18 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
   const f32x4* bias2 = reinterpret_cast<const f32x4*>(wd + 256) + g;
   const float bias3 = wd[384];
   float xr[16];
-  const int64_t fstride = a.plane ? a.plane : 1;   // distance between two features of one agent
+  // Feature k of agent i sits `(i F + k) * 4` (rows) or `(k plane + i) * 4` (planes) bytes behind a.obs: 32-bit byte offsets from the
+  // wave-uniform base (the launcher keeps the buffer below 4 GiB per launch), so a feature load is `global_load v, voffset, s[base]`
+  // and what the tile loop keeps per feature is nothing - 64-bit per-feature addresses were 32 registers this kernel does not have.
+  const char* const obs_base = reinterpret_cast<const char*>(a.obs);
+  const uint32_t fstride4 = (uint32_t)(a.plane ? a.plane : 1) * 4u, astride4 = (uint32_t)(a.plane ? 1 : a.F) * 4u;
   auto row_of = [&](int64_t t) {
     const int64_t agent = t * 16 + r;
-    return a.obs + (agent < a.A ? agent : a.A - 1) * (a.plane ? 1 : (int64_t)a.F);
+    return (uint32_t)(agent < a.A ? agent : a.A - 1) * astride4;
   };
-  auto feature = [&](const float* x, int s) { return x[min(kbase + s, a.F - 1) * fstride]; };
+  auto feature = [&](uint32_t x, int s) { return *reinterpret_cast<const float*>(obs_base + (x + (uint32_t)min(tile_local(kbase) + s, a.F - 1) * fstride4)); };
   if (wave < a.ntiles) {
-    const float* x = row_of(wave);
+    const uint32_t x = row_of(wave);
 #pragma unroll
     for (int s = 0; s < 16; ++s) xr[s] = feature(x, s < a.S1 ? s : 0);
   }
@@ -260,7 +273,7 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
     const int64_t agent = t * 16 + r;
     const bool valid = agent < a.A;
     if ((it & 3) == 0) {
-      const int64_t ag = (t + g * nwaves) * 16 + r;
+      const int64_t ag = a.agent0 + (t + tile_local(g) * nwaves) * 16 + r;
       rnd = philox4x32_10((uint32_t)ag, (uint32_t)((uint64_t)ag >> 32), a.step_lo + (a.step_dev ? (uint32_t)*a.step_dev : 0u), TAG_ACTION ^ a.step_hi, loop_local(a.k0), loop_local(a.k1)).x;
     }
     f32x4 acc[MB];
@@ -280,7 +293,7 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
     if (TAIL) acc[MB - 1] = sum_lane_groups(acc[MB - 1]);   // units 96 + v of the lane's agent, in every lane group (bias: group 0 brought it)
     // ---- layer 2 (the next tile's features are loaded between its k-steps, one per step)
     const bool more = t + nwaves < a.ntiles;
-    const float* xn = row_of(more ? t + nwaves : t);
+    const uint32_t xn = row_of(more ? t + nwaves : t);
     f32x4 out[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) out[mb] = bias2[mb * 4];
@@ -415,7 +428,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) 
     if ((it & 3) == 0) {
 #pragma unroll
       for (int c = 0; c < NCB; ++c) {
-        const int64_t ag = ((t + g * nwaves) * NCB + c) * 16 + r;
+        const int64_t ag = ((t + tile_local(g) * nwaves) * NCB + c) * 16 + r;
         rnd[c] = philox4x32_10((uint32_t)ag, (uint32_t)((uint64_t)ag >> 32), a.step_lo + (a.step_dev ? (uint32_t)*a.step_dev : 0u),
                                TAG_ACTION ^ a.step_hi, loop_local(a.k0), loop_local(a.k1)).x;
       }
@@ -702,8 +715,9 @@ __device__ __forceinline__ void observe_build_table(uint16_t* table, int tid, in
 }
 
 template <int TILE>
-__device__ __forceinline__ void observe_store_rows(const float* rows, const uint16_t* table, float* out_tile, int lane, int nrows = TILE) {
+__device__ __forceinline__ void observe_store_rows(const float* rows, const uint16_t* table, float* out_tile, int lane_in, int nrows = TILE) {
   constexpr int QUADS = TILE * 51 / 4;   // 408 | 204
+  const int lane = tile_local(lane_in);
   if (((uintptr_t)out_tile & 15u) != 0) {   // a transition buffer whose per-step slice is not 16-byte aligned (A * 51 % 4 != 0): 4-byte stores
     for (int i = lane; i < nrows * 51; i += 64) __builtin_nontemporal_store(rows[table[i]], out_tile + i);
     return;
@@ -764,14 +778,14 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
   __syncthreads();
 
   const int r = lane & 15, g = lane >> 4;
-  const int64_t wave = (int64_t)blockIdx.x * WAVESB + (tid >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * WAVESB;
+  const int wave = blockIdx.x * WAVESB + (tid >> 6);   // tile indices fit 32 bits (the launcher checks): one register each, not two
+  const int nwaves = gridDim.x * WAVESB;
   const f32x4* bias1 = reinterpret_cast<const f32x4*>(wd + 128) + g;
   const f32x4* bias2 = reinterpret_cast<const f32x4*>(wd + 256) + g;
   const float bias3 = wd[384];
   const double* sig_row = observe_sig_row(o);
   TileCursor tc;
-  tc.init(wave * TILE, nwaves * TILE, o.N);
+  tc.init((int64_t)wave * TILE, (int64_t)nwaves * TILE, o.N);
   float xr[NCB][16];
   // the lane's 16 features of column block c: two runs of 8 floats of row c * 16 + r.  `first_agent`: the tile's first agent -
   // with `store`, the quotients go back into the window and the wave copies the tile's rows out (observe_store_rows)
@@ -808,31 +822,32 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
   SegSlot slot{};
   if (wave < a.ntiles) {
     if (GEN) {
-      const HouseRegs first = observe_load_gen<TILE>(o, sig_row, tc.e, tc.h0, wave * TILE, a.A, lane, slot);
+      const HouseRegs first = observe_load_gen<TILE>(o, sig_row, tc.e, tc.h0, (int64_t)wave * TILE, a.A, lane, slot);
       observe_stage_gen(o, first, slot, rows);
     } else {
       const HouseRegs first = observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
       observe_stage<TILE>(o, first, rows, lane);
     }
     observe_window_fence();
-    gather(wave * TILE);
+    gather((int64_t)wave * TILE);
   }
   uint32_t rnd[NCB] = {};
   int it = 0;
-  for (int64_t t = wave; t < a.ntiles; t += nwaves, ++it) {
+  const int ntiles = (int)a.ntiles;
+  for (int t = wave; t < ntiles; t += nwaves, ++it) {
     if ((it & 3) == 0) {
 #pragma unroll
       for (int c = 0; c < NCB; ++c) {
-        const int64_t ag = ((t + g * nwaves) * NCB + c) * 16 + r;
+        const int64_t ag = (((int64_t)t + (int64_t)tile_local(g) * nwaves) * NCB + c) * 16 + r;
         rnd[c] = philox4x32_10((uint32_t)ag, (uint32_t)((uint64_t)ag >> 32), a.step_lo + (a.step_dev ? (uint32_t)*a.step_dev : 0u),
                                TAG_ACTION ^ a.step_hi, loop_local(a.k0), loop_local(a.k1)).x;
       }
     }
     // the next tile's compact state: issued now, consumed between the k-steps of layer 2
-    const bool more = t + nwaves < a.ntiles;
+    const bool more = t + nwaves < ntiles;
     tc.next();
     HouseRegs nxt{};
-    if (more) nxt = GEN ? observe_load_gen<TILE>(o, sig_row, tc.e, tc.h0, (t + nwaves) * TILE, a.A, lane, slot) : observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
+    if (more) nxt = GEN ? observe_load_gen<TILE>(o, sig_row, tc.e, tc.h0, (int64_t)(t + nwaves) * TILE, a.A, lane, slot) : observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
     f32x4 acc[NCB][MB];
 #pragma unroll
     for (int c = 0; c < NCB; ++c)
@@ -898,12 +913,12 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
     }
     if (more) {   // LDS operations of one wave complete in order: the rows staged above are what these loads see
       observe_window_fence();
-      gather((t + nwaves) * TILE);
+      gather((int64_t)(t + nwaves) * TILE);
     }
     // ---- head
 #pragma unroll
     for (int c = 0; c < NCB; ++c) {
-      const int64_t agent = (t * NCB + c) * 16 + r;
+      const int64_t agent = ((int64_t)t * NCB + c) * 16 + r;
       const bool valid = agent < a.A;
       float d = 0.0f;
 #pragma unroll
@@ -997,7 +1012,7 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_observe16(ActorArgs a, m
     const int64_t agent = t * 16 + r;
     const bool valid = agent < a.A;
     if ((it & 3) == 0) {
-      const int64_t ag = (t + g * nwaves) * 16 + r;
+      const int64_t ag = (t + tile_local(g) * nwaves) * 16 + r;
       rnd = philox4x32_10((uint32_t)ag, (uint32_t)((uint64_t)ag >> 32), a.step_lo + (a.step_dev ? (uint32_t)*a.step_dev : 0u), TAG_ACTION ^ a.step_hi, loop_local(a.k0), loop_local(a.k1)).x;
     }
     const bool more = t + nwaves < a.ntiles;
@@ -1141,6 +1156,7 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
   a.rows_out = rows_out;
   a.A = (int64_t)o.E * o.N;
   a.ntiles = (a.A + tile - 1) / tile;
+  if (a.ntiles > 0x7FFFFFFF) return MDR_ERR_UNSUPPORTED;   // the kernels count tiles in 32 bits
   a.F = actor->num_state; a.S1 = steps1(layout, actor->num_state); a.S2 = steps2(layout, actor->hidden1);
   a.k0 = (uint32_t)(seed & 0xFFFFFFFFull); a.k1 = (uint32_t)(seed >> 32);
   a.step_lo = (uint32_t)(step & 0xFFFFFFFFull); a.step_hi = (uint32_t)(step >> 32);
@@ -1229,8 +1245,28 @@ int mdr_actor_sample(const mdr_actor_t* actor, const float* obs, int64_t obs_pla
   };
   const int mb = blocks16(actor->hidden1, actor->hidden2);
   if (lbf) return mb == 7 ? launch(k_actor_sample_bf16<7>) : launch(k_actor_sample_bf16<8>);
-  if (layout == MDR_ACTOR_FRAG16T) return launch(k_actor_sample16<7, true>);
-  if (l16) return mb == 7 ? launch(k_actor_sample16<7, false>) : launch(k_actor_sample16<8, false>);
+  if (l16) {
+    // k_actor_sample16 addresses its features by 32-bit byte offsets from `obs`: a launch covers at most 4 GiB of observations
+    // (20 million agents at F = 51); a bigger batch goes out in slices of whole tiles
+    const uint64_t limit = 0xFFFFFFFFull;
+    if (obs_plane_stride != 0 && ((uint64_t)(a.F - 1) * (uint64_t)obs_plane_stride + (uint64_t)nb_agents) * 4ull > limit)
+      return MDR_ERR_UNSUPPORTED;   // feature planes further apart than 32 bits reach: hand over rows
+    const int64_t per = obs_plane_stride != 0 ? nb_agents : (int64_t)((limit / ((uint64_t)a.F * 4ull)) & ~15ull);
+    for (int64_t first = 0; first < nb_agents; first += per) {
+      const int64_t count = nb_agents - first < per ? nb_agents - first : per;
+      a.obs = obs + first * (obs_plane_stride != 0 ? 1 : (int64_t)a.F);
+      a.action = action + first;
+      a.a_prob = a_prob ? a_prob + first : nullptr;
+      a.probs = probs ? probs + 2 * first : nullptr;
+      a.A = count;
+      a.agent0 = first;
+      a.ntiles = (count + tile - 1) / tile;
+      const int rc = layout == MDR_ACTOR_FRAG16T ? launch(k_actor_sample16<7, true>)
+                                                  : (mb == 7 ? launch(k_actor_sample16<7, false>) : launch(k_actor_sample16<8, false>));
+      if (rc != MDR_OK) return rc;
+    }
+    return MDR_OK;
+  }
   if (a.S1 <= 32 && a.S2 == 52) return launch(k_actor_sample<32, 52>);   // the reference's shape: num_state <= 62, layers [100, 100]
   if (a.S1 <= 32) return launch(k_actor_sample<32, 0>);
   return launch(k_actor_sample<0, 0>);
