@@ -137,7 +137,11 @@ typedef struct mdr_buffers {
   /* outputs, written every step */
   float *reward;
   float *obs;                      /* [MDR_OBS_COLUMNS][E][N] planes: (Ta-20)/5, (Tm-20)/5, on, lock,
-                                      sso/lockout, reg_signal/norm, cluster_hvac_power/norm */
+                                      sso/lockout, reg_signal/norm, cluster_hvac_power/norm.
+                                      Optional (NULL = the step kernels do not write them: 71 instead of 99 bytes per
+                                      house-step) - for callers that observe through mdr_env_actor_sample / mdr_env_obs_vector,
+                                      which read the state itself (rollout collection, train_ppo.py:69-72);
+                                      mdr_env_refresh_obs brings planes bound later up to date */
   /* per env, [E] */
   int64_t *t0;                     /* episode start, epoch seconds */
   double *phase, *ratio, *max_power;
@@ -254,6 +258,10 @@ int mdr_env_set_interp_grid(mdr_env_t *env, const mdr_interp_grid_t *grid);
 /* build_environment, part 2 (env 125-133): with max_power[E] final (all-reduced by the caller when houses
  * are sharded), build the time tables from time index 0: OD temp (env 793), initial signal (env 133). */
 int mdr_env_begin_episode(mdr_env_t *env, void *stream);
+
+/* The seven observation planes of the CURRENT state (what the last step would have written): after steps taken with
+ * mdr_buffers_t.obs == NULL and a re-bind with the planes in place. */
+int mdr_env_refresh_obs(mdr_env_t *env, void *stream);
 
 /* MADemandResponseEnv.step (env 174-210), whole step on this device. */
 int mdr_env_step(mdr_env_t *env, uint8_t *actions, int action_source, void *stream);

@@ -133,7 +133,7 @@ OBS_PLANES, OBS_ROWS = 0, 1
 EXPORTS = (
     "mdr_abi_version", "mdr_status_string", "mdr_last_error", "mdr_partials_per_env", "mdr_env_partial_records",
     "mdr_env_create", "mdr_env_destroy", "mdr_env_bind", "mdr_env_reset", "mdr_env_load_episode",
-    "mdr_env_set_od_table", "mdr_env_set_interp_grid", "mdr_env_begin_episode", "mdr_env_step", "mdr_env_rollout", "mdr_env_rollout_fused",
+    "mdr_env_set_od_table", "mdr_env_set_interp_grid", "mdr_env_begin_episode", "mdr_env_refresh_obs", "mdr_env_step", "mdr_env_rollout", "mdr_env_rollout_fused",
     "mdr_env_step_begin", "mdr_env_step_end", "mdr_env_step_end_gathered", "mdr_env_step_begin_records", "mdr_env_step_end_records", "mdr_env_step_end_begin_records",
     "mdr_env_interp_due", "mdr_env_interp_local", "mdr_env_interp_apply", "mdr_obs_vector_length", "mdr_env_obs_vector",
     "mdr_obs_message_fields", "mdr_env_obs_messages", "mdr_env_obs_vector_ext", "mdr_env_comm_draws",
@@ -185,6 +185,7 @@ def load():
         "mdr_env_set_od_table": (C.c_int, [vp, vp, i64]),
         "mdr_env_set_interp_grid": (C.c_int, [vp, C.POINTER(MdrInterpGrid)]),
         "mdr_env_begin_episode": (C.c_int, [vp, vp]),
+        "mdr_env_refresh_obs": (C.c_int, [vp, vp]),
         "mdr_env_step": (C.c_int, [vp, vp, C.c_int, vp]),
         "mdr_env_rollout": (C.c_int, [vp, vp, C.c_int, i32, vp]),
         "mdr_env_rollout_fused": (C.c_int, [vp, vp, i32, C.POINTER(MdrRolloutOut), vp]),

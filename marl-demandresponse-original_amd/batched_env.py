@@ -44,7 +44,8 @@ class BatchedDemandResponseEnv:
                  table_steps: int = 64, env_offset: int = 0,
                  house_shard: Optional[Tuple[int, int]] = None, process_group=None,
                  stagger_bytes: int = 2304, interp_grid=None, regenerate_missing_grid: bool = True,
-                 graph_mode: bool = False, exchange_always: bool = False, partial_records: Optional[int] = None):
+                 graph_mode: bool = False, exchange_always: bool = False, partial_records: Optional[int] = None,
+                 obs_planes: bool = True):
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedDemandResponseEnv needs a ROCm device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -76,6 +77,9 @@ class BatchedDemandResponseEnv:
         # None = this shard's own count, raised to the group's maximum at the first episode (TorchDistExchange.agree_partial_records)
         self._partial_records = None if partial_records is None else int(partial_records)
         self.graph_mode = bool(graph_mode)      # device-resident cursor: steps / observations can be captured in a graph
+        # obs_planes=False: mdr_buffers_t.obs stays NULL and the step kernels skip the seven planes (71 instead of 99 B per
+        # house-step) - for loops that observe through obs_vector() / FusedActor.sample_env, which read the state itself
+        self._obs_planes_alloc = self._obs_planes_on = bool(obs_planes)
         self._handle = C.c_void_p()
         self._cfg = self._make_config()
         rc = self._lib.mdr_env_create(C.byref(self._cfg), C.byref(self._handle))
@@ -136,7 +140,7 @@ class BatchedDemandResponseEnv:
         items = [(n, torch.float32, (E, N)) for n in _HOUSE_F32]
         items += [(n, torch.int32, (E, N)) for n in _HOUSE_I32]
         items += [(n, torch.uint8, (E, N)) for n in _HOUSE_U8]
-        items += [("obs", torch.float32, (nat.MDR_OBS_COLUMNS, E, N))]
+        items += [("obs", torch.float32, (nat.MDR_OBS_COLUMNS, E, N) if self._obs_planes_alloc else (0,))]
         items += [("t0", torch.int64, (E,))] + [(n, torch.float64, (E,)) for n in ("phase", "ratio", "max_power", "P", "base_power")]
         items += [("tot", torch.float64, (3, E))]     # local aggregates as ONE block: tot_sum = tot[0:2], tot_max = tot[2]
         items += [("tab_od", torch.float32, (K1, E)), ("tab_solar", torch.float32, (K1, E)), ("tab_signal", torch.float64, (K1, E)),
@@ -181,9 +185,26 @@ class BatchedDemandResponseEnv:
                 continue
             if fname == "cursor" and not self.graph_mode:
                 continue                                    # NULL: launch arguments carry the table rows
+            if fname == "obs" and not self._obs_planes_on:
+                continue                                    # NULL: the step kernels do not write the planes
             setattr(b, fname, self.t[fname].data_ptr() if self.t[fname].numel() else None)      # an empty optional buffer is NULL
         self._buffers = b
         nat.check(self._lib, self._handle, self._lib.mdr_env_bind(self._handle, C.byref(b)), "mdr_env_bind")
+
+    def set_obs_planes(self, on: bool) -> None:
+        """Switch the seven per-step observation planes on or off (a re-bind: mdr_buffers_t.obs = NULL skips their 28 B per
+        house-step).  Switched on again - or on for the first time - they are brought up to date from the current state."""
+        on = bool(on)
+        if on == self._obs_planes_on:
+            return
+        if on and self.t["obs"].numel() == 0:
+            self.t["obs"] = torch.zeros((nat.MDR_OBS_COLUMNS, self.nb_envs, self.nb_houses), dtype=torch.float32, device=self.device)
+        self._obs_planes_on = on
+        self._shard_graph = None      # captured steps hold the old binding
+        self._bind()
+        if on and self.episode >= 0:
+            with torch.cuda.device(self.device):
+                nat.check(self._lib, self._handle, self._lib.mdr_env_refresh_obs(self._handle, self._stream()), "mdr_env_refresh_obs")
 
     def _install_interp_grid(self, interp_grid):
         """PowerGrid.__init__ in interpolation mode (env 1130-1165): load the grid and hand it to the library."""
@@ -885,7 +906,7 @@ class BatchedDemandResponseEnv:
 
     def __deepcopy__(self, memo):
         other = BatchedDemandResponseEnv(copy.deepcopy(self.config, memo), nb_envs=self.nb_envs, device=self.device,
-                                         seed=self.seed, test=self.test, table_steps=self.table_steps,
+                                         seed=self.seed, test=self.test, table_steps=self.table_steps, obs_planes=self._obs_planes_alloc,
                                          env_offset=self.env_offset,
                                          house_shard=(self.house_offset, self.nb_houses) if self.sharded else None,
                                          exchange_always=self._exchange_always, partial_records=self._partial_records,

@@ -102,7 +102,7 @@ std::string check_buffers(const mdr_buffers_t& b, bool need_partials) {
   MDR_NEED(k01); MDR_NEED(s0); MDR_NEED(k10); MDR_NEED(s1); MDR_NEED(inv_Ua); MDR_NEED(Q_hvac); MDR_NEED(P_max);
   MDR_NEED(target); MDR_NEED(deadband); MDR_NEED(lockout);
   MDR_NEED(Ua); MDR_NEED(Cm); MDR_NEED(Ca); MDR_NEED(Hm); MDR_NEED(capacity); MDR_NEED(COP); MDR_NEED(latent);
-  MDR_NEED(reward); MDR_NEED(obs);
+  MDR_NEED(reward);   /* obs is optional: NULL = the step kernels do not write the seven planes */
   MDR_NEED(t0); MDR_NEED(phase); MDR_NEED(ratio); MDR_NEED(max_power); MDR_NEED(P); MDR_NEED(tot_sum); MDR_NEED(tot_max);
   MDR_NEED(tab_od); MDR_NEED(tab_solar); MDR_NEED(tab_signal);
 #undef MDR_NEED
@@ -488,8 +488,22 @@ int mdr_env_begin_episode(mdr_env_t* env, void* stream) {
   mdr::StepArgs a;
   rc = step_args(env, nullptr, MDR_ACTIONS_BANGBANG, (hipStream_t)stream, &a);  // row 0 of the fresh tables
   if (rc != MDR_OK) return rc;
-  hipError_t e = mdr::launch_reset_obs(a, (hipStream_t)stream);
+  hipError_t e = mdr::launch_reset_obs(a, true, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "reset_obs");
+  return MDR_OK;
+}
+
+int mdr_env_refresh_obs(mdr_env_t* env, void* stream) {
+  if (!env) return MDR_ERR_INVALID;
+  if (!env->bound || !env->has_tables) return fail(env, MDR_ERR_UNBOUND, "no episode: call reset/load_episode and begin_episode first");
+  if (!env->buf.obs) return fail(env, MDR_ERR_UNBOUND, "buffer 'obs' is NULL");
+  if (env->split_pending) return fail(env, MDR_ERR_INVALID, "step_begin without step_end");
+  if (capturing((hipStream_t)stream) && graph_mode(env)) return fail(env, MDR_ERR_INVALID, "mdr_env_refresh_obs takes its table row from the host cursor: not inside a capture");
+  mdr::StepArgs a;
+  int rc = step_args(env, nullptr, MDR_ACTIONS_BANGBANG, (hipStream_t)stream, &a);   // sig_old = the row of the current time index
+  if (rc != MDR_OK) return rc;
+  hipError_t e = mdr::launch_reset_obs(a, false, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(env, e, "refresh_obs");
   return MDR_OK;
 }
 

@@ -206,7 +206,7 @@ hipError_t launch_pack_env(const StepArgs& a, int e, double temp_ref, const doub
                            const double* abs_noise_row, double* out, hipStream_t s);
 hipError_t launch_cursor_set(int32_t* cursor, int32_t row, int32_t k, hipStream_t s);
 hipError_t launch_signal_error(const StepArgs& a, double* sq_signal_error_sum, hipStream_t s);   // += (sig_old - P)^2
-hipError_t launch_reset_obs(const StepArgs& a, hipStream_t s);  // uses sig_old = table row 0
+hipError_t launch_reset_obs(const StepArgs& a, bool zero_reward, hipStream_t s);  // planes of the current state; uses sig_old = the row of the current time index
 hipError_t launch_step(const StepArgs& a, const StepPlan& p, hipStream_t s);
 hipError_t launch_step_end_begin_split(const StepArgs& finish, const StepArgs& begin, hipStream_t s);   // finish of step k and partial of step k + 1 in ONE launch
 bool rollout_fused_supported(const StepPlan& p);

@@ -3,6 +3,8 @@
 // Bound: HBM bandwidth (element-wise fp32, ~0.4 flop/B) - no MFMA.  One fused launch per env step:
 // every per-house array is read/written once with 16-byte accesses, the per-env reductions stay in
 // registers + LDS, per-env scalars (weather, solar, signal) come from small pre-built time tables.
+#include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 
 #include "mdr_device.h"
@@ -107,9 +109,12 @@ __global__ __launch_bounds__(256) void k_env_max_power(EpisodeArgs a) {
 
 // Observation planes right after reset (MADemandResponseEnv.reset, env 163-170): every HVAC is off
 // (env 796-801) so cluster_hvac_power = 0; reg_signal is the initial signal (table row 0); rewards <- 0.
-__global__ __launch_bounds__(256) void k_reset_obs(StepArgs a) {
+// Also mdr_env_refresh_obs (zero_reward = 0): the seven planes of the CURRENT state, e.g. after steps taken without planes.
+__global__ __launch_bounds__(256) void k_reset_obs(StepArgs a, int zero_reward) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.plane) return;
+  if (zero_reward) a.reward[i] = 0.0f;
+  if (a.obs == nullptr) return;
   const int e = (int)(i / a.N);
   a.obs[0 * a.plane + i] = (a.Ta[i] + a.obs_tshift) * 0.2f;
   a.obs[1 * a.plane + i] = (a.Tm[i] + a.obs_tshift) * 0.2f;
@@ -118,7 +123,6 @@ __global__ __launch_bounds__(256) void k_reset_obs(StepArgs a) {
   a.obs[4 * a.plane + i] = (float)a.sso[i] / (float)a.lockout[i];
   a.obs[5 * a.plane + i] = (float)(a.sig_old[e] * a.inv_obs_norm);
   a.obs[6 * a.plane + i] = (float)(a.P[e] * a.inv_obs_norm);
-  a.reward[i] = 0.0f;
 }
 
 // =================================================================================================
@@ -289,6 +293,117 @@ __global__ __launch_bounds__(256) void k_fill_tables(TableArgs a) {
   if (a.tab_abs_noise != nullptr) a.tab_abs_noise[i] = abs_noise;
   sig *= a.ratio[e];                        // env 1312
   a.tab_signal[i] = fmin(sig, a.max_power[e]);  // env 1314
+}
+
+// The same tables with one thread per (env, run of `chunk` consecutive rows): what depends on the MINUTE only - the calendar,
+// the outdoor sinusoid (minute stairs, env 1066-1068), the solar polynomial - is evaluated when the minute changes, and a Perlin
+// octave's two lattice gradients (two Philox calls) when the octave's lattice cell changes (0.05 .. 0.8 cells per 4-s step for the
+// default five octaves) instead of at every row.  For batches of small envs the tables are O(E) fp64 + Philox work per step
+// (209,715 envs x 65 rows per refill at 20 houses per env): per row this leaves the OD Gaussian, the fade polynomials and ~1.5
+// Philox calls of the ten.  Every value is produced by the very expressions of k_fill_tables from the very inputs: bit-identical
+// tables (tests/test_gpu_tables.py).  Thread id = run * E + env: a wave writes consecutive envs of one row.
+constexpr int TABLE_RUN_OCTAVES = 8;
+
+#ifndef MDR_TABLE_RUN_WAVES
+#define MDR_TABLE_RUN_WAVES 3
+#endif
+__global__ __launch_bounds__(256, MDR_TABLE_RUN_WAVES) void k_fill_tables_runs(TableArgs a, int chunk) {
+  // a thread's lattice cells and gradients per octave: in LDS, so that the octave loop stays a loop (unrolled over registers it
+  // cost 206 of them and two waves per SIMD)
+  __shared__ uint32_t s_cell[TABLE_RUN_OCTAVES][256];
+  __shared__ double2 s_grad[TABLE_RUN_OCTAVES][256];
+  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int runs = (a.rows + chunk - 1) / chunk;
+  if (id >= (int64_t)runs * a.E) return;
+  const int run = (int)(id / a.E);
+  const int e = (int)(id % a.E);
+  const int r0 = run * chunk, r1 = min(a.rows, r0 + chunk);
+  const uint32_t eg = (uint32_t)(e + a.env_offset);
+  const int64_t t0 = a.t0[e];
+  const double phase = a.phase[e], ratio = a.ratio[e], max_power = a.max_power[e];
+  const double base = a.base_power ? a.base_power[e] : a.avg_power_per_hvac * (double)a.n_total;
+  const double amp = 0.5 * (a.day_temp - a.night_temp), bias = 0.5 * (a.day_temp + a.night_temp);
+  int64_t minute = INT64_MIN;   // floor(t / 60) of the cached calendar
+  Civil c{};
+  int64_t t_civil = 0;          // the time the cached calendar was taken at (its seconds-of-day belong to it)
+  double od_base = 0.0;
+  float solar = 0.0f;
+  uint32_t have = 0u;           // bit q: octave q's cell is cached
+  const double w_last = 1.0 / (ldexp(1.0, a.perlin_octaves) - 1.0);
+  for (int r = r0; r < r1; ++r) {
+    const int64_t i = (int64_t)r * a.E + e;
+    const int64_t j = a.j0 + r;
+    const int64_t t = t0 + j * (int64_t)a.dt;
+    int64_t m = t / 60;
+    if (t - m * 60 < 0) m -= 1;
+    if (m != minute) {
+      minute = m;
+      c = civil_from_epoch(t);
+      t_civil = t;
+      const double tday = (double)c.hour + (double)c.minute / 60.0;
+      od_base = amp * sin(6.283185307179586476925286766559 * (tday + (-6.0 + phase)) / 24.0) + bias;
+      solar = a.solar_on ? (float)(a.area_shading * solar_cooling_load(c.hour, c.minute, c.month, c.day)) : 0.0f;
+    }
+    double od;
+    if (a.od_ext != nullptr && j < a.od_ext_rows) {
+      od = a.od_ext[j * a.E + e];
+    } else {
+      od = od_base;
+      if (a.temp_std != 0.0) {
+        const u32x4 g = philox4x32_10(eg, (uint32_t)j, a.episode, TAG_OD_NOISE, a.k0, a.k1);
+        od += a.temp_std * gauss01(g.x, g.y);
+      }
+    }
+    a.tab_od[i] = (float)(od - a.temp_ref);
+    a.tab_solar[i] = solar;
+    const double sod = (double)(c.sod + (int)(t - t_civil));   // same minute, hence same day: the calendar's seconds-of-day moved on
+    double sig, abs_noise = 0.0;
+    if (a.signal_mode == MDR_SIGNAL_FLAT) {
+      sig = base;
+    } else if (a.signal_mode == MDR_SIGNAL_SINUSOIDALS) {
+      sig = base;
+      for (int q = 0; q < a.nb_sin; ++q)
+        sig += base * a.sin_ratios[q] * sin(6.283185307179586476925286766559 * sod / a.sin_periods[q]);
+    } else if (a.signal_mode == MDR_SIGNAL_REGULAR_STEPS) {
+      const double ampl = a.steps_amp * (double)a.n_total;
+      const double duty = base / ampl;
+      {
+#pragma clang fp contract(off)
+        const double edge = (1.0 - duty) * a.steps_period;
+        const double x = fmod(sod, a.steps_period) - edge;
+        sig = x >= 0.0 ? ampl : 0.0;
+      }
+    } else {
+      const double x = sod / a.perlin_period;
+      double n = 0.0;
+      for (int q = 0; q < a.perlin_octaves; ++q) {
+        const double f = ldexp(a.perlin_step, q);
+        const double w = (q < a.perlin_octaves - 1) ? ldexp(1.0, -q) : w_last;
+        // lattice_noise_1d(x * f, ...) with the cell's two gradients kept while the cell stays
+        const double xx = x * f;
+        const double l0 = floor(xx);
+        const double d0 = xx - l0;
+        const double d1 = d0 - 1.0;
+        const uint32_t li = (uint32_t)(int64_t)l0;
+        const bool cached = (have >> q) & 1u;
+        const uint32_t was = s_cell[q][threadIdx.x];
+        double2 g = s_grad[q][threadIdx.x];
+        if (!cached || li != was) {
+          g.x = (cached && li == was + 1u) ? g.y : 2.0 * u01(philox4x32_10(eg, li, a.episode, TAG_PERLIN, a.k0, a.k1).x) - 1.0;
+          g.y = 2.0 * u01(philox4x32_10(eg, li + 1u, a.episode, TAG_PERLIN, a.k0, a.k1).x) - 1.0;
+          s_cell[q][threadIdx.x] = li;
+          s_grad[q][threadIdx.x] = g;
+          have |= 1u << q;
+        }
+        n += w * (fade5(1.0 - d0) * g.x * d0 + fade5(1.0 + d1) * g.y * d1);
+      }
+      sig = fmax(0.0, base + base * a.perlin_amp * n);
+      abs_noise = fabs(base * a.perlin_amp * n);
+    }
+    if (a.tab_abs_noise != nullptr) a.tab_abs_noise[i] = abs_noise;
+    sig *= ratio;
+    a.tab_signal[i] = fmin(sig, max_power);
+  }
 }
 
 // =================================================================================================
@@ -706,8 +821,10 @@ __global__ __launch_bounds__(256) void k_step_single_house(StepArgs a) {
   if (a.action_source == MDR_ACTIONS_BANGBANG && a.actions != nullptr) store_bytes<4>(a.actions, e0, act);
   store_obs_local<4>(a, e0, o, lk);
   store_out<4>(a.reward, e0, rew);
-  store_out<4>(a.obs + 5 * a.plane, e0, c5);
-  store_out<4>(a.obs + 6 * a.plane, e0, c6);
+  if (a.obs != nullptr) {
+    store_out<4>(a.obs + 5 * a.plane, e0, c5);
+    store_out<4>(a.obs + 6 * a.plane, e0, c6);
+  }
   cursor_done(a);
 }
 
@@ -1882,17 +1999,31 @@ hipError_t launch_rollout_accumulate(const StepArgs& a, const RolloutArgs& ro, h
 }
 
 hipError_t launch_patch_signal_plane(const StepArgs& a, hipStream_t s) {
+  if (a.obs == nullptr) return hipSuccess;
   hipLaunchKernelGGL(k_patch_signal_plane, dim3((unsigned)((a.plane + 255) / 256)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
-hipError_t launch_reset_obs(const StepArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_reset_obs, dim3((unsigned)((a.plane + 255) / 256)), dim3(256), 0, s, a);
+hipError_t launch_reset_obs(const StepArgs& a, bool zero_reward, hipStream_t s) {
+  hipLaunchKernelGGL(k_reset_obs, dim3((unsigned)((a.plane + 255) / 256)), dim3(256), 0, s, a, zero_reward ? 1 : 0);
   return hipGetLastError();
 }
 
 hipError_t launch_tables(const TableArgs& a, hipStream_t s) {
   const int64_t n = (int64_t)a.rows * a.E;
+  // Runs of rows per thread once the batch has envs to spare: as long as a run per thread still puts ~256 K threads on the device
+  // (MDR_TABLE_RUN: 0 = always one thread per entry, n = runs of n rows whatever the batch)
+  static const int knob = [] { const char* t = getenv("MDR_TABLE_RUN"); return t ? atoi(t) : -1; }();
+  int chunk = 1;
+  if (a.perlin_octaves <= TABLE_RUN_OCTAVES || a.signal_mode != MDR_SIGNAL_PERLIN) {
+    if (knob >= 0) chunk = knob;
+    else if (n >= (int64_t)1 << 19) chunk = (int)std::min<int64_t>(a.rows, n >> 18);
+  }
+  if (chunk > 1) {
+    const int64_t threads = (int64_t)((a.rows + chunk - 1) / chunk) * a.E;
+    hipLaunchKernelGGL(k_fill_tables_runs, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a, chunk);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k_fill_tables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
   return hipGetLastError();
 }

@@ -194,6 +194,7 @@ __device__ __forceinline__ void step_vec(const StepArgs& a, int64_t i, float od_
 // The five observation columns that do not depend on the env-wide reductions.
 template <int VEC>
 __device__ __forceinline__ void store_obs_local(const StepArgs& a, int64_t i, const HouseOut* o, const int* lockout) {
+  if (a.obs == nullptr) return;   // mdr_buffers_t.obs == NULL: nobody reads the planes (observe -> act rollouts): 28 B per house-step not written
   float c0[VEC], c1[VEC], c2[VEC], c3[VEC], c4[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
@@ -221,6 +222,7 @@ __device__ __forceinline__ void store_reward_power(const StepArgs& a, int64_t i,
     c6[v] = o_pow;
   }
   store_out<VEC>(a.reward, i, r);
+  if (a.obs == nullptr) return;
   store_out<VEC>(a.obs + 5 * a.plane, i, c5);
   store_out<VEC>(a.obs + 6 * a.plane, i, c6);
 }

@@ -128,7 +128,7 @@ def discounted_returns(reward: torch.Tensor, done: torch.Tensor, gamma: float,
 def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.99, critic: Optional[nn.Module] = None,
                         generator: Optional[torch.Generator] = None, store_states: bool = True,
                         fused: Optional[bool] = None, seed: int = 0, policy_precision: str = "fp32",
-                        observe_act: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+                        observe_act: Optional[bool] = None, obs_planes: Optional[bool] = None) -> Dict[str, torch.Tensor]:
     """Roll ``nb_steps`` with actions sampled from ``actor`` for every agent of every env.
 
     ``fused`` (default: whenever the actor has the reference's shape - two hidden layers of <= 127 units, two actions -
@@ -141,6 +141,10 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
     observation and policy are ONE kernel (``FusedActor.sample_env``): the 51 features of every agent are built in LDS from the
     compact state and fed to the matrix cores from there; with ``store_states`` the same kernel copies the rows into the
     transition buffer on the side (written once, never read back by the policy), without it they are not materialised at all.
+
+    ``obs_planes`` (default: False whenever observation and policy are one kernel): with False the env steps WITHOUT writing its
+    seven per-step observation planes during the collection - nothing here reads them (71 instead of 99 bytes per house-step,
+    train_ppo.py:69-72 observes through normStateDict) - and brings them up to date once at the end.
 
     Returns tensors with the agents flattened as [T, E*N, ...] in the reference's per-agent order:
     ``state`` [T+1, E*N, F] (``state[t+1]`` is ``next_state[t]``; omitted if ``store_states`` is False), ``action`` int64,
@@ -170,6 +174,11 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
             return env.obs_vector("rows", out=states[t].view(E, N, F_len)).view(E * N, F_len)
         return env.obs_vector("rows").view(E * N, F_len)
 
+    if obs_planes is None:
+        obs_planes = not observe_act
+    planes_were_on = bool(getattr(env, "_obs_planes_on", True))
+    if not obs_planes and planes_were_on and not env.sharded:
+        env.set_obs_planes(False)
     obs = None if observe_act else observe(0)
     step0 = env.steps_taken
     for t in range(T):
@@ -190,6 +199,8 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
             obs = observe(t + 1)
     if observe_act and (store_states or critic is not None):
         obs = observe(T)            # next_state of the last transition / the critic's bootstrap input
+    if planes_were_on and not env._obs_planes_on:
+        env.set_obs_planes(True)    # one pass over the state: the planes of the last step
     if policy is not None:
         action.copy_(act_u8)        # one widening pass at the end (the reference stores Categorical's int64)
     done = torch.zeros((T, E * N), dtype=torch.bool, device=dev)

@@ -1,0 +1,51 @@
+"""The per-env time tables (outdoor temperature env/MA_DemandResponse.py:1057-1081, solar gain utils.py:1277-1350, regulation
+signal env 1236-1316) built by runs of rows per thread - calendar / sinusoid / solar polynomial once per minute, Perlin gradients
+once per lattice cell - must equal the one-thread-per-entry tables bit for bit.  A batch of a few envs takes the per-entry
+kernel, a big batch the runs (mdr_kernels.hip launch_tables); env_offset puts the small batch on the same global envs."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(signal, temp_mode, dt):
+    import mdr_amd
+    cfg = mdr_amd.default_config()
+    env = cfg["default_env_prop"]
+    env["cluster_prop"]["nb_agents"] = 2
+    env["cluster_prop"]["temp_mode"] = temp_mode
+    env["time_step"] = dt
+    env["power_grid_prop"]["base_power_mode"] = "constant"
+    env["power_grid_prop"]["signal_mode"] = signal
+    env["power_grid_prop"]["artificial_signal_ratio_range"] = 2
+    env["start_datetime_mode"] = "random"
+    cfg["default_house_prop"]["solar_gain_bool"] = True
+    cfg["noise_hvac_prop"]["noise_mode"] = "big_noise"
+    return cfg
+
+
+@pytest.mark.parametrize("signal,temp_mode,dt,E", [
+    ("perlin", "noisy_sinusoidal_heatwave", 4, 262144),      # runs of a whole window (65 rows)
+    ("perlin", "noisy_sinusoidal_hot", 60, 65536),           # runs of 16 rows, a new minute at every row
+    ("sinusoidals", "sinusoidal_hot", 7, 16384),             # runs of 4 rows
+    ("regular_steps", "noisy_sinusoidal_cold", 4, 131072),
+    ("flat", "constant", 4, 40000),
+])
+def test_tables_by_runs_equal_tables_by_entry(signal, temp_mode, dt, E):
+    import mdr_amd
+    cfg = _cfg(signal, temp_mode, dt)
+    big = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=77, table_steps=64)
+    big.reset(episode=3)
+    smalls = []
+    for off in (0, 1001, E - 8):
+        small = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=8, device="cuda:0", seed=77, table_steps=64, env_offset=off)
+        small.reset(episode=3)
+        smalls.append((off, small))
+    for rounds in range(4):       # the first tables, then three refills further into the episode (incl. midnight for dt = 60)
+        for off, small in smalls:
+            for name in ("tab_od", "tab_solar", "tab_signal", "tab_abs_noise"):
+                assert torch.equal(small.t[name], big.t[name][:, off:off + 8]), (rounds, off, name)
+        big.rollout(65)
+        for _, small in smalls:
+            small.rollout(65)
+        assert big.cursor() == smalls[0][1].cursor()

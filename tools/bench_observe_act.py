@@ -56,10 +56,11 @@ def main():
             del kept
             if layout == FRAG16:      # the rollout picks FRAG16T for the reference's [100, 100] by itself: kernel comparison only
                 continue
-            for key, observe, keep in (("rows", False, False), ("observe_act", True, False), ("rows_states_kept", False, True),
-                                       ("observe_act_states_kept", True, True)):
-                collect_ppo_rollout(env, actor, 3, store_states=keep, policy_precision=name, observe_act=observe)
-                us = [timeit(lambda: collect_ppo_rollout(env, actor, args.steps, store_states=keep, policy_precision=name, observe_act=observe), 1, warm=0) / args.steps
+            for key, observe, keep, planes in (("rows", False, False, True), ("observe_act", True, False, False), ("observe_act_with_planes", True, False, True),
+                                               ("rows_states_kept", False, True, True), ("observe_act_states_kept", True, True, False)):
+                collect_ppo_rollout(env, actor, 3, store_states=keep, policy_precision=name, observe_act=observe, obs_planes=planes)
+                us = [timeit(lambda: collect_ppo_rollout(env, actor, args.steps, store_states=keep, policy_precision=name, observe_act=observe,
+                                                         obs_planes=planes), 1, warm=0) / args.steps
                       for _ in range(3)]
                 out["rollout_step_%s_%s_us" % (key, name)] = round(min(us), 1)
                 torch.cuda.empty_cache()
