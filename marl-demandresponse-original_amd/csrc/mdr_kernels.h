@@ -187,7 +187,7 @@ int64_t persist_mailbox_granules(int E, int world, int stride);
 hipError_t persist_resident_blocks(int vec, bool system_scope, int depth, int64_t* blocks);   // workgroups of the kernel the device holds at once
 hipError_t launch_rollout_persist(const StepArgs& a, const RolloutArgs& r, const PersistArgs& m, bool system_scope, hipStream_t s);
 
-enum StepKind { STEP_FUSED = 0, STEP_GROUP = 1, STEP_SPLIT = 2, STEP_SINGLE = 3 };
+enum StepKind { STEP_FUSED = 0, STEP_GROUP = 1, STEP_SPLIT = 2, STEP_SINGLE = 3, STEP_MULTI = 4 };   // STEP_MULTI: `tiles` envs share a group of `threads` lanes (mdr_multi.hip)
 struct StepPlan {
   int kind, vec, threads, tiles;
 };
@@ -208,6 +208,9 @@ hipError_t launch_cursor_set(int32_t* cursor, int32_t row, int32_t k, hipStream_
 hipError_t launch_signal_error(const StepArgs& a, double* sq_signal_error_sum, hipStream_t s);   // += (sig_old - P)^2
 hipError_t launch_reset_obs(const StepArgs& a, bool zero_reward, hipStream_t s);  // planes of the current state; uses sig_old = the row of the current time index
 hipError_t launch_step(const StepArgs& a, const StepPlan& p, hipStream_t s);
+int64_t multi_blocks(int64_t E, const StepPlan& p);
+hipError_t launch_step_multi(const StepArgs& a, const StepPlan& p, hipStream_t s);
+hipError_t launch_rollout_multi(const StepArgs& a, const RolloutArgs& r, const StepPlan& p, hipStream_t s);
 hipError_t launch_step_end_begin_split(const StepArgs& finish, const StepArgs& begin, hipStream_t s);   // finish of step k and partial of step k + 1 in ONE launch
 bool rollout_fused_supported(const StepPlan& p);
 hipError_t launch_rollout_accumulate(const StepArgs& a, const RolloutArgs& ro, hipStream_t s);   // after ONE single step

@@ -410,15 +410,6 @@ __global__ __launch_bounds__(256, MDR_TABLE_RUN_WAVES) void k_fill_tables_runs(T
 // Step kernels
 // =================================================================================================
 // Graph mode: a captured launch carries the pointers of table row 0; the device-resident cursor says where the episode is.
-__device__ __forceinline__ void rebase(StepArgs& a) {
-  if (a.cursor == nullptr) return;
-  const int64_t off = (int64_t)min(a.cursor[0], a.cursor_max) * a.E;
-  a.od_old += off;
-  a.solar_new += off;
-  a.sig_old += off;
-  a.sig_new += off;
-}
-
 __device__ __forceinline__ void rebase(ObsArgs& a) {
   if (a.cursor == nullptr) return;
   const int64_t off = (int64_t)min(a.cursor[0], a.cursor_max + 1) * a.E;
@@ -426,22 +417,6 @@ __device__ __forceinline__ void rebase(ObsArgs& a) {
   a.od_now += off;
   a.solar_now += off;
   a.k = a.cursor[1];
-}
-
-// Graph mode: the last workgroup of a step's last kernel moves the cursor on.  Every thread read the cursor first thing (rebase)
-// and then either left the kernel or waits at the barrier below, so when the last workgroup's thread 0 has counted all arrivals
-// nobody in this launch reads it any more; whatever reads it next is a later launch on the stream.  Saves each captured step a
-// one-thread launch of its own (~2 us of node-to-node latency on a 6-10 us step).  Thread 0 of every workgroup must get here.
-__device__ __forceinline__ void cursor_done(const StepArgs& a) {
-  if (a.cursor_adv == nullptr) return;
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  const unsigned total = gridDim.x * gridDim.y * gridDim.z;
-  if (atomicAdd(reinterpret_cast<unsigned*>(a.cursor_adv + 3), 1u) == total - 1u) {
-    a.cursor_adv[3] = 0;
-    a.cursor_adv[0] += 1;
-    a.cursor_adv[1] += 1;
-  }
 }
 
 // The split kernels need no counting: a partial kernel notes its table row in a slot (cursor[2] | cursor[4]) that nobody in its
@@ -2052,6 +2027,18 @@ StepPlan plan_step(int N, int64_t E) {
   // exposes the most parallelism; wide accesses only pay once the device is full.
   if (N <= 64 && E * N < 262144) vec = 1;
   const int lanes = (N + vec - 1) / vec;
+  // Device-filling batches of small envs with N % 4 == 2 (the reference deploys with 50 houses): TWO envs per lane group keep every
+  // lane on 16-byte accesses where one env per group allows 8 bytes (mdr_multi.hip; measured at 4.19 M houses: 50 houses 66.9 ->
+  // 63.9 us, 10 houses 68.7 -> 65.9 us.  Three or four envs per group - 20 houses at 15 of 16 lanes, odd N - were measured too and
+  // lose: the per-env reductions and selects outweigh the fuller lanes, e.g. 20 houses 64.1 -> 69.6 us, 27 houses 70.1 -> 98.6 us)
+  static const bool multi_ok = [] { const char* t = getenv("MDR_PLAN_MULTI"); return !(t && t[0] == '0'); }();
+  if (multi_ok && N % 4 == 2 && N >= 6 && N <= 126 && E >= 2 && E * N >= 262144) {
+    p.kind = STEP_MULTI;
+    p.vec = 4;
+    p.threads = pow2_at_least(N / 2);   // lanes per group of two envs
+    p.tiles = 2;                        // envs per group
+    return p;
+  }
   if (N == 1 && E % 4 == 0 && E >= 262144) {   // single-house envs in bulk: vectorise over the env axis
     p.kind = STEP_SINGLE;
     p.vec = 4;
@@ -2088,7 +2075,7 @@ StepPlan plan_step(int N, int64_t E) {
 // The multi-step kernels keep one house per lane (sub-wave groups) or VEC x TILES houses per thread (workgroup per env)
 StepPlan plan_rollout(int N, int64_t E) {
   StepPlan p = plan_step(N, E);
-  if (p.kind == STEP_GROUP) return p;   // same lane mapping as the single-step kernel
+  if (p.kind == STEP_GROUP || p.kind == STEP_MULTI) return p;   // same lane mapping as the single-step kernel
   if (p.kind == STEP_SINGLE) {          // one lane per env; nothing to reduce, so any mapping gives the same bits
     p.kind = STEP_GROUP;
     p.vec = 1;
@@ -2167,10 +2154,11 @@ hipError_t launch_step_end_begin_split(const StepArgs& f, const StepArgs& p, hip
   return hipGetLastError();
 }
 
-bool rollout_fused_supported(const StepPlan& p) { return p.kind == STEP_GROUP || p.kind == STEP_FUSED; }
+bool rollout_fused_supported(const StepPlan& p) { return p.kind == STEP_GROUP || p.kind == STEP_FUSED || p.kind == STEP_MULTI; }
 
 hipError_t launch_rollout_fused(const StepArgs& a, const RolloutArgs& r, const StepPlan& p, hipStream_t s) {
   if (!rollout_fused_supported(p)) return hipErrorInvalidValue;
+  if (p.kind == STEP_MULTI) return launch_rollout_multi(a, r, p, s);
   if (p.kind == STEP_GROUP) {
     const int64_t lanes = (int64_t)a.E * p.threads;
     const dim3 gg((unsigned)((lanes + 255) / 256)), b(256);
@@ -2228,6 +2216,7 @@ static int cursor_atomic_blocks() {
 static int64_t step_blocks(const StepArgs& a, const StepPlan& p) {
   if (p.kind == STEP_SINGLE) return (a.E / 4 + 255) / 256;
   if (p.kind == STEP_FUSED) return a.E;
+  if (p.kind == STEP_MULTI) return multi_blocks(a.E, p);
   return ((int64_t)a.E * p.threads + 255) / 256;
 }
 
@@ -2240,6 +2229,7 @@ hipError_t launch_step(const StepArgs& args, const StepPlan& p, hipStream_t s) {
     hipLaunchKernelGGL(k_cursor_advance, dim3(1), dim3(1), 0, s, args.cursor_adv);
     return hipGetLastError();
   }
+  if (p.kind == STEP_MULTI) return launch_step_multi(a, p, s);
   if (p.kind == STEP_SINGLE) {
     hipLaunchKernelGGL(k_step_single_house, dim3((unsigned)((a.E / 4 + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();

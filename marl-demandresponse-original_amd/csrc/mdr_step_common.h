@@ -143,9 +143,10 @@ __device__ __forceinline__ void store_bytes(uint8_t* __restrict__ p, int64_t i, 
   }
 }
 
-// Loads VEC houses starting at flat index i, steps them, stores the new state, returns outputs.
+// Loads VEC houses starting at flat index i, steps them, stores the new state, returns outputs.  od_old[v] / solar[v]: the table
+// values of house v's env (one env per call in most kernels; k_step_multi's lanes may hold the end of one env and the start of the next).
 template <int VEC>
-__device__ __forceinline__ void step_vec(const StepArgs& a, int64_t i, float od_old, float solar, HouseOut* out, int* lockout) {
+__device__ __forceinline__ void step_vec_rows(const StepArgs& a, int64_t i, const float* od_old, const float* solar, HouseOut* out, int* lockout) {
   float Ta[VEC], Tm[VEC], k01[VEC], s0[VEC], k10[VEC], s1[VEC], iu[VEC], q[VEC], pm[VEC], tg[VEC], db[VEC];
   int sso[VEC];
   unsigned fl[VEC], act[VEC];
@@ -173,7 +174,7 @@ __device__ __forceinline__ void step_vec(const StepArgs& a, int64_t i, float od_
     // BangBangController.act (agents/bangbang_controllers.py:49-59) on the pre-step observation
     const bool cmd = (a.action_source == MDR_ACTIONS_BANGBANG) ? (Ta[v] > tg[v]) : (act[v] != 0u);
     if (a.action_source == MDR_ACTIONS_BANGBANG) act[v] = cmd ? 1u : 0u;
-    out[v] = house_step(h, cmd, od_old, solar, a.dt);
+    out[v] = house_step(h, cmd, od_old[v], solar[v], a.dt);
     nTa[v] = out[v].Ta;
     nTm[v] = out[v].Tm;
     nsso[v] = out[v].sso;
@@ -189,6 +190,17 @@ __device__ __forceinline__ void step_vec(const StepArgs& a, int64_t i, float od_
   store_vec<VEC>(a.sso, i, nsso);
   store_bytes<VEC>(a.flags, i, nfl);
   if (a.action_source == MDR_ACTIONS_BANGBANG && a.actions != nullptr) store_bytes<VEC>(a.actions, i, act);
+}
+
+template <int VEC>
+__device__ __forceinline__ void step_vec(const StepArgs& a, int64_t i, float od_old, float solar, HouseOut* out, int* lockout) {
+  float od[VEC], so[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    od[v] = od_old;
+    so[v] = solar;
+  }
+  step_vec_rows<VEC>(a, i, od, so, out, lockout);
 }
 
 // The five observation columns that do not depend on the env-wide reductions.
@@ -225,6 +237,33 @@ __device__ __forceinline__ void store_reward_power(const StepArgs& a, int64_t i,
   if (a.obs == nullptr) return;
   store_out<VEC>(a.obs + 5 * a.plane, i, c5);
   store_out<VEC>(a.obs + 6 * a.plane, i, c6);
+}
+
+// Graph mode: a captured launch carries the pointers of table row 0; the device-resident cursor says where the episode is.
+__device__ __forceinline__ void rebase(StepArgs& a) {
+  if (a.cursor == nullptr) return;
+  const int64_t off = (int64_t)min(a.cursor[0], a.cursor_max) * a.E;
+  a.od_old += off;
+  a.solar_new += off;
+  a.sig_old += off;
+  a.sig_new += off;
+}
+
+
+// Graph mode: the last workgroup of a step's last kernel moves the cursor on.  Every thread read the cursor first thing (rebase)
+// and then either left the kernel or waits at the barrier below, so when the last workgroup's thread 0 has counted all arrivals
+// nobody in this launch reads it any more; whatever reads it next is a later launch on the stream.  Saves each captured step a
+// one-thread launch of its own (~2 us of node-to-node latency on a 6-10 us step).  Thread 0 of every workgroup must get here.
+__device__ __forceinline__ void cursor_done(const StepArgs& a) {
+  if (a.cursor_adv == nullptr) return;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+  if (atomicAdd(reinterpret_cast<unsigned*>(a.cursor_adv + 3), 1u) == total - 1u) {
+    a.cursor_adv[3] = 0;
+    a.cursor_adv[0] += 1;
+    a.cursor_adv[1] += 1;
+  }
 }
 
 }  // namespace mdr
