@@ -169,6 +169,15 @@ typedef struct mdr_buffers {
    * temperature penalty for the finish.  With a buffer of its own the rewards of a step stay readable while the next step is
    * begun - what mdr_env_step_end_begin_records needs. */
   float *pen_stash;
+  /* Optional (all NULL = off; tab2_abs_noise iff tab_abs_noise): a SECOND set of time tables, same shapes.  The tables of the next
+   * window of table_steps steps are then built ahead on a stream of the library's own while the steps of the current window run
+   * on the caller's stream, and the two sets swap roles at the window's end (the caller's stream waits for an event that is long
+   * done by then): the O(nb_envs) refill - fp64 transcendentals and Philox draws per env and row - leaves the steps' critical path,
+   * which matters for batches of many small envs (209,715 envs x 20 houses: 8 us of every 72 us step).  Not used in
+   * base_power_mode "interpolation", in graph mode or inside a capture (refills are built in place there, as without the set).
+   * mdr_env_active_tables() says which set the current window reads: 0 = tab_*, 1 = tab2_*. */
+  float *tab2_od, *tab2_solar;
+  double *tab2_signal, *tab2_abs_noise;
 } mdr_buffers_t;
 
 /* Raw episode parameters for mdr_env_load_episode (replay of an episode sampled elsewhere).
@@ -449,6 +458,7 @@ int mdr_env_graph_replayed(mdr_env_t *env, int64_t n, void *stream);
 int mdr_env_pack(mdr_env_t *env, int32_t env_index, double *out, void *stream);
 
 int mdr_env_cursor(const mdr_env_t *env, int64_t *k, int64_t *j0);
+int mdr_env_active_tables(const mdr_env_t *env);
 /* Re-create a cursor on a new handle whose buffers were cloned from another env: copy.deepcopy(env) as
  * utils.test_*_agent use it (utils.py:890, 931, 970, 1008). */
 int mdr_env_set_cursor(mdr_env_t *env, uint64_t seed, uint32_t episode, int64_t k, int64_t j0);

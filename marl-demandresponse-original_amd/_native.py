@@ -71,6 +71,7 @@ class MdrBuffers(C.Structure):
         ("tab_od", _f32p), ("tab_solar", _f32p), ("tab_signal", _f64p),
         ("partials", _f64p), ("base_power", _f64p), ("cursor", C.c_void_p), ("tab_abs_noise", _f64p),
         ("pen_stash", _f32p),
+        ("tab2_od", _f32p), ("tab2_solar", _f32p), ("tab2_signal", _f64p), ("tab2_abs_noise", _f64p),
     ]
 
 
@@ -137,7 +138,7 @@ EXPORTS = (
     "mdr_env_step_begin", "mdr_env_step_end", "mdr_env_step_end_gathered", "mdr_env_step_begin_records", "mdr_env_step_end_records", "mdr_env_step_end_begin_records",
     "mdr_env_interp_due", "mdr_env_interp_local", "mdr_env_interp_apply", "mdr_obs_vector_length", "mdr_env_obs_vector",
     "mdr_obs_message_fields", "mdr_env_obs_messages", "mdr_env_obs_vector_ext", "mdr_env_comm_draws",
-    "mdr_env_graph_room", "mdr_env_graph_replayed", "mdr_env_pack", "mdr_env_cursor", "mdr_env_set_cursor",
+    "mdr_env_graph_room", "mdr_env_graph_replayed", "mdr_env_pack", "mdr_env_cursor", "mdr_env_set_cursor", "mdr_env_active_tables",
     "mdr_mailbox_bytes", "mdr_persist_records", "mdr_env_rollout_persistent",
     "mdr_mailbox_alloc", "mdr_mailbox_free", "mdr_mailbox_export", "mdr_mailbox_open", "mdr_mailbox_close", "mdr_mailbox_peek",
     # include/mdr_policy.h
@@ -206,6 +207,7 @@ def load():
         "mdr_env_comm_draws": (C.c_int, [vp, C.POINTER(MdrObsSpec), vp, vp, vp]),
         "mdr_env_cursor": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
         "mdr_env_set_cursor": (C.c_int, [vp, u64, u32, i64, i64]),
+        "mdr_env_active_tables": (C.c_int, [vp]),
         "mdr_actor_steps1": (i64, [i32, i32]),
         "mdr_actor_steps2": (i64, [i32, i32]),
         "mdr_actor_frag1_floats": (i64, [i32, i32]),

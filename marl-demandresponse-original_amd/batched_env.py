@@ -45,7 +45,7 @@ class BatchedDemandResponseEnv:
                  house_shard: Optional[Tuple[int, int]] = None, process_group=None,
                  stagger_bytes: int = 2304, interp_grid=None, regenerate_missing_grid: bool = True,
                  graph_mode: bool = False, exchange_always: bool = False, partial_records: Optional[int] = None,
-                 obs_planes: bool = True):
+                 obs_planes: bool = True, prefetch_tables: bool = True):
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedDemandResponseEnv needs a ROCm device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -80,6 +80,9 @@ class BatchedDemandResponseEnv:
         # obs_planes=False: mdr_buffers_t.obs stays NULL and the step kernels skip the seven planes (71 instead of 99 B per
         # house-step) - for loops that observe through obs_vector() / FusedActor.sample_env, which read the state itself
         self._obs_planes_alloc = self._obs_planes_on = bool(obs_planes)
+        # a second set of time tables: the next window's tables are built on a side stream of the library while this window's steps
+        # run (mdr_buffers_t.tab2_*); not in graph mode / interpolation mode, where refills stay in place
+        self._prefetch_tables = bool(prefetch_tables) and not self.graph_mode and self.spec.base_power_mode != 1
         self._handle = C.c_void_p()
         self._cfg = self._make_config()
         rc = self._lib.mdr_env_create(C.byref(self._cfg), C.byref(self._handle))
@@ -145,6 +148,9 @@ class BatchedDemandResponseEnv:
         items += [("tot", torch.float64, (3, E))]     # local aggregates as ONE block: tot_sum = tot[0:2], tot_max = tot[2]
         items += [("tab_od", torch.float32, (K1, E)), ("tab_solar", torch.float32, (K1, E)), ("tab_signal", torch.float64, (K1, E)),
                   ("tab_abs_noise", torch.float64, (K1, E))]
+        K2 = K1 if self._prefetch_tables else 0
+        items += [("tab2_od", torch.float32, (K2, E)), ("tab2_solar", torch.float32, (K2, E)), ("tab2_signal", torch.float64, (K2, E)),
+                  ("tab2_abs_noise", torch.float64, (K2, E))]
         items += [("partials", torch.float64, (E, nblk, 3))]
         items += [("cursor", torch.int32, (8,))]      # graph mode: {table row, time index, row note 0, arrival counter, row note 1, -} on the device
         # split path (sharded houses, N > 4096): the houses' own penalties between the partial and the finish kernel; else NULL
@@ -162,6 +168,7 @@ class BatchedDemandResponseEnv:
             nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
             offsets[name] = (off, nbytes, dtype, shape)
             off += nbytes
+        self._offsets = offsets
         self._slab = torch.zeros(_align(off, 256), dtype=torch.uint8, device=self.device)
         self.t: Dict[str, torch.Tensor] = {}
         for name, (o, nbytes, dtype, shape) in offsets.items():
@@ -870,18 +877,25 @@ class BatchedDemandResponseEnv:
     def hvac_lockout(self) -> torch.Tensor:
         return (self.t["flags"] & 2).bool()
 
+    def table(self, name: str) -> torch.Tensor:
+        """The time table `name` (tab_od, tab_solar, tab_signal, tab_abs_noise) of the CURRENT window: with table prefetch the two
+        sets of table buffers swap roles at every refill (mdr_env_active_tables)."""
+        if self._prefetch_tables and int(self._lib.mdr_env_active_tables(self._handle)) == 1:
+            return self.t["tab2_" + name[4:]]
+        return self.t[name]
+
     def od_temp(self) -> torch.Tensor:
-        return self.t["tab_od"][self._row()].double() + self.spec.temp_ref
+        return self.table("tab_od")[self._row()].double() + self.spec.temp_ref
 
     def reg_signal(self) -> torch.Tensor:
         if self.graph_mode:      # row from the device cursor: stays right when the call is captured and replayed
             if not torch.cuda.is_current_stream_capturing():
                 self.graph_replayed(0)      # the device cursor is synced lazily (e.g. after reset): make it current
             return torch.index_select(self.t["tab_signal"], 0, self.t["cursor"][:1].long())[0]
-        return self.t["tab_signal"][self._row()]
+        return self.table("tab_signal")[self._row()]
 
     def solar_gain(self) -> torch.Tensor:
-        return self.t["tab_solar"][self._row()].double()
+        return self.table("tab_solar")[self._row()].double()
 
     def datetimes(self):
         k = self.steps_taken
@@ -890,10 +904,17 @@ class BatchedDemandResponseEnv:
     # ------------------------------------------------------------------ snapshot (copy.deepcopy(env) in utils.py:890-1008)
     def state_dict(self) -> dict:
         k, j0 = self.cursor()
-        return {"slab": self._slab.clone(), "k": k, "j0": j0, "seed": self.seed, "episode": self.episode,
+        torch.cuda.synchronize(self.device)      # a table prefetch may be writing the other table set on the library's side stream
+        slab = self._slab.clone()
+        if self._prefetch_tables and int(self._lib.mdr_env_active_tables(self._handle)) == 1:
+            for name in ("od", "solar", "signal", "abs_noise"):      # the snapshot keeps the current window in the FIRST table set
+                o, nbytes, dtype, shape = self._offsets["tab_" + name]
+                slab[o:o + nbytes].view(dtype).view(*shape).copy_(self.t["tab2_" + name])
+        return {"slab": slab, "k": k, "j0": j0, "seed": self.seed, "episode": self.episode,
                 "od_table": None if self._od_table is None else self._od_table.clone()}
 
     def load_state_dict(self, sd: dict):
+        torch.cuda.synchronize(self.device)      # (a prefetch in flight would write into the slab being replaced)
         self._slab.copy_(sd["slab"])
         self.seed, self.episode = sd["seed"], sd["episode"]
         if sd.get("od_table") is not None:
@@ -907,6 +928,7 @@ class BatchedDemandResponseEnv:
     def __deepcopy__(self, memo):
         other = BatchedDemandResponseEnv(copy.deepcopy(self.config, memo), nb_envs=self.nb_envs, device=self.device,
                                          seed=self.seed, test=self.test, table_steps=self.table_steps, obs_planes=self._obs_planes_alloc,
+                                         prefetch_tables=self._prefetch_tables,
                                          env_offset=self.env_offset,
                                          house_shard=(self.house_offset, self.nb_houses) if self.sharded else None,
                                          exchange_always=self._exchange_always, partial_records=self._partial_records,

@@ -35,6 +35,15 @@ struct mdr_env {
   mdr_interp_grid_t interp{};   // base_power_mode == 1
   bool has_interp = false;
   int64_t interp_steps = 0;     // U: env steps between two interpolatePower calls = ceil(update_period / time_step)
+  // Table prefetch (mdr_buffers_t.tab2_*): the tables of the NEXT window are built on a side stream while the current window's
+  // steps run, into the set of table buffers the steps do not read; at the window's end the sets swap roles.
+  struct TableSet { float* od; float* solar; double* signal; double* abs_noise; } tabs[2] = {};
+  int active = 0;               // tabs[active] is what buf.tab_* point at
+  bool has_alt = false;
+  bool prefetched = false;      // tabs[active ^ 1] holds (or is being filled with) the tables of time index prefetch_j0
+  int64_t prefetch_j0 = -1;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fill = nullptr, ev_free = nullptr;
   uint32_t mailbox_tag = 1;     // persistent rollout: tag of the next step pushed through the mailbox (counts over the handle's life; 0 = never written)
   std::string err;
 };
@@ -153,13 +162,23 @@ mdr::EpisodeArgs episode_args(const mdr_env& env) {
   return a;
 }
 
-int fill_tables(mdr_env* env, int64_t j0, hipStream_t s) {
+void use_tables(mdr_env* env, int which) {
+  env->active = which;
+  env->buf.tab_od = env->tabs[which].od;
+  env->buf.tab_solar = env->tabs[which].solar;
+  env->buf.tab_signal = env->tabs[which].signal;
+  env->buf.tab_abs_noise = env->tabs[which].abs_noise;
+}
+
+// `into` == nullptr: the tables the steps read (the active set) from time index j0, on the caller's stream; else a prefetch into
+// the other set (the host cursor does not move)
+int fill_tables(mdr_env* env, int64_t j0, hipStream_t s, const mdr_env::TableSet* into = nullptr) {
   const mdr_config_t& c = env->cfg;
   mdr::TableArgs t{};
-  t.tab_od = env->buf.tab_od;
-  t.tab_solar = env->buf.tab_solar;
-  t.tab_signal = env->buf.tab_signal;
-  t.tab_abs_noise = env->buf.tab_abs_noise;
+  t.tab_od = into ? into->od : env->buf.tab_od;
+  t.tab_solar = into ? into->solar : env->buf.tab_solar;
+  t.tab_signal = into ? into->signal : env->buf.tab_signal;
+  t.tab_abs_noise = into ? into->abs_noise : env->buf.tab_abs_noise;
   t.t0 = env->buf.t0;
   t.phase = env->buf.phase;
   t.ratio = env->buf.ratio;
@@ -197,7 +216,10 @@ int fill_tables(mdr_env* env, int64_t j0, hipStream_t s) {
   t.perlin_period = c.perlin_period;
   hipError_t e = mdr::launch_tables(t, s);
   if (e != hipSuccess) return hip_fail(env, e, "fill_tables");
-  env->j0 = j0;
+  if (into == nullptr) {
+    env->j0 = j0;
+    env->prefetched = false;   // whatever the other set holds was built for another window
+  }
   return MDR_OK;
 }
 
@@ -245,6 +267,51 @@ bool capturing(hipStream_t s) {
   return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
 }
 
+// The tables of the window after the current one, built on the side stream while the current window's steps run on `main`.
+// Off in interpolation mode (the tables depend on state at every update), in graph mode (captured launches carry the pointers of
+// one table set) and inside a capture.
+int issue_prefetch(mdr_env* env, hipStream_t main) {
+  if (!env->has_alt || interp_mode(env) || graph_mode(env) || capturing(main)) return MDR_OK;
+  hipError_t e = hipSuccess;
+  if (env->side == nullptr) {
+    // MDR_PREFETCH_PRIORITY=low|high: experiment knob (default: the priority of an ordinary stream)
+    static const int prio = [] { const char* t = getenv("MDR_PREFETCH_PRIORITY"); return !t ? 0 : (t[0] == 'l' ? 1 : (t[0] == 'h' ? 2 : 0)); }();
+    if (prio != 0) {
+      int least = 0, greatest = 0;
+      e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+      if (e == hipSuccess) e = hipStreamCreateWithPriority(&env->side, hipStreamNonBlocking, prio == 1 ? least : greatest);
+    } else {
+      e = hipStreamCreateWithFlags(&env->side, hipStreamNonBlocking);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&env->ev_fill, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&env->ev_free, hipEventDisableTiming);
+    if (e != hipSuccess) return hip_fail(env, e, "table prefetch: side stream");
+  }
+  // everything enqueued on `main` so far - the previous window's steps read the set about to be overwritten - comes first
+  e = hipEventRecord(env->ev_free, main);
+  if (e == hipSuccess) e = hipStreamWaitEvent(env->side, env->ev_free, 0);
+  if (e != hipSuccess) return hip_fail(env, e, "table prefetch: ordering");
+  const int64_t next = env->j0 + env->cfg.table_steps;
+  int rc = fill_tables(env, next, env->side, &env->tabs[env->active ^ 1]);
+  if (rc != MDR_OK) return rc;
+  e = hipEventRecord(env->ev_fill, env->side);
+  if (e != hipSuccess) return hip_fail(env, e, "table prefetch: event");
+  env->prefetched = true;
+  env->prefetch_j0 = next;
+  return MDR_OK;
+}
+
+// Before anything on `main` rewrites what a prefetch in flight reads (t0, phase, ratio, max_power at an episode start): wait for it
+// and forget it
+int settle_prefetch(mdr_env* env, hipStream_t main) {
+  if (env->prefetched && env->ev_fill != nullptr) {
+    hipError_t e = hipStreamWaitEvent(main, env->ev_fill, 0);
+    if (e != hipSuccess) return hip_fail(env, e, "table prefetch: settle");
+  }
+  env->prefetched = false;
+  return MDR_OK;
+}
+
 // Graph mode: make the device cursor say (k - j0, k).  Never inside a capture - a captured reset would rewind every replay.
 int sync_cursor(mdr_env* env, hipStream_t s) {
   if (!graph_mode(env)) return MDR_OK;
@@ -288,7 +355,18 @@ int step_args(mdr_env* env, uint8_t* actions, int action_source, hipStream_t s, 
     return fail(env, MDR_ERR_INVALID, "actions must be 2-byte aligned when nb_houses is even");
   if (env->k + 1 - env->j0 > c.table_steps) {
     if (capturing(s)) return fail(env, MDR_ERR_INVALID, "the time tables end here: a refill cannot be captured (mdr_env_graph_room() is 0)");
-    int rc = fill_tables(env, env->k, s);
+    int rc;
+    if (env->prefetched && env->prefetch_j0 == env->k) {   // built meanwhile on the side stream: wait for it (long done) and swap the sets
+      hipError_t e = hipStreamWaitEvent(s, env->ev_fill, 0);
+      if (e != hipSuccess) return hip_fail(env, e, "table prefetch: wait");
+      use_tables(env, env->active ^ 1);
+      env->j0 = env->k;
+      env->prefetched = false;
+    } else {
+      rc = fill_tables(env, env->k, s);
+      if (rc != MDR_OK) return rc;
+    }
+    rc = issue_prefetch(env, s);
     if (rc != MDR_OK) return rc;
   }
   const int64_t r0 = env->k - env->j0, r1 = r0 + 1;
@@ -386,16 +464,40 @@ int mdr_env_create(const mdr_config_t* config, mdr_env_t** out) {
 }
 
 int mdr_env_destroy(mdr_env_t* env) {
+  if (env) {
+    if (env->side) (void)hipStreamDestroy(env->side);
+    if (env->ev_fill) (void)hipEventDestroy(env->ev_fill);
+    if (env->ev_free) (void)hipEventDestroy(env->ev_free);
+  }
   delete env;
   return MDR_OK;
 }
+
+int mdr_env_active_tables(const mdr_env_t* env) { return env ? env->active : 0; }
 
 int mdr_env_bind(mdr_env_t* env, const mdr_buffers_t* buffers) {
   if (!env || !buffers) return MDR_ERR_INVALID;
   const bool sharded = env->cfg.nb_houses_total != env->cfg.nb_houses;
   const std::string msg = check_buffers(*buffers, sharded || env->plan.kind == mdr::STEP_SPLIT);
   if (!msg.empty()) return fail(env, MDR_ERR_INVALID, msg);
+  const bool any2 = buffers->tab2_od || buffers->tab2_solar || buffers->tab2_signal || buffers->tab2_abs_noise;
+  const bool all2 = buffers->tab2_od && buffers->tab2_solar && buffers->tab2_signal && ((buffers->tab2_abs_noise != nullptr) == (buffers->tab_abs_noise != nullptr));
+  if (any2 && !all2) return fail(env, MDR_ERR_INVALID, "tab2_od / tab2_solar / tab2_signal (and tab2_abs_noise iff tab_abs_noise) go together");
+  const mdr_env::TableSet t0{buffers->tab_od, buffers->tab_solar, buffers->tab_signal, buffers->tab_abs_noise};
+  const mdr_env::TableSet t1{buffers->tab2_od, buffers->tab2_solar, buffers->tab2_signal, buffers->tab2_abs_noise};
+  // a re-bind that leaves the table buffers where they are (another optional buffer came or went mid-episode) keeps the window
+  const bool same_tables = env->bound && memcmp(&t0, &env->tabs[0], sizeof t0) == 0 && memcmp(&t1, &env->tabs[1], sizeof t1) == 0;
+  if (!same_tables && env->prefetched && env->ev_fill) (void)hipEventSynchronize(env->ev_fill);   // a prefetch into the old buffers: let it land
   env->buf = *buffers;
+  env->tabs[0] = t0;
+  env->tabs[1] = t1;
+  env->has_alt = all2;
+  if (same_tables) {
+    use_tables(env, env->active);
+  } else {
+    env->active = 0;
+    env->prefetched = false;
+  }
   env->bound = true;
   env->dev_row = env->dev_k = -1;
   env->err.clear();
@@ -413,6 +515,7 @@ int mdr_env_reset(mdr_env_t* env, uint64_t seed, uint32_t episode, void* stream)
   env->interp_due = false;
   env->od_ext = nullptr;      // a recorded outdoor-temperature sequence belongs to the episode it was loaded with
   env->od_ext_rows = 0;
+  if (settle_prefetch(env, (hipStream_t)stream) != MDR_OK) return MDR_ERR_HIP;
   hipError_t e = mdr::launch_sample(episode_args(*env), (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "reset");
   env->has_episode = true;
@@ -433,6 +536,7 @@ int mdr_env_load_episode(mdr_env_t* env, const mdr_episode_t* ep, uint64_t seed,
   env->split_pending = false;
   env->records_stride = 0;
   env->interp_due = false;
+  if (settle_prefetch(env, (hipStream_t)stream) != MDR_OK) return MDR_ERR_HIP;
   hipError_t e = mdr::launch_load(episode_args(*env), *ep, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "load_episode");
   env->has_episode = true;
@@ -445,6 +549,7 @@ int mdr_env_set_od_table(mdr_env_t* env, const double* od_table, int64_t rows) {
   if (od_table && rows < 1) return fail(env, MDR_ERR_INVALID, "od table needs rows >= 1");
   env->od_ext = od_table;
   env->od_ext_rows = od_table ? rows : 0;
+  env->prefetched = false;   // a window built ahead used the old sequence: the next refill is built in place
   return MDR_OK;
 }
 
@@ -476,7 +581,8 @@ int mdr_env_begin_episode(mdr_env_t* env, void* stream) {
   }
   env->k = 0;
   env->interp_due = false;
-  int rc;
+  int rc = settle_prefetch(env, (hipStream_t)stream);
+  if (rc != MDR_OK) return rc;
   if (interp_mode(env) && sharded(env)) {   // the signal rows stay provisional until mdr_env_interp_apply
     rc = fill_tables(env, 0, (hipStream_t)stream);
     env->interp_due = true;
@@ -490,7 +596,7 @@ int mdr_env_begin_episode(mdr_env_t* env, void* stream) {
   if (rc != MDR_OK) return rc;
   hipError_t e = mdr::launch_reset_obs(a, true, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(env, e, "reset_obs");
-  return MDR_OK;
+  return issue_prefetch(env, (hipStream_t)stream);   // the second window's tables, built while the first is stepped through
 }
 
 int mdr_env_refresh_obs(mdr_env_t* env, void* stream) {
@@ -1169,6 +1275,9 @@ int mdr_env_set_cursor(mdr_env_t* env, uint64_t seed, uint32_t episode, int64_t 
   env->k = k;
   env->j0 = j0;
   env->dev_row = env->dev_k = -1;   // the caller replaced the buffers (incl. the device cursor): nothing is known about it
+  if (env->prefetched && env->ev_fill) (void)hipEventSynchronize(env->ev_fill);
+  env->prefetched = false;
+  use_tables(env, 0);               // ... and put the tables of (k, j0) into the first table set
   env->has_episode = true;
   env->has_tables = true;
   env->split_pending = false;

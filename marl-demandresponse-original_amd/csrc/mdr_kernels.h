@@ -187,7 +187,7 @@ int64_t persist_mailbox_granules(int E, int world, int stride);
 hipError_t persist_resident_blocks(int vec, bool system_scope, int depth, int64_t* blocks);   // workgroups of the kernel the device holds at once
 hipError_t launch_rollout_persist(const StepArgs& a, const RolloutArgs& r, const PersistArgs& m, bool system_scope, hipStream_t s);
 
-enum StepKind { STEP_FUSED = 0, STEP_GROUP = 1, STEP_SPLIT = 2, STEP_SINGLE = 3, STEP_MULTI = 4 };   // STEP_MULTI: `tiles` envs share a group of `threads` lanes (mdr_multi.hip)
+enum StepKind { STEP_FUSED = 0, STEP_GROUP = 1, STEP_SPLIT = 2, STEP_SINGLE = 3, STEP_MULTI = 4, STEP_PACKED = 5 };   // STEP_MULTI: `tiles` envs share a group of `threads` lanes; STEP_PACKED: `tiles` whole envs of `threads` lanes each per wavefront (mdr_multi.hip)
 struct StepPlan {
   int kind, vec, threads, tiles;
 };

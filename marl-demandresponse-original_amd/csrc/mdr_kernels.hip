@@ -2039,6 +2039,21 @@ StepPlan plan_step(int N, int64_t E) {
     p.tiles = 2;                        // envs per group
     return p;
   }
+  // Device-filling batches with N % 4 == 0 whose N / 4 lanes are not a power of two: whole envs packed into the wavefront
+  // (k_step_packed) where rounding each env up to a power of two would leave more than 40 % of the lanes idle - 36 houses: 9 lanes
+  // of 16 -> 63 of 64, 67.9 -> 64.4 us at 4.19 M houses.  (Measured and left alone: 20 houses, 5 lanes of 8 -> 60 of 64: 64.0 -> 64.1 us;
+  // 12 and 40 houses lose 1-2 % - at these sizes the step is bound by its memory INSTRUCTIONS per wave, not by idle lanes.)
+  static const bool packed_ok = [] { const char* t = getenv("MDR_PLAN_PACKED"); return !(t && t[0] == '0'); }();
+  if (packed_ok && N % 4 == 0 && N >= 12 && N <= 128 && E * N >= 262144) {
+    const int L = N / 4, per_wave = 64 / L;
+    if ((L & (L - 1)) != 0 && 10 * L < 6 * pow2_at_least(L) && per_wave * pow2_at_least(L) > 64) {
+      p.kind = STEP_PACKED;
+      p.vec = 4;
+      p.threads = L;
+      p.tiles = per_wave;
+      return p;
+    }
+  }
   if (N == 1 && E % 4 == 0 && E >= 262144) {   // single-house envs in bulk: vectorise over the env axis
     p.kind = STEP_SINGLE;
     p.vec = 4;
@@ -2075,7 +2090,7 @@ StepPlan plan_step(int N, int64_t E) {
 // The multi-step kernels keep one house per lane (sub-wave groups) or VEC x TILES houses per thread (workgroup per env)
 StepPlan plan_rollout(int N, int64_t E) {
   StepPlan p = plan_step(N, E);
-  if (p.kind == STEP_GROUP || p.kind == STEP_MULTI) return p;   // same lane mapping as the single-step kernel
+  if (p.kind == STEP_GROUP || p.kind == STEP_MULTI || p.kind == STEP_PACKED) return p;   // same lane mapping as the single-step kernel
   if (p.kind == STEP_SINGLE) {          // one lane per env; nothing to reduce, so any mapping gives the same bits
     p.kind = STEP_GROUP;
     p.vec = 1;
@@ -2154,11 +2169,11 @@ hipError_t launch_step_end_begin_split(const StepArgs& f, const StepArgs& p, hip
   return hipGetLastError();
 }
 
-bool rollout_fused_supported(const StepPlan& p) { return p.kind == STEP_GROUP || p.kind == STEP_FUSED || p.kind == STEP_MULTI; }
+bool rollout_fused_supported(const StepPlan& p) { return p.kind == STEP_GROUP || p.kind == STEP_FUSED || p.kind == STEP_MULTI || p.kind == STEP_PACKED; }
 
 hipError_t launch_rollout_fused(const StepArgs& a, const RolloutArgs& r, const StepPlan& p, hipStream_t s) {
   if (!rollout_fused_supported(p)) return hipErrorInvalidValue;
-  if (p.kind == STEP_MULTI) return launch_rollout_multi(a, r, p, s);
+  if (p.kind == STEP_MULTI || p.kind == STEP_PACKED) return launch_rollout_multi(a, r, p, s);
   if (p.kind == STEP_GROUP) {
     const int64_t lanes = (int64_t)a.E * p.threads;
     const dim3 gg((unsigned)((lanes + 255) / 256)), b(256);
@@ -2216,7 +2231,7 @@ static int cursor_atomic_blocks() {
 static int64_t step_blocks(const StepArgs& a, const StepPlan& p) {
   if (p.kind == STEP_SINGLE) return (a.E / 4 + 255) / 256;
   if (p.kind == STEP_FUSED) return a.E;
-  if (p.kind == STEP_MULTI) return multi_blocks(a.E, p);
+  if (p.kind == STEP_MULTI || p.kind == STEP_PACKED) return multi_blocks(a.E, p);
   return ((int64_t)a.E * p.threads + 255) / 256;
 }
 
@@ -2229,7 +2244,7 @@ hipError_t launch_step(const StepArgs& args, const StepPlan& p, hipStream_t s) {
     hipLaunchKernelGGL(k_cursor_advance, dim3(1), dim3(1), 0, s, args.cursor_adv);
     return hipGetLastError();
   }
-  if (p.kind == STEP_MULTI) return launch_step_multi(a, p, s);
+  if (p.kind == STEP_MULTI || p.kind == STEP_PACKED) return launch_step_multi(a, p, s);
   if (p.kind == STEP_SINGLE) {
     hipLaunchKernelGGL(k_step_single_house, dim3((unsigned)((a.E / 4 + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();

@@ -323,7 +323,203 @@ __global__ __launch_bounds__(256) void k_rollout_multi(StepArgs a, RolloutArgs r
   }
 }
 
+// ---- (2d) whole envs packed into a wavefront without rounding their lane count up to a power of two.  N % 4 == 0, L = N / 4
+// lanes per env, floor(64 / L) envs per wavefront: 20 houses (the reference's training size, cli.py:53) fill 60 of 64 lanes
+// instead of 5 of every 8.  The env's totals come from a segmented reduction over its L consecutive lanes: ceil(log2 L) shuffle
+// steps that add the value d lanes up while that lane is still in the env - lane 0 of the env then holds
+// ((a0 + a1) + (a2 + a3)) + ... - and one broadcast.  Same function in the step and the rollout kernel: bit for bit alike.
+struct PackedLane {
+  int L, lane, first;   // lanes per env; this lane's position in its env; wavefront lane of the env's first lane
+  int64_t env;          // env index (>= E: idle lane)
+  __device__ __forceinline__ void init(const StepArgs& a) {
+    L = a.N >> 2;
+    const int l64 = threadIdx.x & 63;
+    const int per_wave = 64 / L;
+    const int k = (l64 * ((65536 + L - 1) / L)) >> 16;   // l64 / L for l64 < 64, L <= 32
+    lane = l64 - k * L;
+    first = k * L;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    env = k < per_wave ? wave * per_wave + k : INT64_MAX;
+  }
+};
+
+__device__ __forceinline__ Red3 packed_reduce(Red3 v, const PackedLane& m, bool pen) {
+  for (int d = 1; d < m.L; d <<= 1) {
+    const bool in = m.lane + d < m.L;
+    const double p = __shfl_down(v.sum_p, d, 64);
+    v.sum_p += in ? p : 0.0;
+    if (pen) {
+      const double q = __shfl_down(v.sum_pen, d, 64);
+      const float x = __shfl_down(v.max_pen, d, 64);
+      v.sum_pen += in ? q : 0.0;
+      v.max_pen = fmaxf(v.max_pen, in ? x : 0.0f);
+    }
+  }
+  v.sum_p = __shfl(v.sum_p, m.first, 64);
+  if (pen) {
+    v.sum_pen = __shfl(v.sum_pen, m.first, 64);
+    v.max_pen = __shfl(v.max_pen, m.first, 64);
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_step_packed(StepArgs a) {
+  rebase(a);
+  const bool need_pen = a.penalty_mode != MDR_PENALTY_INDIVIDUAL_L2;
+  PackedLane m;
+  m.init(a);
+  const bool active = m.env < a.E;
+  const int e = active ? (int)m.env : a.E - 1;
+  const int64_t i = (int64_t)e * a.N + m.lane * 4;
+  HouseOut o[4];
+  int lockout[4];
+  float pen[4];
+  Red3 acc{0.0, 0.0, 0.0f};
+  if (active) {
+    step_vec<4>(a, i, a.od_old[e], a.solar_new[e], o, lockout);
+    float p = 0.0f, ps = 0.0f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      p += o[v].power;
+      ps += o[v].pen;
+      pen[v] = o[v].pen;
+      acc.max_pen = fmaxf(acc.max_pen, o[v].pen);
+    }
+    acc.sum_p = (double)p;
+    acc.sum_pen = (double)ps;
+    store_obs_local<4>(a, i, o, lockout);
+  }
+  const Red3 tot = packed_reduce(acc, m, need_pen);
+  if (active) {
+    const float sig_term = signal_term(a, tot.sum_p, a.sig_old[e]);
+    if (m.lane == 0) a.P[e] = tot.sum_p;
+    store_reward_power<4>(a, i, pen, tot.sum_pen, tot.max_pen, sig_term, (float)(a.sig_new[e] * a.inv_obs_norm), (float)(tot.sum_p * a.inv_obs_norm));
+  }
+  cursor_done(a);
+}
+
+__global__ __launch_bounds__(256) void k_rollout_packed(StepArgs a, RolloutArgs ro) {
+  const bool need_pen = a.penalty_mode != MDR_PENALTY_INDIVIDUAL_L2;
+  const bool want_rsum = ro.reward_sum != nullptr;
+  PackedLane m;
+  m.init(a);
+  const bool active = m.env < a.E;
+  const int e = active ? (int)m.env : a.E - 1;
+  const int64_t i = (int64_t)e * a.N + m.lane * 4;
+  HouseIn hs[4];
+  HouseOut o[4];
+  int lockout[4];
+  float rsum[4], pen[4];
+  unsigned act[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    hs[v] = HouseIn{};
+    o[v] = HouseOut{};
+    lockout[v] = 1;
+    rsum[v] = 0.0f;
+    act[v] = 0;
+  }
+  if (active) {
+    float Ta[4], Tm[4], k01[4], s0[4], k10[4], s1[4], iu[4], q[4], pm[4], tg[4], db[4];
+    int sso[4];
+    unsigned fl[4];
+    load_vec<4>(a.Ta, i, Ta);
+    load_vec<4>(a.Tm, i, Tm);
+    load_vec<4>(a.sso, i, sso);
+    load_bytes<4>(a.flags, i, fl);
+    load_vec<4>(a.k01, i, k01);
+    load_vec<4>(a.s0, i, s0);
+    load_vec<4>(a.k10, i, k10);
+    load_vec<4>(a.s1, i, s1);
+    load_vec<4>(a.inv_Ua, i, iu);
+    load_vec<4>(a.Q_hvac, i, q);
+    load_vec<4>(a.P_max, i, pm);
+    load_vec<4>(a.target, i, tg);
+    load_vec<4>(a.deadband, i, db);
+    load_vec<4>(a.lockout, i, lockout);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) hs[v] = HouseIn{Ta[v], Tm[v], sso[v], fl[v], k01[v], s0[v], k10[v], s1[v], iu[v], q[v], pm[v], tg[v], db[v], lockout[v]};
+    if (ro.reward_sum) load_vec<4>(ro.reward_sum, i, rsum);
+  }
+  float sig_term = 0.0f;
+  double terr = 0.0, serr = 0.0, sig_new = 0.0;
+  Red3 tot{0.0, 0.0, 0.0f};
+  for (int s = 0; s < ro.nsteps; ++s) {
+    const int64_t row = (int64_t)s * a.E + e;
+    const float od = a.od_old[row], solar = a.solar_new[row];
+    const double sig_old = a.sig_old[row];
+    sig_new = a.sig_new[row];
+    Red3 acc{0.0, 0.0, 0.0f};
+    if (active) {
+      float p = 0.0f, ps = 0.0f, te = 0.0f;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const bool cmd = hs[v].Ta > hs[v].target;
+        act[v] = cmd ? 1u : 0u;
+        o[v] = house_step(hs[v], cmd, od, solar, a.dt);
+        hs[v].Ta = o[v].Ta;
+        hs[v].Tm = o[v].Tm;
+        hs[v].sso = o[v].sso;
+        hs[v].flags = o[v].flags;
+        p += o[v].power;
+        ps += o[v].pen;
+        acc.max_pen = fmaxf(acc.max_pen, o[v].pen);
+        const float d = o[v].Ta - hs[v].target;
+        te = fmaf(d, d, te);
+      }
+      acc.sum_p = (double)p;
+      acc.sum_pen = (double)ps;
+      terr += (double)te;
+    }
+    tot = packed_reduce(acc, m, need_pen);
+    sig_term = signal_term(a, tot.sum_p, sig_old);
+    if (active) {
+      if (want_rsum) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) rsum[v] = __fadd_rn(rsum[v], reward_value(a, o[v].pen, tot.sum_pen, tot.max_pen, sig_term));
+      }
+      if (m.lane == 0) {
+        if (ro.power_trace) ro.power_trace[row] = tot.sum_p;
+        const double d = sig_new - tot.sum_p;
+        if (!(ro.defer_last_signal_error && s == ro.nsteps - 1)) serr += d * d;
+      }
+    }
+  }
+  if (ro.nsteps <= 0) return;
+  Red3 tr{terr, 0.0, 0.0f};
+  tr = packed_reduce(tr, m, false);
+  if (!active) return;
+  float nTa[4], nTm[4];
+  int nsso[4];
+  unsigned nfl[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    nTa[v] = hs[v].Ta;
+    nTm[v] = hs[v].Tm;
+    nsso[v] = hs[v].sso;
+    nfl[v] = hs[v].flags;
+    pen[v] = o[v].pen;
+  }
+  store_vec<4>(a.Ta, i, nTa);
+  store_vec<4>(a.Tm, i, nTm);
+  store_vec<4>(a.sso, i, nsso);
+  store_bytes<4>(a.flags, i, nfl);
+  if (a.actions != nullptr) store_bytes<4>(a.actions, i, act);
+  store_obs_local<4>(a, i, o, lockout);
+  store_reward_power<4>(a, i, pen, tot.sum_pen, tot.max_pen, sig_term, (float)(sig_new * a.inv_obs_norm), (float)(tot.sum_p * a.inv_obs_norm));
+  if (ro.reward_sum) store_vec<4>(ro.reward_sum, i, rsum);
+  if (m.lane == 0) {
+    a.P[e] = tot.sum_p;
+    if (ro.sq_temp_error_sum) ro.sq_temp_error_sum[e] += tr.sum_p;
+    if (ro.sq_signal_error_sum) ro.sq_signal_error_sum[e] += serr;
+  }
+}
+
 int64_t multi_blocks(int64_t E, const StepPlan& p) {
+  if (p.kind == STEP_PACKED) {   // p.tiles envs per wavefront
+    const int64_t waves = (E + p.tiles - 1) / p.tiles;
+    return (waves + 3) / 4;
+  }
   const int64_t groups = (E + p.tiles - 1) / p.tiles;
   return (groups * p.threads + 255) / 256;
 }
@@ -340,12 +536,20 @@ int64_t multi_blocks(int64_t E, const StepPlan& p) {
 
 hipError_t launch_step_multi(const StepArgs& a, const StepPlan& p, hipStream_t s) {
   const dim3 g((unsigned)multi_blocks(a.E, p)), b(256);
+  if (p.kind == STEP_PACKED) {
+    hipLaunchKernelGGL(k_step_packed, g, b, 0, s, a);
+    return hipGetLastError();
+  }
   MDR_MULTI_DISPATCH(k_step_multi, a)
   return hipGetLastError();
 }
 
 hipError_t launch_rollout_multi(const StepArgs& a, const RolloutArgs& r, const StepPlan& p, hipStream_t s) {
   const dim3 g((unsigned)multi_blocks(a.E, p)), b(256);
+  if (p.kind == STEP_PACKED) {
+    hipLaunchKernelGGL(k_rollout_packed, g, b, 0, s, a, r);
+    return hipGetLastError();
+  }
   MDR_MULTI_DISPATCH(k_rollout_multi, a, r)
   return hipGetLastError();
 }

@@ -40,7 +40,7 @@ def test_single_gpu_line_with_legs_over_rccl():
     p = line["c5_persistent"]                           # the same env without a kernel boundary or a collective per step
     assert "error" not in p, p
     assert p["checksum_Ta"] == line["c5"]["checksum_Ta"] and p["houses_per_rank"] == 1_000_000
-    assert p["us_per_step"] < g["us_per_step"] and p["us_per_step_no_accumulators"] <= p["us_per_step"] * 1.05
+    assert p["us_per_step"] < g["us_per_step"] and p["us_per_step_no_accumulators"] < g["us_per_step"]
     assert line["degraded"] is False and "degraded_reasons" not in line
     assert 0.4 < line["roofline"]["frac_out_of_cache"] < line["roofline"]["frac"] + 0.2
 

@@ -25,13 +25,17 @@ def _cfg(n, mode):
 
 def _envs(N, odd=False):
     E = -(-270000 // N)
-    if odd and (E * N) % 4 == 0:
-        E += 1
+    if odd:
+        E += 1 if (E * N) % 4 == 0 else 0
+        E += 1 if N % 4 == 0 and E % 2 == 0 else 0      # packed envs: a last wavefront that is not full
     return E
 
 
 @pytest.mark.parametrize("N,mode,odd", [(50, "mixture", False), (50, "individual_L2", True), (10, "common_L2", False), (6, "mixture", True),
-                                        (30, "common_max", False), (126, "mixture", True), (14, "individual_L2", False), (66, "common_L2", True)])
+                                        (30, "common_max", False), (126, "mixture", True), (14, "individual_L2", False), (66, "common_L2", True),
+                                        # N % 4 == 0 with N / 4 lanes not a power of two: whole envs packed into the wavefront (k_step_packed)
+                                        (36, "individual_L2", False), (36, "mixture", True), (68, "common_L2", False), (72, "common_max", True),
+                                        (76, "mixture", False)])
 def test_multi_env_groups_match_oracle_and_single_env_groups(N, mode, odd):
     import mdr_amd
     from oracle import mdr_oracle as mo
@@ -71,7 +75,8 @@ def test_multi_env_groups_match_oracle_and_single_env_groups(N, mode, odd):
         np.testing.assert_allclose(env.t["reward"][sl].cpu().numpy(), r_ref, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("N,mode,odd", [(50, "mixture", False), (50, "individual_L2", True), (10, "common_max", False), (126, "common_L2", True)])
+@pytest.mark.parametrize("N,mode,odd", [(50, "mixture", False), (50, "individual_L2", True), (10, "common_max", False), (126, "common_L2", True),
+                                        (36, "mixture", False), (36, "individual_L2", True), (72, "common_L2", True), (76, "common_max", False)])
 def test_multi_env_fused_rollout_equals_single_steps(N, mode, odd):
     import mdr_amd
     E = _envs(N, odd)

@@ -44,7 +44,7 @@ def test_tables_by_runs_equal_tables_by_entry(signal, temp_mode, dt, E):
     for rounds in range(4):       # the first tables, then three refills further into the episode (incl. midnight for dt = 60)
         for off, small in smalls:
             for name in ("tab_od", "tab_solar", "tab_signal", "tab_abs_noise"):
-                assert torch.equal(small.t[name], big.t[name][:, off:off + 8]), (rounds, off, name)
+                assert torch.equal(small.table(name), big.table(name)[:, off:off + 8]), (rounds, off, name)
         big.rollout(65)
         for _, small in smalls:
             small.rollout(65)
