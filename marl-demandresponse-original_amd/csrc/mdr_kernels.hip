@@ -717,8 +717,11 @@ __global__ __launch_bounds__(256) void k_step_group(StepArgs a) {
   int lockout[VEC];
   float pen[VEC];
   Red3 acc{0.0, 0.0, 0.0f};
+  // (fetching the env's four table values by the group's first lane only and handing them round by shuffles was measured: no gain)
+  const float od_e = a.od_old[e], so_e = a.solar_new[e];
+  const double sg_old = a.sig_old[e], sg_new = a.sig_new[e];
   if (active) {
-    step_vec<VEC>(a, i, a.od_old[e], a.solar_new[e], o, lockout);
+    step_vec<VEC>(a, i, od_e, so_e, o, lockout);
     float p = 0.0f, ps = 0.0f;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
@@ -733,9 +736,9 @@ __global__ __launch_bounds__(256) void k_step_group(StepArgs a) {
   }
   const Red3 tot = lanes_reduce<GROUP>(acc);
   if (active) {
-    const float sig_term = signal_term(a, tot.sum_p, a.sig_old[e]);
+    const float sig_term = signal_term(a, tot.sum_p, sg_old);
     if (lane == 0) a.P[e] = tot.sum_p;
-    store_reward_power<VEC>(a, i, pen, tot.sum_pen, tot.max_pen, sig_term, (float)(a.sig_new[e] * a.inv_obs_norm),
+    store_reward_power<VEC>(a, i, pen, tot.sum_pen, tot.max_pen, sig_term, (float)(sg_new * a.inv_obs_norm),
                             (float)(tot.sum_p * a.inv_obs_norm));
   }
   cursor_done(a);
