@@ -47,10 +47,12 @@ typedef struct mdr_actor {
   int32_t greedy;      /* 0: action ~ Categorical(softmax) (PPOAgent.act, agents/rl_controllers.py:28-36); 1: action = argmax of the two
                           outputs (DQNAgent.act, rl_controllers.py:53-60: the same Linear/ReLU stack read as Q-values), no draw */
   int32_t feature_order; /* which input feature column k of W1 multiplies: 0 = MDR_FEATURES_NORMSTATE, normStateDict's own order
-                            (mdr_actor_sample); 1 = MDR_FEATURES_OBSERVE, the order mdr_env_actor_sample stages the default observation
-                            in - the 10 messages first (k = 4 m + field), then the 11 own features (k = 40 + i): W1's columns
-                            permuted with k -> normStateDict index (k < 40 ? 11 + k : k - 40) */
-  int32_t reserved0;
+                            (mdr_actor_sample); 1 = MDR_FEATURES_OBSERVE, the order mdr_env_actor_sample stages the observation
+                            in - the messages first (k = 4 m + field), then the own features in normStateDict order (k = M + i,
+                            M = observe_msg_floats): W1's columns permuted with k -> normStateDict index (k < M ? own + k : k - M),
+                            own = num_state - M */
+  int32_t observe_msg_floats; /* MDR_FEATURES_OBSERVE: M = 4 * nb_comm message floats lead the staged row (40 for the reference's
+                                 default 10 neighbours; 0 = no messages) */
   /* device, MFMA fragment order.  W1z / W2z / W3z: the weight matrices zero-padded to 128 rows / columns.
    * MDR_ACTOR_FRAG32 (S1 = ceil((F + 1) / 2), S2 = mdr_actor_steps2, r = lane & 31, h = lane >> 5) carries the biases as a
    * constant-1 input feature / hidden unit:  W1e = [[W1 b1] [0 1]],  W2e = [[W2 b2] [0 1]],  W3e = [W3 b3]:

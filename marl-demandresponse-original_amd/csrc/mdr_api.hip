@@ -1215,18 +1215,39 @@ int mdr_env_actor_sample(mdr_env_t* env, const mdr_obs_spec_t* spec, const mdr_a
   int rc = obs_args(env, spec, false, &a);
   if (rc == MDR_OK) rc = sync_cursor(env, (hipStream_t)stream);
   if (rc != MDR_OK) return rc;
-  // the reference's default observation only (utils.py:774-878 with every optional column off, 10 circular neighbours, no defects)
-  if (spec->state_hour || spec->state_day || spec->state_solar_gain || spec->state_thermal || spec->state_hvac || spec->message_thermal ||
-      spec->message_hvac || spec->nb_comm != 10 || spec->links != nullptr || spec->random_links || spec->comm_defect_prob > 0.0)
-    return fail(env, MDR_ERR_UNSUPPORTED, "observe -> act covers the default observation (51 features) only");
+  // circular neighbours with 4-field messages (utils.py:843-878 without the optional message columns); the optional STATE columns
+  // (774-830), any neighbour count and link defects (env 988-1002) take the extended kernels
+  if (spec->message_thermal || spec->message_hvac || spec->links != nullptr || spec->random_links)
+    return fail(env, MDR_ERR_UNSUPPORTED, "observe -> act covers circular neighbours with 4-field messages: link tables, random_sample and the optional message columns go through mdr_env_obs_vector + mdr_actor_sample");
   mdr::ObserveArgs o{};
   o.Ta = a.Ta; o.Tm = a.Tm; o.target = a.target; o.deadband = a.deadband; o.capacity = a.capacity; o.P_max = a.P_max;
   o.sso = a.sso; o.lockout = a.lockout; o.flags = a.flags; o.P = a.P; o.sig_now = a.sig_now;
   o.cursor = a.cursor; o.cursor_max = a.cursor_max;
   o.E = a.E; o.N = a.N;
   o.obs_tshift = a.obs_tshift; o.inv_norm_reg = a.inv_norm_reg; o.inv_cap = a.inv_cap; o.inv_obs_norm = a.inv_obs_norm;
+  const bool ext = spec->state_hour || spec->state_day || spec->state_solar_gain || spec->state_thermal || spec->state_hvac ||
+                   spec->nb_comm != 10 || spec->comm_defect_prob > 0.0;
+  if (ext) {
+    if (env->split_pending) return fail(env, MDR_ERR_INVALID, "step_begin without step_end");
+    o.ext = 1;
+    o.c = spec->nb_comm;
+    o.before = spec->nb_comm / 2;
+    o.f_hour = spec->state_hour != 0; o.f_day = spec->state_day != 0; o.f_solar = spec->state_solar_gain != 0;
+    o.f_thermal = spec->state_thermal != 0; o.f_hvac = spec->state_hvac != 0;
+    o.own = 11 + 2 * o.f_hour + 2 * o.f_day + o.f_solar + 5 * o.f_thermal + 2 * o.f_hvac;
+    o.Ua = a.Ua; o.Cm = a.Cm; o.Ca = a.Ca; o.Hm = a.Hm; o.COP = a.COP; o.latent = a.latent;
+    o.inv_Ua = a.inv_Ua; o.inv_Cm = a.inv_Cm; o.inv_Ca = a.inv_Ca; o.inv_Hm = a.inv_Hm; o.inv_COP = a.inv_COP; o.inv_latent = a.inv_latent;
+    // per-env columns: the handle's local-aggregate scratch (tot_sum [2][E], tot_max [E] doubles = 6 E floats), idle between the
+    // steps of an unsharded handle
+    o.env_extra_a = reinterpret_cast<float*>(env->buf.tot_sum);
+    o.env_extra_b = reinterpret_cast<float*>(env->buf.tot_max);
+    o.od_now = a.od_now; o.solar_now = a.solar_now; o.t0 = a.t0; o.k = a.k; o.dt = a.dt;
+    o.defect_prob = a.defect_prob;
+    o.env_offset = a.env_offset; o.house_offset = a.house_offset;
+    o.k0 = a.k0; o.k1 = a.k1; o.episode = a.episode;
+  }
   rc = mdr::launch_actor_observe(actor, o, seed, step, step_dev, action, a_prob, probs, rows_out, (hipStream_t)stream);
-  if (rc == MDR_ERR_UNSUPPORTED) return fail(env, rc, "observe -> act: shape or actor layout without a kernel (nb_houses >= 11, FRAG16 / BF16X3 in MDR_FEATURES_OBSERVE order)");
+  if (rc == MDR_ERR_UNSUPPORTED) return fail(env, rc, "observe -> act: shape or actor layout without a kernel (nb_houses > nb_comm <= 13, at most 64 features, FRAG16 / BF16X3 packed in MDR_FEATURES_OBSERVE order for this nb_comm)");
   if (rc != MDR_OK) return fail(env, rc, "actor_observe launch failed");
   return MDR_OK;
 }

@@ -165,6 +165,25 @@ struct ObserveArgs {
   int E, N;
   float obs_tshift, inv_norm_reg, inv_cap;
   double inv_obs_norm;
+  // The extended form (ext != 0): optional STATE columns (utils.py:774-830), any number of circular neighbours with 4-field
+  // messages, link defects (env 988-1002).  c neighbours: c / 2 before the house, c - c / 2 after (env 816-828); own = number of
+  // own normStateDict features (11 + 5 thermal + 2 hvac + 2 hour + 2 day + 1 solar); a row of the window is
+  // [4 c message floats | own features in normStateDict order | zeros up to 64 | L | 1 / L | pad] = OBS_ROW_EXT floats.
+  int ext, c, before, own;
+  int f_hour, f_day, f_solar, f_thermal, f_hvac;
+  const float *Ua, *Cm, *Ca, *Hm, *COP, *latent;       // raw per-house parameters (thermal / hvac columns)
+  float inv_Ua, inv_Cm, inv_Ca, inv_Hm, inv_COP, inv_latent;
+  // per-env columns, [6][E] floats written by k_observe_env_extras into the handle's tot_sum / tot_max scratch (unsharded handles
+  // do not use those between steps): (OD - 20) / 5, sin / cos of the day angle, sin / cos of the hour angle, solar gain / 1000
+  float* env_extra_a;        // [4][E]: OD, sin day, cos day, sin hour
+  float* env_extra_b;        // [2][E]: cos hour, solar
+  const float *od_now, *solar_now;
+  const int64_t* t0;
+  int64_t k;                 // time index (graph mode: cursor[1])
+  int dt;
+  float defect_prob;
+  int64_t env_offset, house_offset;
+  uint32_t k0, k1, episode;
 };
 
 // Persistent sharded rollout (mdr_persist.hip): the mailboxes of every rank, laid out in 8-byte granules as

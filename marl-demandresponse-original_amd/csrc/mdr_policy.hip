@@ -203,6 +203,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_actor_sample(ActorArgs a) {
 // [kb][reg] of layer 1: lane group g = lane >> 4 supplies row 16 kb + 4 g + reg - again no lane movement.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int WAVES16 = 16;
+constexpr int WAVES16_EXT = 12;   // the extended observe -> act form: three waves per SIMD (168 registers; the fp32 forms level off at three waves)
 
 // MDR_ACTOR_FRAG16T: the last of the MB blocks holds at most 4 hidden units (the reference's 100 = 6 x 16 + 4) and runs on
 // v_mfma_f32_4x4x1_16B_f32 instead - 16 independent 4x4 outer products, block = lane >> 2: D[v](lane) += A(lane (lane & ~3) + v) *
@@ -375,6 +376,7 @@ __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
 }
 
 constexpr int WAVESB = 8;    // 2 per SIMD: two column blocks of accumulators (~200 registers per lane)
+constexpr int WAVESB_EXT = 6; // the extended observe -> act form: its 68-float rows make a window 8.8 KB, six of them fit beside the 96 KB of weight fragments
 constexpr int NCB = 2;       // 16-agent column blocks per wavefront: every weight fragment read from LDS feeds NCB MFMAs (with one block
                              // the fragment reads, 84 KB per 16 agents, kept the LDS busier than the matrix pipe)
 
@@ -561,6 +563,10 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) 
 // are staged between the k-steps of layer 2, read back before the head, so one window per wave suffices.
 // =================================================================================================================
 constexpr int OBS_HALO = 5, OBS_C = 10, OBS_ROW = 56, OBS_PAD = 16;   // floats; 56 = 40 + 11 + L + 1/L + 3 (16-byte rows)
+// The extended form (ObserveArgs.ext; template parameter EXT): optional state columns, c != 10 circular neighbours, link defects.
+// A row is [4 c message floats | own features in normStateDict order | zeros up to 64 | L | 1 / L | pad]: feature k of a row is
+// normStateDict index (k < 4 c ? own + k : k - 4 c), the packed weights follow (mdr_actor_t.feature_order = 1), F = 4 c + own <= 64.
+constexpr int OBS_ROW_EXT = 68, OBS_L_EXT = 64, OBS_MAX_C = 13;
 typedef float v4f_nt __attribute__((ext_vector_type(4)));
 
 // between a wave's window stores and its loads of what OTHER lanes stored
@@ -574,6 +580,8 @@ struct HouseRegs {
   int sso, lk;
   unsigned fl;
   float sig, pw;
+  float Ua, Cm, Ca, Hm, COP, latent;   // EXT: raw parameters of the thermal / hvac columns (already scaled by 1 / default)
+  int e;                               // EXT: the house's env (its per-env columns are fetched when the row is staged)
 };
 
 __device__ __forceinline__ const double* observe_sig_row(const mdr::ObserveArgs& o) {
@@ -634,9 +642,10 @@ struct SegSlot {
   bool live;
 };
 
-template <int TILE>
+template <int TILE, bool EXT = false>
 __device__ __forceinline__ HouseRegs observe_load_gen(const mdr::ObserveArgs& o, const double* sig_row, int e0, int h0, int64_t a0, int64_t A,
                                                       int lane, SegSlot& slot) {
+  const int before = EXT ? o.before : OBS_HALO, c = EXT ? o.c : 2 * OBS_HALO;   // senders before the house / in all (env 816-828)
   HouseRegs r{};
   slot = SegSlot{0, 0, 0, 0, false};
   // the segment walk is wave-uniform: keep it on the scalar unit (the tile index comes out of threadIdx, which the compiler
@@ -646,9 +655,9 @@ __device__ __forceinline__ HouseRegs observe_load_gen(const mdr::ObserveArgs& o,
 #pragma unroll 1
   while (rem > 0) {                          // at most 4 segments
     const int len = min(o.N - hs, rem);
-    const bool whole = len + 2 * OBS_HALO >= o.N;
-    const int start = whole ? 0 : (hs - OBS_HALO + o.N) % o.N;
-    const int wlen = whole ? o.N : len + 2 * OBS_HALO;
+    const bool whole = len + c >= o.N;
+    const int start = whole ? 0 : (hs - before + o.N) % o.N;
+    const int wlen = whole ? o.N : len + c;
     if (lane >= wb && lane < wb + wlen) {
       int j = start + (lane - wb);
       j -= j >= o.N ? o.N : 0;
@@ -674,23 +683,82 @@ __device__ __forceinline__ HouseRegs observe_load_gen(const mdr::ObserveArgs& o,
     r.fl = o.flags[i];
     r.sig = (float)(sig_row[my_e] * o.inv_obs_norm);
     r.pw = (float)(o.P[my_e] * o.inv_obs_norm);
+    if (EXT) {
+      r.e = my_e;
+      if (o.f_thermal) {
+        r.Ua = o.Ua[i] * o.inv_Ua;
+        r.Cm = o.Cm[i] * o.inv_Cm;
+        r.Ca = o.Ca[i] * o.inv_Ca;
+        r.Hm = o.Hm[i] * o.inv_Hm;
+      }
+      if (o.f_hvac) {
+        r.COP = o.COP[i] * o.inv_COP;
+        r.latent = o.latent[i] * o.inv_latent;
+      }
+    }
   }
   return r;
 }
 
+template <bool EXT = false>
 __device__ __forceinline__ void observe_stage_gen(const mdr::ObserveArgs& o, const HouseRegs& r, const SegSlot& slot, float* rows) {
   if (!slot.live) return;
+  constexpr int ROW = EXT ? OBS_ROW_EXT : OBS_ROW;
+  const int before = EXT ? o.before : OBS_HALO, c = EXT ? o.c : OBS_C;
   const float4 rec = make_float4((r.Ta - r.tg) * 0.2f, (float)r.sso, ((r.fl & 1u) ? r.pm : 0.0f) * o.inv_norm_reg, r.pm * o.inv_norm_reg);
 #pragma unroll
-  for (int m = 0; m < OBS_C; ++m) {
-    const int off = m < OBS_HALO ? m - OBS_HALO : m - OBS_HALO + 1;   // slot m listens to house h + off (env 816-828)
-    int h = slot.j - off;                                            // ... so this house is slot m of house j - off
+  for (int m = 0; m < (EXT ? OBS_MAX_C : OBS_C); ++m) {
+    if (EXT && m >= c) break;
+    const int off = m < before ? m - before : m - before + 1;   // slot m listens to house h + off (env 816-828)
+    int h = slot.j - off;                                      // ... so this house is slot m of house j - off
     h += h < 0 ? o.N : 0;
     h -= h >= o.N ? o.N : 0;
     const int k = h - slot.hs;
-    if (k >= 0 && k < slot.len) *reinterpret_cast<float4*>(rows + (slot.rb + k) * OBS_ROW + 4 * m) = rec;
+    if (k >= 0 && k < slot.len) *reinterpret_cast<float4*>(rows + (slot.rb + k) * ROW + 4 * m) = rec;
   }
   const int k = slot.j - slot.hs;
+  if (EXT) {
+    if (k >= 0 && k < slot.len) {   // the own features in normStateDict order (obs_features() in mdr_kernels.hip), optional ones where they belong
+      const float L = (float)r.lk;
+      float* row = rows + (slot.rb + k) * ROW;
+      float* own = row + 4 * c;
+      int j = 0;
+      own[j++] = (r.Ta + o.obs_tshift) * 0.2f;
+      own[j++] = (r.Tm + o.obs_tshift) * 0.2f;
+      own[j++] = (r.tg + o.obs_tshift) * 0.2f;
+      if (o.f_thermal) own[j++] = o.env_extra_a[r.e];
+      own[j++] = r.db;
+      if (o.f_day) {
+        own[j++] = o.env_extra_a[(int64_t)o.E + r.e];
+        own[j++] = o.env_extra_a[2 * (int64_t)o.E + r.e];
+      }
+      if (o.f_hour) {
+        own[j++] = o.env_extra_a[3 * (int64_t)o.E + r.e];
+        own[j++] = o.env_extra_b[r.e];
+      }
+      if (o.f_solar) own[j++] = o.env_extra_b[(int64_t)o.E + r.e];
+      own[j++] = r.cap * o.inv_cap;
+      if (o.f_thermal) {
+        own[j++] = r.Ua;
+        own[j++] = r.Cm;
+        own[j++] = r.Ca;
+        own[j++] = r.Hm;
+      }
+      if (o.f_hvac) {
+        own[j++] = r.COP;
+        own[j++] = r.latent;
+      }
+      own[j++] = (r.fl & 1u) ? 1.0f : 0.0f;
+      own[j++] = (r.fl & 2u) ? 1.0f : 0.0f;
+      own[j++] = (float)r.sso / L;
+      own[j++] = L / L;
+      own[j++] = r.sig;
+      own[j++] = r.pw;
+      row[OBS_L_EXT] = L;
+      row[OBS_L_EXT + 1] = 1.0f / L;
+    }
+    return;
+  }
   if (k >= 0 && k < slot.len) {
     const float L = (float)r.lk;
     float* own = rows + (slot.rb + k) * OBS_ROW + 4 * OBS_C;
@@ -699,6 +767,52 @@ __device__ __forceinline__ void observe_stage_gen(const mdr::ObserveArgs& o, con
     *reinterpret_cast<float4*>(own + 8) = make_float4(L / L, r.sig, r.pw, L);
     own[12] = 1.0f / L;
   }
+}
+
+// Link defects (env 988-1002; the draws of k_obs_* in mdr_kernels.hip: Philox stream TAG_COMM, counter (env, house, time index,
+// block of four slots), a link delivers iff (float)u > comm_defect_prob): lane group g draws block g of ITS agent and zeroes the
+// dead message records in the agent's staged row - the all-zero message(empty=True) of the reference.
+__device__ __forceinline__ void observe_apply_defects(const mdr::ObserveArgs& o, float* row, int64_t agent, int g, int64_t A) {
+  if (!(o.defect_prob > 0.0f) || 4 * g >= o.c || agent >= A) return;
+  const uint32_t ag = (uint32_t)agent, e = ag / (uint32_t)o.N, h = ag - e * (uint32_t)o.N;   // (the launcher keeps A below 2^31 here)
+  const uint32_t k = o.cursor ? (uint32_t)o.cursor[1] : (uint32_t)o.k;
+  const u32x4 rnd = philox4x32_10(e + (uint32_t)o.env_offset, h + (uint32_t)o.house_offset, k, mdr::TAG_COMM | ((uint32_t)g << 8), o.k0,
+                                  o.k1 ^ (o.episode * 0x85EBCA6Bu));
+  const uint32_t x[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = 4 * g + j;
+    if (m < o.c && !((float)mdr::u01(x[j]) > o.defect_prob)) *reinterpret_cast<float4*>(row + 4 * m) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+}
+
+// The per-env observation columns of the extended form, once per env and step (obs_features() evaluates them per house):
+// (OD - 20) / 5 (utils.py:803-805), sin / cos of tm_yday 2 pi / 365 (806-809) and of the integer hour 2 pi / 24 (810-813),
+// solar gain / 1000 (0 until the first step, env 573) -> env_extra_a [4][E] | env_extra_b [2][E].
+__global__ __launch_bounds__(256) void k_observe_env_extras(mdr::ObserveArgs o) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= o.E) return;
+  int64_t off = 0, k = o.k;
+  if (o.cursor != nullptr) {
+    off = (int64_t)min(o.cursor[0], o.cursor_max + 1) * o.E;
+    k = o.cursor[1];
+  }
+  const int64_t E = o.E;
+  if (o.f_thermal) o.env_extra_a[e] = (o.od_now[off + e] + o.obs_tshift) * 0.2f;
+  if (o.f_day || o.f_hour) {
+    const mdr::Civil c = mdr::civil_from_epoch(o.t0[e] + k * (int64_t)o.dt);
+    if (o.f_day) {
+      const double ang = (double)c.yday * 6.283185307179586476925286766559 / 365.0;
+      o.env_extra_a[E + e] = (float)sin(ang);
+      o.env_extra_a[2 * E + e] = (float)cos(ang);
+    }
+    if (o.f_hour) {
+      const double ang = (double)c.hour * 6.283185307179586476925286766559 / 24.0;
+      o.env_extra_a[3 * E + e] = (float)sin(ang);
+      o.env_extra_b[e] = (float)cos(ang);
+    }
+  }
+  if (o.f_solar) o.env_extra_b[E + e] = k > 0 ? o.solar_now[off + e] * 1e-3f : 0.0f;
 }
 
 // Optional side product of observe -> act: the tile's observation rows, in normStateDict order, for the transition buffer
@@ -713,17 +827,26 @@ __device__ __forceinline__ void observe_build_table(uint16_t* table, int tid, in
     table[o] = (uint16_t)(OBS_ROW * r + (n < 11 ? 4 * OBS_C + n : n - 11));
   }
 }
-
 template <int TILE>
-__device__ __forceinline__ void observe_store_rows(const float* rows, const uint16_t* table, float* out_tile, int lane_in, int nrows = TILE) {
-  constexpr int QUADS = TILE * 51 / 4;   // 408 | 204
+__device__ __forceinline__ void observe_build_table_ext(uint16_t* table, int tid, int nthreads, int own, int c) {
+  const int F = own + 4 * c;
+  for (int o = tid; o < TILE * F; o += nthreads) {
+    const int r = o / F, n = o - F * r;
+    table[o] = (uint16_t)(OBS_ROW_EXT * r + (n < own ? 4 * c + n : n - own));
+  }
+}
+
+template <int TILE, bool EXT = false>
+__device__ __forceinline__ void observe_store_rows(const float* rows, const uint16_t* table, float* out_tile, int lane_in, int nrows = TILE, int F = 51) {
+  constexpr int QUADS = TILE * (EXT ? 64 : 51) / 4;   // 408 | 204 (EXT: the bound for F = 64)
   const int lane = tile_local(lane_in);
-  if (((uintptr_t)out_tile & 15u) != 0) {   // a transition buffer whose per-step slice is not 16-byte aligned (A * 51 % 4 != 0): 4-byte stores
-    for (int i = lane; i < nrows * 51; i += 64) __builtin_nontemporal_store(rows[table[i]], out_tile + i);
+  if (!EXT) F = 51;
+  if (((uintptr_t)out_tile & 15u) != 0) {   // a transition buffer whose per-step slice is not 16-byte aligned (A * F % 4 != 0): 4-byte stores
+    for (int i = lane; i < nrows * F; i += 64) __builtin_nontemporal_store(rows[table[i]], out_tile + i);
     return;
   }
-  const int quads = nrows * 51 / 4;      // the last tile of a batch may hold fewer agents (51 nrows need not be a multiple of 4)
-  if (lane < nrows * 51 - 4 * quads) out_tile[4 * quads + lane] = rows[table[4 * quads + lane]];
+  const int quads = nrows * F / 4;      // the last tile of a batch may hold fewer agents (F nrows need not be a multiple of 4)
+  if (lane < nrows * F - 4 * quads) out_tile[4 * quads + lane] = rows[table[4 * quads + lane]];
 #pragma unroll
   for (int i = 0; i < (QUADS + 63) / 64; ++i) {
     const int q = i * 64 + lane;
@@ -756,30 +879,37 @@ struct TileCursor {
 };
 
 // ---- bf16x3 form: 32 agents per wavefront (two 16-agent column blocks), k-step s of layer 1 = row floats [32 s + 8 g, + 8)
-template <int MB, bool STORE, bool GEN>
-__global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a, mdr::ObserveArgs o) {
+template <int MB, bool STORE, bool GEN, bool EXT = false>
+__global__ __launch_bounds__(64 * (EXT ? WAVESB_EXT : WAVESB)) void k_actor_observe_bf16(ActorArgs a, mdr::ObserveArgs o) {
+  constexpr int NW = EXT ? WAVESB_EXT : WAVESB;   // waves per workgroup
+  static_assert(!EXT || GEN, "the extended form stages through the general windows");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int S2B = (MB + 1) / 2, TILE = 16 * NCB, WIN = TILE * OBS_ROW + OBS_PAD;
+  constexpr int S2B = (MB + 1) / 2, TILE = 16 * NCB, ROW = EXT ? OBS_ROW_EXT : OBS_ROW, WIN = TILE * ROW + OBS_PAD;
+  const int F = EXT ? o.own + 4 * o.c : 51;
   uint4* f1 = reinterpret_cast<uint4*>(lds);                    // [2][8][2][64] fragments of 8 bf16
-  uint4* f2 = f1 + 2 * 1024;                                    // [S2B][8][2][64]
+  const int S1B = EXT ? a.S1 : 2;                               // k-steps of layer 1: 32 features each (the extended form: one for F <= 32)
+  uint4* f2 = f1 + S1B * 1024;                                  // [S2B][8][2][64]
   float* wd = reinterpret_cast<float*>(f2 + S2B * 1024);        // head weights + biases (512 floats reserved)
   const int tid = threadIdx.x;
   float* rows = wd + 512 + (tid >> 6) * WIN;                    // this wave's window
-  uint16_t* table = reinterpret_cast<uint16_t*>(wd + 512 + WAVESB * WIN);   // [TILE * 51] (only when rows are stored)
+  uint16_t* table = reinterpret_cast<uint16_t*>(wd + 512 + NW * WIN);   // [TILE * 51] (only when rows are stored)
   const uint4* g1 = reinterpret_cast<const uint4*>(a.frag1);
   const uint4* g2 = reinterpret_cast<const uint4*>(a.frag2);
-  for (int i = tid; i < 2 * 1024; i += 64 * WAVESB) f1[i] = g1[i];
-  for (int i = tid; i < S2B * 1024; i += 64 * WAVESB) f2[i] = g2[i];
-  if (tid < 388) wd[tid] = a.wdiff[tid];
+  for (int i = tid; i < S1B * 1024; i += 64 * NW) f1[i] = g1[i];
+  for (int i = tid; i < S2B * 1024; i += 64 * NW) f2[i] = g2[i];
+  for (int i = tid; i < 388; i += 64 * NW) wd[i] = a.wdiff[i];   // (a workgroup of the extended bf16 form has 384 threads)
   const int lane = tid & 63;
   for (int i = lane; i < WIN; i += 64) rows[i] = 0.0f;          // pads are read (against zero weights): they must be finite
   constexpr bool store = STORE;   // rows_out != nullptr (a compile-time variant: the plain form keeps its registers)
-  if (store) observe_build_table<TILE>(table, tid, 64 * WAVESB);
+  if (store) {
+    if (EXT) observe_build_table_ext<TILE>(table, tid, 64 * NW, o.own, o.c);
+    else observe_build_table<TILE>(table, tid, 64 * NW);
+  }
   __syncthreads();
 
   const int r = lane & 15, g = lane >> 4;
-  const int wave = blockIdx.x * WAVESB + (tid >> 6);   // tile indices fit 32 bits (the launcher checks): one register each, not two
-  const int nwaves = gridDim.x * WAVESB;
+  const int wave = blockIdx.x * NW + (tid >> 6);   // tile indices fit 32 bits (the launcher checks): one register each, not two
+  const int nwaves = gridDim.x * NW;
   const f32x4* bias1 = reinterpret_cast<const f32x4*>(wd + 128) + g;
   const f32x4* bias2 = reinterpret_cast<const f32x4*>(wd + 256) + g;
   const float bias3 = wd[384];
@@ -790,40 +920,46 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
   // the lane's 16 features of column block c: two runs of 8 floats of row c * 16 + r.  `first_agent`: the tile's first agent -
   // with `store`, the quotients go back into the window and the wave copies the tile's rows out (observe_store_rows)
   auto gather = [&](int64_t first_agent) {
+    if (EXT && o.defect_prob > 0.0f) {   // dead links first: the runs below then read zeros
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) observe_apply_defects(o, rows + (c * 16 + r) * ROW, first_agent + c * 16 + r, g, a.A);
+      observe_window_fence();
+    }
 #pragma unroll
     for (int c = 0; c < NCB; ++c) {
-      float* row = rows + (c * 16 + r) * OBS_ROW;
-      const float L = row[4 * OBS_C + 11], y = row[4 * OBS_C + 12];
+      float* row = rows + (c * 16 + r) * ROW;
+      const float L = row[EXT ? OBS_L_EXT : 4 * OBS_C + 11], y = row[EXT ? OBS_L_EXT + 1 : 4 * OBS_C + 12];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const float4 v0 = *reinterpret_cast<const float4*>(row + 32 * s + 8 * g);
         const float4 v1 = *reinterpret_cast<const float4*>(row + 32 * s + 8 * g + 4);
-        const bool msg = (s == 0) || (g == 0);   // this run holds two message records: their second field is seconds_since_off
+        // message records (their second field is the sender's seconds_since_off): the default shape's 40 message floats are the
+        // runs s == 0 and (s == 1, g == 0); the extended form asks per four-float record
+        const bool msg = (s == 0) || (g == 0);
+        const bool msg_a = EXT ? (32 * s + 8 * g + 4 <= 4 * o.c) : msg, msg_b = EXT ? (32 * s + 8 * g + 8 <= 4 * o.c) : msg;
         xr[c][8 * s + 0] = v0.x;
-        xr[c][8 * s + 1] = msg ? mdr::div_by_lockout(v0.y, L, y) : v0.y;
+        xr[c][8 * s + 1] = msg_a ? mdr::div_by_lockout(v0.y, L, y) : v0.y;
         xr[c][8 * s + 2] = v0.z;
         xr[c][8 * s + 3] = v0.w;
         xr[c][8 * s + 4] = v1.x;
-        xr[c][8 * s + 5] = msg ? mdr::div_by_lockout(v1.y, L, y) : v1.y;
+        xr[c][8 * s + 5] = msg_b ? mdr::div_by_lockout(v1.y, L, y) : v1.y;
         xr[c][8 * s + 6] = v1.z;
         xr[c][8 * s + 7] = v1.w;
-        if (store && msg) {
-          row[32 * s + 8 * g + 1] = xr[c][8 * s + 1];
-          row[32 * s + 8 * g + 5] = xr[c][8 * s + 5];
-        }
+        if (store && msg_a) row[32 * s + 8 * g + 1] = xr[c][8 * s + 1];
+        if (store && msg_b) row[32 * s + 8 * g + 5] = xr[c][8 * s + 5];
       }
     }
     if (store) {
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      observe_store_rows<TILE>(rows, table, a.rows_out + first_agent * 51, lane,
-                               GEN ? (int)((a.A - first_agent) < (int64_t)TILE ? (a.A - first_agent) : (int64_t)TILE) : TILE);
+      observe_store_rows<TILE, EXT>(rows, table, a.rows_out + first_agent * F, lane,
+                                    GEN ? (int)((a.A - first_agent) < (int64_t)TILE ? (a.A - first_agent) : (int64_t)TILE) : TILE, F);
     }
   };
   SegSlot slot{};
   if (wave < a.ntiles) {
     if (GEN) {
-      const HouseRegs first = observe_load_gen<TILE>(o, sig_row, tc.e, tc.h0, (int64_t)wave * TILE, a.A, lane, slot);
-      observe_stage_gen(o, first, slot, rows);
+      const HouseRegs first = observe_load_gen<TILE, EXT>(o, sig_row, tc.e, tc.h0, (int64_t)wave * TILE, a.A, lane, slot);
+      observe_stage_gen<EXT>(o, first, slot, rows);
     } else {
       const HouseRegs first = observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
       observe_stage<TILE>(o, first, rows, lane);
@@ -847,7 +983,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
     const bool more = t + nwaves < ntiles;
     tc.next();
     HouseRegs nxt{};
-    if (more) nxt = GEN ? observe_load_gen<TILE>(o, sig_row, tc.e, tc.h0, (int64_t)(t + nwaves) * TILE, a.A, lane, slot) : observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
+    if (more) nxt = GEN ? observe_load_gen<TILE, EXT>(o, sig_row, tc.e, tc.h0, (int64_t)(t + nwaves) * TILE, a.A, lane, slot) : observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
     f32x4 acc[NCB][MB];
 #pragma unroll
     for (int c = 0; c < NCB; ++c)
@@ -856,6 +992,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
     // ---- layer 1 (F = 51: both k-steps)
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
+      if (EXT && s >= S1B) continue;
       bf16x8 Bh[NCB], Bl[NCB];
 #pragma unroll
       for (int c = 0; c < NCB; ++c) {
@@ -885,7 +1022,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
 #pragma unroll
     for (int s = 0; s < S2B; ++s) {
       if (s == 1 && more) {
-        if (GEN) observe_stage_gen(o, nxt, slot, rows);
+        if (GEN) observe_stage_gen<EXT>(o, nxt, slot, rows);
         else observe_stage<TILE>(o, nxt, rows, lane);
       }
       bf16x8 Bh[NCB], Bl[NCB];
@@ -947,28 +1084,34 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
 }
 
 // ---- exact-fp32 form (v_mfma_f32_16x16x4_f32): 16 agents per wavefront, lane group g holds features [13 g, 13 g + 13) of its agent
-template <int MB, bool STORE, bool GEN, bool TAIL>
-__global__ __launch_bounds__(64 * WAVES16) void k_actor_observe16(ActorArgs a, mdr::ObserveArgs o) {
+template <int MB, bool STORE, bool GEN, bool TAIL, bool EXT = false>
+__global__ __launch_bounds__(64 * (EXT ? WAVES16_EXT : WAVES16)) void k_actor_observe16(ActorArgs a, mdr::ObserveArgs o) {
+  constexpr int NW = EXT ? WAVES16_EXT : WAVES16;   // waves per workgroup
+  static_assert(!EXT || GEN, "the extended form stages through the general windows");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int TILE = 16, WIN = TILE * OBS_ROW + OBS_PAD, S1 = 13;
+  constexpr int TILE = 16, ROW = EXT ? OBS_ROW_EXT : OBS_ROW, WIN = TILE * ROW + OBS_PAD;
+  const int S1 = EXT ? a.S1 : 13, F = EXT ? o.own + 4 * o.c : 51;   // lane group g holds features [S1 g, S1 g + S1) of its agent
   float* f1 = lds;                       // [13][64][8]
   float* f2 = f1 + S1 * 512;             // [S2][64][8]
   float* wd = f2 + a.S2 * 512;           // head weights + biases (512 floats reserved)
   const int tid = threadIdx.x;
   float* rows = wd + 512 + (tid >> 6) * WIN;
-  uint16_t* table = reinterpret_cast<uint16_t*>(wd + 512 + WAVES16 * WIN);   // [TILE * 51] (only when rows are stored)
-  for (int i = tid * 4; i < S1 * 512; i += 64 * WAVES16 * 4) *reinterpret_cast<float4*>(f1 + i) = *reinterpret_cast<const float4*>(a.frag1 + i);
-  for (int i = tid * 4; i < a.S2 * 512; i += 64 * WAVES16 * 4) *reinterpret_cast<float4*>(f2 + i) = *reinterpret_cast<const float4*>(a.frag2 + i);
-  if (tid < 388) wd[tid] = a.wdiff[tid];
+  uint16_t* table = reinterpret_cast<uint16_t*>(wd + 512 + NW * WIN);   // [TILE * 51] (only when rows are stored)
+  for (int i = tid * 4; i < S1 * 512; i += 64 * NW * 4) *reinterpret_cast<float4*>(f1 + i) = *reinterpret_cast<const float4*>(a.frag1 + i);
+  for (int i = tid * 4; i < a.S2 * 512; i += 64 * NW * 4) *reinterpret_cast<float4*>(f2 + i) = *reinterpret_cast<const float4*>(a.frag2 + i);
+  for (int i = tid; i < 388; i += 64 * NW) wd[i] = a.wdiff[i];   // (a workgroup of the extended bf16 form has 384 threads)
   const int lane = tid & 63;
   for (int i = lane; i < WIN; i += 64) rows[i] = 0.0f;
   constexpr bool store = STORE;   // rows_out != nullptr (a compile-time variant: the plain form keeps its registers)
-  if (store) observe_build_table<TILE>(table, tid, 64 * WAVES16);
+  if (store) {
+    if (EXT) observe_build_table_ext<TILE>(table, tid, 64 * NW, o.own, o.c);
+    else observe_build_table<TILE>(table, tid, 64 * NW);
+  }
   __syncthreads();
 
   const int r = lane & 15, g = lane >> 4;
-  const int64_t wave = (int64_t)blockIdx.x * WAVES16 + (tid >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * WAVES16;
+  const int64_t wave = (int64_t)blockIdx.x * NW + (tid >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * NW;
   const f32x4* bias1 = reinterpret_cast<const f32x4*>(wd + 128) + g;
   const f32x4* bias2 = reinterpret_cast<const f32x4*>(wd + 256) + g;
   const float bias3 = wd[384];
@@ -977,28 +1120,33 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_observe16(ActorArgs a, m
   tc.init(wave * TILE, nwaves * TILE, o.N);
   float xr[16];
   auto gather = [&](int64_t first_agent) {
-    float* row = rows + r * OBS_ROW;
-    const float L = row[4 * OBS_C + 11], y = row[4 * OBS_C + 12];
+    float* row = rows + r * ROW;
+    const float L = row[EXT ? OBS_L_EXT : 4 * OBS_C + 11], y = row[EXT ? OBS_L_EXT + 1 : 4 * OBS_C + 12];
     // the senders' seconds_since_off (float 1 of every message record) become quotients by the RECEIVER's lockout, in place: lane
     // group g takes the messages g, g + 4 and g + 8 of its agent's row - three sites instead of a test on each of the 13 features
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < (EXT ? 4 : 3); ++i) {
       const int m = g + 4 * i;
-      if (m < OBS_C) row[4 * m + 1] = mdr::div_by_lockout(row[4 * m + 1], L, y);
+      if (m < (EXT ? o.c : OBS_C)) row[4 * m + 1] = mdr::div_by_lockout(row[4 * m + 1], L, y);
+    }
+    if (EXT && o.defect_prob > 0.0f) {   // after the quotients (LDS operations of a wave complete in issue order): a dead record is all zeros
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      observe_apply_defects(o, row, first_agent + r, g, a.A);
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 #pragma unroll
-    for (int s = 0; s < S1; ++s) xr[s] = row[S1 * g + s];
+    for (int s = 0; s < (EXT ? 16 : 13); ++s)
+      if (!EXT || s < S1) xr[s] = row[S1 * g + s];
     if (store) {
-      observe_store_rows<TILE>(rows, table, a.rows_out + first_agent * 51, lane,
-                               GEN ? (int)((a.A - first_agent) < (int64_t)TILE ? (a.A - first_agent) : (int64_t)TILE) : TILE);
+      observe_store_rows<TILE, EXT>(rows, table, a.rows_out + first_agent * F, lane,
+                                    GEN ? (int)((a.A - first_agent) < (int64_t)TILE ? (a.A - first_agent) : (int64_t)TILE) : TILE, F);
     }
   };
   SegSlot slot{};
   if (wave < a.ntiles) {
     if (GEN) {
-      const HouseRegs first = observe_load_gen<TILE>(o, sig_row, tc.e, tc.h0, wave * TILE, a.A, lane, slot);
-      observe_stage_gen(o, first, slot, rows);
+      const HouseRegs first = observe_load_gen<TILE, EXT>(o, sig_row, tc.e, tc.h0, wave * TILE, a.A, lane, slot);
+      observe_stage_gen<EXT>(o, first, slot, rows);
     } else {
       const HouseRegs first = observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
       observe_stage<TILE>(o, first, rows, lane);
@@ -1018,13 +1166,14 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_observe16(ActorArgs a, m
     const bool more = t + nwaves < a.ntiles;
     tc.next();
     HouseRegs nxt{};
-    if (more) nxt = GEN ? observe_load_gen<TILE>(o, sig_row, tc.e, tc.h0, (t + nwaves) * TILE, a.A, lane, slot) : observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
+    if (more) nxt = GEN ? observe_load_gen<TILE, EXT>(o, sig_row, tc.e, tc.h0, (t + nwaves) * TILE, a.A, lane, slot) : observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
     f32x4 acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[mb] = bias1[mb * 4];
     // ---- layer 1
 #pragma unroll
-    for (int s = 0; s < S1; ++s) {
+    for (int s = 0; s < (EXT ? 16 : 13); ++s) {
+      if (EXT && s >= S1) continue;
       const float4 w0 = *reinterpret_cast<const float4*>(f1 + s * 512 + lane * 8);
       const float4 w1 = *reinterpret_cast<const float4*>(f1 + s * 512 + lane * 8 + 4);
       const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
@@ -1039,7 +1188,7 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_observe16(ActorArgs a, m
 #pragma unroll
     for (int q = 0; q < 4 * MB; ++q) {
       if (q == 8 && more) {
-        if (GEN) observe_stage_gen(o, nxt, slot, rows);
+        if (GEN) observe_stage_gen<EXT>(o, nxt, slot, rows);
         else observe_stage<TILE>(o, nxt, rows, lane);
       }
       if (q < a.S2) {
@@ -1135,6 +1284,26 @@ bool tail_shape_ok(const mdr_actor_t* actor) {
 
 namespace mdr {
 
+// Lanes the general staging needs for a tile of `tile` agents (c senders per house, N houses per env): a tile is cut into per-env
+// segments, each staging its houses plus the c around them - or the whole env when that wraps onto itself; worst case over the tile
+// starts (the pattern repeats with the env).
+static int observe_window_lanes(int N, int c, int tile) {
+  int worst = 0;
+  const int starts = N < 4096 ? N : 1;   // big envs: at most two segments, tile + 2 c lanes
+  for (int h0 = 0; h0 < starts; ++h0) {
+    int lanes = 0, hs = h0, rem = tile;
+    while (rem > 0) {
+      const int len = N - hs < rem ? N - hs : rem;
+      lanes += len + c >= N ? N : len + c;
+      rem -= len;
+      hs = 0;
+    }
+    if (lanes > worst) worst = lanes;
+  }
+  if (N >= 4096) worst = tile + 2 * c;
+  return worst;
+}
+
 int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_t seed, uint64_t step, const int32_t* step_dev, uint8_t* action,
                          float* a_prob, float* probs, float* rows_out, hipStream_t stream) {
   if (!actor || actor->struct_size != sizeof(mdr_actor_t) || !action) return MDR_ERR_INVALID;
@@ -1142,13 +1311,17 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
   const int layout = actor->layout;
   if (layout != MDR_ACTOR_FRAG16 && layout != MDR_ACTOR_BF16X3 && layout != MDR_ACTOR_FRAG16T) return MDR_ERR_UNSUPPORTED;
   if (layout == MDR_ACTOR_FRAG16T && !tail_shape_ok(actor)) return MDR_ERR_UNSUPPORTED;
-  if (actor->feature_order != 1 || actor->num_state != 4 * OBS_C + 11) return MDR_ERR_UNSUPPORTED;
+  const bool ext = o.ext != 0;
+  const int c = ext ? o.c : OBS_C, own = ext ? o.own : 11, F = 4 * c + own;
+  if (actor->feature_order != 1 || actor->num_state != F || actor->observe_msg_floats != 4 * c) return MDR_ERR_UNSUPPORTED;
+  if (F > 64 || c > OBS_MAX_C || c < 0) return MDR_ERR_UNSUPPORTED;
   if (actor->hidden1 <= 0 || actor->hidden2 <= 0 || actor->hidden1 > MDR_ACTOR_MAX_HIDDEN || actor->hidden2 > MDR_ACTOR_MAX_HIDDEN) return MDR_ERR_INVALID;
   const bool lbf = layout == MDR_ACTOR_BF16X3;
-  const int tile = lbf ? 16 * NCB : 16, waves = lbf ? WAVESB : WAVES16;
-  if (o.N < OBS_C + 1) return MDR_ERR_UNSUPPORTED;   // 10 distinct circular neighbours
+  const int tile = lbf ? 16 * NCB : 16, waves = lbf ? (ext ? WAVESB_EXT : WAVESB) : (ext ? WAVES16_EXT : WAVES16);
+  if (o.N < c + 1) return MDR_ERR_UNSUPPORTED;   // c distinct circular neighbours
   static const bool force_gen = [] { const char* t = getenv("MDR_OBSERVE_GEN"); return t && t[0] == '1'; }();   // experiment knob
-  const bool gen = o.N % 32 != 0 || force_gen;     // tiles that start anywhere in an env / span several: the general staging
+  const bool gen = ext || o.N % 32 != 0 || force_gen;     // tiles that start anywhere in an env / span several: the general staging
+  if (gen && observe_window_lanes(o.N, c, tile) > 64) return MDR_ERR_UNSUPPORTED;
   ActorArgs a{};
   a.frag1 = static_cast<const float*>(actor->frag1); a.frag2 = static_cast<const float*>(actor->frag2); a.wdiff = actor->wdiff;
   a.action = action; a.a_prob = a_prob; a.probs = probs;
@@ -1157,15 +1330,20 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
   a.A = (int64_t)o.E * o.N;
   a.ntiles = (a.A + tile - 1) / tile;
   if (a.ntiles > 0x7FFFFFFF) return MDR_ERR_UNSUPPORTED;   // the kernels count tiles in 32 bits
+  if (ext && o.defect_prob > 0.0f && a.A > 0x7FFFFFFF) return MDR_ERR_UNSUPPORTED;   // the defect draws take (env, house) from a 32-bit agent index
   a.F = actor->num_state; a.S1 = steps1(layout, actor->num_state); a.S2 = steps2(layout, actor->hidden1);
   a.k0 = (uint32_t)(seed & 0xFFFFFFFFull); a.k1 = (uint32_t)(seed >> 32);
   a.step_lo = (uint32_t)(step & 0xFFFFFFFFull); a.step_hi = (uint32_t)(step >> 32);
   a.step_dev = step_dev;
   a.greedy = actor->greedy != 0;
-  const size_t window = (size_t)tile * OBS_ROW + OBS_PAD;
+  const size_t window = (size_t)tile * (ext ? OBS_ROW_EXT : OBS_ROW) + OBS_PAD;
   const size_t lds_bytes = ((size_t)(a.S1 + a.S2) * floats_per_step(layout) + 512 + (size_t)waves * window) * sizeof(float) +
-                           (rows_out ? (size_t)tile * 51 * sizeof(uint16_t) : 0);
+                           (rows_out ? (size_t)tile * F * sizeof(uint16_t) : 0);
   if (lds_bytes > 160 * 1024) return MDR_ERR_UNSUPPORTED;
+  if (ext && (o.f_thermal || o.f_day || o.f_hour || o.f_solar)) {   // the per-env columns, once per env
+    hipLaunchKernelGGL(k_observe_env_extras, dim3((unsigned)((o.E + 255) / 256)), dim3(256), 0, stream, o);
+    if (hipGetLastError() != hipSuccess) return MDR_ERR_HIP;
+  }
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
   const int64_t want = (a.ntiles + waves - 1) / waves;
@@ -1177,6 +1355,15 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
     return hipGetLastError() == hipSuccess ? MDR_OK : MDR_ERR_HIP;
   };
   const int mb = blocks16(actor->hidden1, actor->hidden2);
+  if (ext) {   // optional state columns / c != 10 / link defects: the general staging with run-time row shape
+    if (lbf) {
+      if (mb == 7) return rows_out ? launch(k_actor_observe_bf16<7, true, true, true>) : launch(k_actor_observe_bf16<7, false, true, true>);
+      return rows_out ? launch(k_actor_observe_bf16<8, true, true, true>) : launch(k_actor_observe_bf16<8, false, true, true>);
+    }
+    if (layout == MDR_ACTOR_FRAG16T) return rows_out ? launch(k_actor_observe16<7, true, true, true, true>) : launch(k_actor_observe16<7, false, true, true, true>);
+    if (mb == 7) return rows_out ? launch(k_actor_observe16<7, true, true, false, true>) : launch(k_actor_observe16<7, false, true, false, true>);
+    return rows_out ? launch(k_actor_observe16<8, true, true, false, true>) : launch(k_actor_observe16<8, false, true, false, true>);
+  }
 #define MDR_OBSERVE_VARIANT(KERNEL, ...)                                                                     \
   (rows_out ? (gen ? launch(KERNEL<__VA_ARGS__, true, true>) : launch(KERNEL<__VA_ARGS__, true, false>))   \
             : (gen ? launch(KERNEL<__VA_ARGS__, false, true>) : launch(KERNEL<__VA_ARGS__, false, false>)))

@@ -22,15 +22,19 @@ FEATURES_NORMSTATE, FEATURES_OBSERVE = 0, 1
 OBSERVE_NUM_STATE = 51      # the reference's default observation: 11 own features + 10 neighbours x 4 message fields
 
 
-def observe_feature_order() -> np.ndarray:
-    """normStateDict index of staged feature k in MDR_FEATURES_OBSERVE order: the 10 messages first, then the 11 own features."""
-    k = np.arange(OBSERVE_NUM_STATE)
-    return np.where(k < 40, 11 + k, k - 40)
+def observe_feature_order(num_state: int = OBSERVE_NUM_STATE, msg_floats: int = 40) -> np.ndarray:
+    """normStateDict index of staged feature k in MDR_FEATURES_OBSERVE order: the `msg_floats` = 4 * nb_comm message floats
+    first, then the own features in normStateDict order (default observation: 10 messages, 11 own features)."""
+    own = num_state - msg_floats
+    if own < 11 or msg_floats < 0 or msg_floats % 4:
+        raise ValueError("an observation of %d features cannot start with %d message floats" % (num_state, msg_floats))
+    k = np.arange(num_state)
+    return np.where(k < msg_floats, own + k, k - msg_floats)
 
 
 class MdrActor(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("layout", C.c_int32), ("num_state", C.c_int32), ("hidden1", C.c_int32),
-                ("hidden2", C.c_int32), ("greedy", C.c_int32), ("feature_order", C.c_int32), ("reserved0", C.c_int32),
+                ("hidden2", C.c_int32), ("greedy", C.c_int32), ("feature_order", C.c_int32), ("observe_msg_floats", C.c_int32),
                 ("frag1", C.c_void_p), ("frag2", C.c_void_p), ("wdiff", C.c_void_p)]
 
 
@@ -40,7 +44,7 @@ def _acc_row(reg: np.ndarray, half: np.ndarray) -> np.ndarray:
 
 class FusedActor:
     def __init__(self, w1, b1, w2, b2, w3, b3, device="cuda:0", layout: Optional[int] = None, greedy: bool = False,
-                 feature_order: int = FEATURES_NORMSTATE):
+                 feature_order: int = FEATURES_NORMSTATE, observe_msg_floats: int = 40):
         """w1 [H1, F], b1 [H1], w2 [H2, H1], b2 [H2], w3 [2, H2], b3 [2] (torch.nn.Linear layout).
         ``feature_order=FEATURES_OBSERVE`` packs W1's columns in the order ``sample_env`` stages the default observation in
         (observe -> act without observation rows: ``mdr_env_actor_sample``); such an actor serves ``sample_env`` only.
@@ -50,10 +54,11 @@ class FusedActor:
         self._lib = nat.load()
         w1, b1, w2, b2, w3, b3 = (torch.as_tensor(t, dtype=torch.float32).detach().cpu() for t in (w1, b1, w2, b2, w3, b3))
         self.feature_order = int(feature_order)
+        self.observe_msg_floats = int(observe_msg_floats) if self.feature_order == FEATURES_OBSERVE else 0
         if self.feature_order == FEATURES_OBSERVE:
-            if w1.shape[1] != OBSERVE_NUM_STATE:
-                raise ValueError("observe -> act covers the default observation (%d features)" % OBSERVE_NUM_STATE)
-            w1 = w1[:, torch.from_numpy(observe_feature_order())]
+            if w1.shape[1] > 64:
+                raise ValueError("observe -> act covers observations of at most 64 features")
+            w1 = w1[:, torch.from_numpy(observe_feature_order(w1.shape[1], self.observe_msg_floats))]
         H1, F = w1.shape
         H2 = w2.shape[0]
         if w2.shape[1] != H1 or tuple(w3.shape) != (2, H2):
@@ -122,7 +127,7 @@ class FusedActor:
         assert self._wdiff.numel() == (128 if self.layout == FRAG32 else 388)
         assert self._frag1.numel() == self._lib.mdr_actor_frag1_floats(self.layout, F)
         assert self._frag2.numel() == self._lib.mdr_actor_frag2_floats(self.layout, H1)
-        self._desc = MdrActor(C.sizeof(MdrActor), self.layout, F, H1, H2, int(self.greedy), self.feature_order, 0, self._frag1.data_ptr(), self._frag2.data_ptr(),
+        self._desc = MdrActor(C.sizeof(MdrActor), self.layout, F, H1, H2, int(self.greedy), self.feature_order, self.observe_msg_floats, self._frag1.data_ptr(), self._frag2.data_ptr(),
                               self._wdiff.data_ptr())
 
     @staticmethod
@@ -188,12 +193,12 @@ class FusedActor:
         assert self._wdiff.numel() == 388
         assert self._frag1.numel() * 2 == 4 * self._lib.mdr_actor_frag1_floats(self.layout, F)
         assert self._frag2.numel() * 2 == 4 * self._lib.mdr_actor_frag2_floats(self.layout, H1)
-        self._desc = MdrActor(C.sizeof(MdrActor), self.layout, F, H1, H2, int(self.greedy), self.feature_order, 0, self._frag1.data_ptr(), self._frag2.data_ptr(),
+        self._desc = MdrActor(C.sizeof(MdrActor), self.layout, F, H1, H2, int(self.greedy), self.feature_order, self.observe_msg_floats, self._frag1.data_ptr(), self._frag2.data_ptr(),
                               self._wdiff.data_ptr())
 
     @classmethod
     def from_module(cls, actor, device=None, layout: Optional[int] = None, greedy: bool = False,
-                    feature_order: int = FEATURES_NORMSTATE) -> "FusedActor":
+                    feature_order: int = FEATURES_NORMSTATE, observe_msg_floats: int = 40) -> "FusedActor":
         """From an ``ActorMLP`` / the reference's ``Actor`` - or, with ``greedy=True``, its ``DQN_network`` (the same ``fc``
         ModuleList of three Linear layers, agents/network.py:58-77, whose two outputs are Q-values: action = argmax)."""
         fc = list(actor.fc)
@@ -201,7 +206,7 @@ class FusedActor:
             raise ValueError("the fused kernel covers two hidden layers (config.py: layers = [100, 100])")
         dev = device if device is not None else fc[0].weight.device
         return cls(fc[0].weight, fc[0].bias, fc[1].weight, fc[1].bias, fc[2].weight, fc[2].bias, device=dev, layout=layout, greedy=greedy,
-                   feature_order=feature_order)
+                   feature_order=feature_order, observe_msg_floats=observe_msg_floats)
 
     def sample_env(self, env, seed: int, step: int, want_probs: bool = False, action: Optional[torch.Tensor] = None,
                    a_prob: Optional[torch.Tensor] = None, step_dev: Optional[torch.Tensor] = None,
@@ -221,8 +226,8 @@ class FusedActor:
             raise ValueError("step_dev must be an int32 tensor on the device (env.device_time_index)")
         spec = env._obs_spec("rows")
         if rows_out is not None and (rows_out.dtype != torch.float32 or rows_out.device != self.device or not rows_out.is_contiguous()
-                                     or rows_out.numel() != A * OBSERVE_NUM_STATE):
-            raise ValueError("rows_out must be a contiguous float32 [A, %d] tensor on the device" % OBSERVE_NUM_STATE)
+                                     or rows_out.numel() != A * self.num_state):
+            raise ValueError("rows_out must be a contiguous float32 [A, %d] tensor on the device" % self.num_state)
         with torch.cuda.device(self.device):
             rc = self._lib.mdr_env_actor_sample(env._handle, C.byref(spec), C.byref(self._desc), C.c_uint64(seed & (2 ** 64 - 1)),
                                                 C.c_uint64(step & (2 ** 64 - 1)), C.c_void_p(step_dev.data_ptr()) if step_dev is not None else None,

@@ -70,31 +70,34 @@ def _discounted_returns_hip(reward, done, gamma, bootstrap):
     return out
 
 
-def _fused_policy(actor, dev, precision: str = "fp32", observe: bool = False):
+def _fused_policy(actor, dev, precision: str = "fp32", observe: bool = False, msg_floats: int = 40):
     """FusedActor of `actor`, re-packed only when a parameter changed (torch bumps `_version` on in-place updates).
     ``observe``: packed for ``FusedActor.sample_env`` (W1's columns in the order the observe -> act kernels stage the features)."""
     from .policy import BF16X3, FEATURES_NORMSTATE, FEATURES_OBSERVE, FusedActor
     if precision not in ("fp32", "bf16x3"):
         raise ValueError("policy_precision must be 'fp32' or 'bf16x3'")
-    key = tuple((p.data_ptr(), p._version) for p in actor.parameters()) + (str(dev), precision)
+    key = tuple((p.data_ptr(), p._version) for p in actor.parameters()) + (str(dev), precision, msg_floats if observe else 0)
     slot = "_mdr_fused_observe" if observe else "_mdr_fused"
     cached = getattr(actor, slot, None)
     if cached is None or cached[0] != key:
         layout = BF16X3 if precision == "bf16x3" and actor.fc[0].in_features <= 64 else None      # None: the exact-fp32 form that fits
         cached = (key, FusedActor.from_module(actor, device=dev, layout=layout,
-                                              feature_order=FEATURES_OBSERVE if observe else FEATURES_NORMSTATE))
+                                              feature_order=FEATURES_OBSERVE if observe else FEATURES_NORMSTATE, observe_msg_floats=msg_floats))
         setattr(actor, slot, cached)
     return cached[1]
 
 
 def _observe_act_supported(env, actor) -> bool:
-    """Can ``FusedActor.sample_env`` serve this env / actor?  (default observation = 51 features with 10 circular neighbours and
-    no link defects - hence at least 11 houses - and unsharded houses)"""
-    from .policy import OBSERVE_NUM_STATE
-    cluster = env.config["default_env_prop"]["cluster_prop"]
-    return (not env.sharded and env.nb_houses >= 11 and actor.fc[0].in_features == OBSERVE_NUM_STATE
-            and env.obs_vector_length() == OBSERVE_NUM_STATE and cluster["agents_comm_mode"] == "neighbours"
-            and not getattr(env, "_links_forced", False) and float(cluster["comm_defect_prob"]) == 0.0)
+    """Can ``FusedActor.sample_env`` serve this env / actor?  Circular neighbours (at most 13, fewer than the houses) with 4-field
+    messages, any of the optional STATE columns, link defects, at most 64 features, unsharded houses."""
+    from .comm import nb_comm
+    env_prop = env.config["default_env_prop"]
+    cluster, mp = env_prop["cluster_prop"], env_prop["message_properties"]
+    c = nb_comm(cluster)
+    F = env.obs_vector_length()
+    return (not env.sharded and cluster["agents_comm_mode"] == "neighbours" and not getattr(env, "_links_forced", False)
+            and not mp["thermal"] and not mp["hvac"] and c <= 13 and env.nb_houses >= c + 1 and F <= 64
+            and actor.fc[0].in_features == F)
 
 
 def _fusable(actor) -> bool:
@@ -166,7 +169,9 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
     if observe_act and not fused:
         raise ValueError("observe_act needs the fused policy")
     if fused:
-        policy = _fused_policy(actor, dev, policy_precision, observe=observe_act)
+        from .comm import nb_comm
+        policy = _fused_policy(actor, dev, policy_precision, observe=observe_act,
+                               msg_floats=4 * nb_comm(env.config["default_env_prop"]["cluster_prop"]))
         act_u8 = torch.empty((T, E * N), dtype=torch.uint8, device=dev)
 
     def observe(t):      # straight into the transition buffer when states are kept: no 4 F bytes/agent copy per step

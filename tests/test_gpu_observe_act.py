@@ -83,16 +83,87 @@ def test_observe_act_equals_rows_then_actor(E, N, layout, layers):
         _walk(env, 7, seed=k)
 
 
+_STATE_FLAGS = ("hour", "day", "solar_gain", "thermal", "hvac")
+
+
+def _shape_cfg(N, flags=(), nb_comm=10, defects=0.0):
+    patches = {"default_env_prop.cluster_prop.nb_agents_comm": nb_comm, "default_env_prop.cluster_prop.comm_defect_prob": defects,
+               "default_house_prop.solar_gain_bool": True}
+    for f in flags:
+        patches["default_env_prop.state_properties." + f] = True
+    return _cfg(N, **patches)
+
+
+@pytest.mark.parametrize("E,N,flags,nb_comm,defects", [
+    (6, 64, ("thermal", "hvac"), 10, 0.0),                      # F = 58
+    (3, 1024, _STATE_FLAGS, 10, 0.0),                           # every optional state column: F = 63
+    (40, 50, ("hour", "day"), 10, 0.1),                         # the reference's deployment size, 10 % link defects
+    (9, 96, (), 10, 0.5),                                       # default shape, every second link dead
+    (100, 20, ("solar_gain",), 6, 0.0),                         # fewer neighbours
+    (17, 33, ("solar_gain",), 13, 0.2),                         # 13 neighbours: 6 before, 7 after (F = 64)
+    (5, 12, (), 11, 0.0),                                       # an odd count in the smallest env that has it
+    (64, 14, _STATE_FLAGS, 4, 0.3),
+    (2, 4100, ("thermal",), 12, 0.1),
+    (8, 40, (), 0, 0.0),                                        # no neighbours at all: the 11 own features
+    (1, 1000, ("day",), 1, 0.0),
+])
+@pytest.mark.parametrize("layout", [3, 2, 1])
+def test_observe_act_extended_shapes(E, N, flags, nb_comm, defects, layout):
+    """Optional state columns (utils.py:774-830), any number of circular neighbours (env 816-828), link defects (env 988-1002):
+    rows written on the side == mdr_env_obs_vector bit for bit, probabilities == the actor on those rows."""
+    import mdr_amd
+    from mdr_amd.policy import FEATURES_OBSERVE, FusedActor
+    from mdr_amd.rollout import ActorMLP
+    env = mdr_amd.BatchedDemandResponseEnv(_shape_cfg(N, flags, nb_comm, defects), nb_envs=E, device="cuda:0", seed=5 + N)
+    env.reset(episode=1)
+    F = env.obs_vector_length()
+    assert F == 11 + 4 * nb_comm + 2 * ("hour" in flags) + 2 * ("day" in flags) + ("solar_gain" in flags) + 5 * ("thermal" in flags) + 2 * ("hvac" in flags)
+    torch.manual_seed(E)
+    actor = ActorMLP(F, 2, (100, 100)).to("cuda:0")
+    with torch.no_grad():
+        for lin in actor.fc:
+            lin.weight.mul_(2.0)
+            lin.bias.uniform_(-0.5, 0.5)
+    by_rows = FusedActor.from_module(actor, layout=layout)
+    by_state = FusedActor.from_module(actor, layout=layout, feature_order=FEATURES_OBSERVE, observe_msg_floats=4 * nb_comm)
+    for k in range(3):
+        rows = env.obs_vector("rows").view(E * N, F)
+        if defects > 0:
+            msgs = rows[:, F - 4 * nb_comm:].view(E * N, nb_comm, 4)
+            dead = (msgs == 0).all(dim=2).float().mean()
+            assert abs(float(dead) - defects) < 0.05 + 2.0 / (E * N * nb_comm) ** 0.5      # the defects really are in the rows
+        a0, p0, probs0 = by_rows.sample(rows, seed=9, step=k, want_probs=True)
+        kept = torch.full((E * N, F), float("nan"), device="cuda:0")
+        a1, p1, probs1 = by_state.sample_env(env, seed=9, step=k, want_probs=True, rows_out=kept)
+        assert torch.equal(kept, rows), "rows_out differs from obs_vector('rows')"
+        a2, p2, probs2 = by_state.sample_env(env, seed=9, step=k, want_probs=True)
+        assert torch.equal(a2, a1) and torch.equal(probs2, probs1)
+        with torch.no_grad():
+            ref = actor(rows)
+        tol = dict(rtol=2e-3, atol=2e-5) if layout == 2 else dict(rtol=1e-5, atol=2e-6)
+        torch.testing.assert_close(probs1, ref, **tol)
+        torch.testing.assert_close(probs1, probs0, **tol)
+        differ = a0 != a1
+        assert int(differ.sum()) <= max(2, E * N // 20000)
+        _walk(env, 7, seed=k)
+
+
 def test_observe_act_refuses_what_it_does_not_cover():
     import mdr_amd
     from mdr_amd.policy import FEATURES_OBSERVE, FusedActor
+    from mdr_amd.rollout import ActorMLP
     actor = _actor()
     by_state = FusedActor.from_module(actor, layout=1, feature_order=FEATURES_OBSERVE)
-    env = mdr_amd.BatchedDemandResponseEnv(_cfg(10), nb_envs=4, device="cuda:0", seed=1)          # 9 neighbours: not the 51-feature vector
-    env.reset(episode=0)
-    with pytest.raises(NotImplementedError):
-        by_state.sample_env(env, 0, 0)
-    env = mdr_amd.BatchedDemandResponseEnv(_cfg(64, **{"default_env_prop.cluster_prop.comm_defect_prob": 0.2}), nb_envs=4, device="cuda:0", seed=1)
+    # what stays with rows + actor: senders that are not the circular neighbours, the optional MESSAGE columns, more than 64 features
+    for patches in ({"default_env_prop.cluster_prop.agents_comm_mode": "closed_groups"},
+                    {"default_env_prop.cluster_prop.agents_comm_mode": "random_sample"},
+                    {"default_env_prop.message_properties.thermal": True},
+                    {"default_env_prop.message_properties.hvac": True}):
+        env = mdr_amd.BatchedDemandResponseEnv(_cfg(64, **patches), nb_envs=4, device="cuda:0", seed=1)
+        env.reset(episode=0)
+        with pytest.raises(NotImplementedError):
+            by_state.sample_env(env, 0, 0)
+    env = mdr_amd.BatchedDemandResponseEnv(_cfg(10), nb_envs=4, device="cuda:0", seed=1)          # 9 neighbours: an actor packed for 10 does not fit
     env.reset(episode=0)
     with pytest.raises(NotImplementedError):
         by_state.sample_env(env, 0, 0)
@@ -102,8 +173,10 @@ def test_observe_act_refuses_what_it_does_not_cover():
         FusedActor.from_module(actor, layout=1).sample_env(env, 0, 0)
     with pytest.raises(RuntimeError):                 # and the other way round
         by_state.sample(env.obs_vector("rows").view(-1, 51), 0, 0)
-    with pytest.raises(ValueError):
-        FusedActor.from_module(__import__("mdr_amd.rollout", fromlist=["ActorMLP"]).ActorMLP(47).cuda(), feature_order=FEATURES_OBSERVE)
+    with pytest.raises(ValueError):                   # 14 neighbours + 11 own features: beyond the 64 features of the staged row
+        FusedActor.from_module(ActorMLP(67).cuda(), feature_order=FEATURES_OBSERVE, observe_msg_floats=56)
+    with pytest.raises(ValueError):                   # 47 features cannot start with 40 message floats
+        FusedActor.from_module(ActorMLP(47).cuda(), feature_order=FEATURES_OBSERVE)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
