@@ -1225,8 +1225,9 @@ int mdr_env_actor_sample(mdr_env_t* env, const mdr_obs_spec_t* spec, const mdr_a
   o.cursor = a.cursor; o.cursor_max = a.cursor_max;
   o.E = a.E; o.N = a.N;
   o.obs_tshift = a.obs_tshift; o.inv_norm_reg = a.inv_norm_reg; o.inv_cap = a.inv_cap; o.inv_obs_norm = a.inv_obs_norm;
+  static const bool force_ext = [] { const char* t = getenv("MDR_OBSERVE_EXT"); return t && t[0] == '1'; }();   // experiment knob: the extended kernels on the default shape
   const bool ext = spec->state_hour || spec->state_day || spec->state_solar_gain || spec->state_thermal || spec->state_hvac ||
-                   spec->nb_comm != 10 || spec->comm_defect_prob > 0.0;
+                   spec->nb_comm != 10 || spec->comm_defect_prob > 0.0 || force_ext;
   if (ext) {
     if (env->split_pending) return fail(env, MDR_ERR_INVALID, "step_begin without step_end");
     o.ext = 1;

@@ -168,8 +168,9 @@ struct ObserveArgs {
   // The extended form (ext != 0): optional STATE columns (utils.py:774-830), any number of circular neighbours with 4-field
   // messages, link defects (env 988-1002).  c neighbours: c / 2 before the house, c - c / 2 after (env 816-828); own = number of
   // own normStateDict features (11 + 5 thermal + 2 hvac + 2 hour + 2 day + 1 solar); a row of the window is
-  // [4 c message floats | own features in normStateDict order | zeros up to 64 | L | 1 / L | pad] = OBS_ROW_EXT floats.
+  // [4 c message floats | own features in normStateDict order | zeros | L | 1 / L] = `row` floats.
   int ext, c, before, own;
+  int row;                   // floats per staged row (set by the launcher: the forward's reads of a row + L, 1 / L, rounded up to 16 bytes)
   int f_hour, f_day, f_solar, f_thermal, f_hvac;
   const float *Ua, *Cm, *Ca, *Hm, *COP, *latent;       // raw per-house parameters (thermal / hvac columns)
   float inv_Ua, inv_Cm, inv_Ca, inv_Hm, inv_COP, inv_latent;

@@ -202,7 +202,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_actor_sample(ActorArgs a) {
 // A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15].  Layer 2's k-step q = (kb, reg) takes register
 // [kb][reg] of layer 1: lane group g = lane >> 4 supplies row 16 kb + 4 g + reg - again no lane movement.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int WAVES16 = 16;
+#ifndef MDR_WAVES16
+#define MDR_WAVES16 16
+#endif
+constexpr int WAVES16 = MDR_WAVES16;   // (-DMDR_WAVES16=12: experiment build)
 constexpr int WAVES16_EXT = 12;   // the extended observe -> act form: three waves per SIMD (168 registers; the fp32 forms level off at three waves)
 
 // MDR_ACTOR_FRAG16T: the last of the MB blocks holds at most 4 hidden units (the reference's 100 = 6 x 16 + 4) and runs on
@@ -566,7 +569,9 @@ constexpr int OBS_HALO = 5, OBS_C = 10, OBS_ROW = 56, OBS_PAD = 16;   // floats;
 // The extended form (ObserveArgs.ext; template parameter EXT): optional state columns, c != 10 circular neighbours, link defects.
 // A row is [4 c message floats | own features in normStateDict order | zeros up to 64 | L | 1 / L | pad]: feature k of a row is
 // normStateDict index (k < 4 c ? own + k : k - 4 c), the packed weights follow (mdr_actor_t.feature_order = 1), F = 4 c + own <= 64.
-constexpr int OBS_ROW_EXT = 68, OBS_L_EXT = 64, OBS_MAX_C = 13;
+// The row stride of the extended form is a run-time value (ObserveArgs.row; L and 1 / L sit in its floats row - 2, row - 1): the
+// features rounded up to 16 bytes, so that as many windows fit the LDS as for the default shape where the shape allows it.
+constexpr int OBS_ROW_MAX = 68, OBS_MAX_C = 13;   // (run-time strides: 4 c + own + 2 rounded up to 4 * odd, at most 68)
 typedef float v4f_nt __attribute__((ext_vector_type(4)));
 
 // between a wave's window stores and its loads of what OTHER lanes stored
@@ -580,7 +585,7 @@ struct HouseRegs {
   int sso, lk;
   unsigned fl;
   float sig, pw;
-  float Ua, Cm, Ca, Hm, COP, latent;   // EXT: raw parameters of the thermal / hvac columns (already scaled by 1 / default)
+  float Ua, Cm, Ca, Hm, COP, latent;   // EXT: the thermal / hvac columns, already divided by their defaults
   int e;                               // EXT: the house's env (its per-env columns are fetched when the row is staged)
 };
 
@@ -703,7 +708,7 @@ __device__ __forceinline__ HouseRegs observe_load_gen(const mdr::ObserveArgs& o,
 template <bool EXT = false>
 __device__ __forceinline__ void observe_stage_gen(const mdr::ObserveArgs& o, const HouseRegs& r, const SegSlot& slot, float* rows) {
   if (!slot.live) return;
-  constexpr int ROW = EXT ? OBS_ROW_EXT : OBS_ROW;
+  const int ROW = EXT ? o.row : OBS_ROW;
   const int before = EXT ? o.before : OBS_HALO, c = EXT ? o.c : OBS_C;
   const float4 rec = make_float4((r.Ta - r.tg) * 0.2f, (float)r.sso, ((r.fl & 1u) ? r.pm : 0.0f) * o.inv_norm_reg, r.pm * o.inv_norm_reg);
 #pragma unroll
@@ -754,8 +759,8 @@ __device__ __forceinline__ void observe_stage_gen(const mdr::ObserveArgs& o, con
       own[j++] = L / L;
       own[j++] = r.sig;
       own[j++] = r.pw;
-      row[OBS_L_EXT] = L;
-      row[OBS_L_EXT + 1] = 1.0f / L;
+      row[ROW - 2] = L;
+      row[ROW - 1] = 1.0f / L;
     }
     return;
   }
@@ -828,11 +833,11 @@ __device__ __forceinline__ void observe_build_table(uint16_t* table, int tid, in
   }
 }
 template <int TILE>
-__device__ __forceinline__ void observe_build_table_ext(uint16_t* table, int tid, int nthreads, int own, int c) {
+__device__ __forceinline__ void observe_build_table_ext(uint16_t* table, int tid, int nthreads, int own, int c, int row) {
   const int F = own + 4 * c;
   for (int o = tid; o < TILE * F; o += nthreads) {
     const int r = o / F, n = o - F * r;
-    table[o] = (uint16_t)(OBS_ROW_EXT * r + (n < own ? 4 * c + n : n - own));
+    table[o] = (uint16_t)(row * r + (n < own ? 4 * c + n : n - own));
   }
 }
 
@@ -880,29 +885,30 @@ struct TileCursor {
 
 // ---- bf16x3 form: 32 agents per wavefront (two 16-agent column blocks), k-step s of layer 1 = row floats [32 s + 8 g, + 8)
 template <int MB, bool STORE, bool GEN, bool EXT = false>
-__global__ __launch_bounds__(64 * (EXT ? WAVESB_EXT : WAVESB)) void k_actor_observe_bf16(ActorArgs a, mdr::ObserveArgs o) {
-  constexpr int NW = EXT ? WAVESB_EXT : WAVESB;   // waves per workgroup
+__global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a, mdr::ObserveArgs o) {
+  const int NW = EXT ? (int)(blockDim.x >> 6) : WAVESB;   // waves per workgroup: the extended form takes as many as its windows leave room for (6 .. 8; two per SIMD either way)
   static_assert(!EXT || GEN, "the extended form stages through the general windows");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int S2B = (MB + 1) / 2, TILE = 16 * NCB, ROW = EXT ? OBS_ROW_EXT : OBS_ROW, WIN = TILE * ROW + OBS_PAD;
+  constexpr int S2B = (MB + 1) / 2, TILE = 16 * NCB;
+  const int ROW = EXT ? o.row : OBS_ROW, WIN = TILE * ROW + OBS_PAD;
   const int F = EXT ? o.own + 4 * o.c : 51;
   uint4* f1 = reinterpret_cast<uint4*>(lds);                    // [2][8][2][64] fragments of 8 bf16
   const int S1B = EXT ? a.S1 : 2;                               // k-steps of layer 1: 32 features each (the extended form: one for F <= 32)
-  uint4* f2 = f1 + S1B * 1024;                                  // [S2B][8][2][64]
+  uint4* f2 = f1 + 2 * 1024;                                    // [S2B][8][2][64] (f1: both k-steps, the second zero-filled when S1B = 1)
   float* wd = reinterpret_cast<float*>(f2 + S2B * 1024);        // head weights + biases (512 floats reserved)
   const int tid = threadIdx.x;
   float* rows = wd + 512 + (tid >> 6) * WIN;                    // this wave's window
   uint16_t* table = reinterpret_cast<uint16_t*>(wd + 512 + NW * WIN);   // [TILE * 51] (only when rows are stored)
   const uint4* g1 = reinterpret_cast<const uint4*>(a.frag1);
   const uint4* g2 = reinterpret_cast<const uint4*>(a.frag2);
-  for (int i = tid; i < S1B * 1024; i += 64 * NW) f1[i] = g1[i];
+  for (int i = tid; i < 2 * 1024; i += 64 * NW) f1[i] = i < S1B * 1024 ? g1[i] : uint4{0u, 0u, 0u, 0u};
   for (int i = tid; i < S2B * 1024; i += 64 * NW) f2[i] = g2[i];
   for (int i = tid; i < 388; i += 64 * NW) wd[i] = a.wdiff[i];   // (a workgroup of the extended bf16 form has 384 threads)
   const int lane = tid & 63;
   for (int i = lane; i < WIN; i += 64) rows[i] = 0.0f;          // pads are read (against zero weights): they must be finite
   constexpr bool store = STORE;   // rows_out != nullptr (a compile-time variant: the plain form keeps its registers)
   if (store) {
-    if (EXT) observe_build_table_ext<TILE>(table, tid, 64 * NW, o.own, o.c);
+    if (EXT) observe_build_table_ext<TILE>(table, tid, 64 * NW, o.own, o.c, ROW);
     else observe_build_table<TILE>(table, tid, 64 * NW);
   }
   __syncthreads();
@@ -928,7 +934,7 @@ __global__ __launch_bounds__(64 * (EXT ? WAVESB_EXT : WAVESB)) void k_actor_obse
 #pragma unroll
     for (int c = 0; c < NCB; ++c) {
       float* row = rows + (c * 16 + r) * ROW;
-      const float L = row[EXT ? OBS_L_EXT : 4 * OBS_C + 11], y = row[EXT ? OBS_L_EXT + 1 : 4 * OBS_C + 12];
+      const float L = row[EXT ? ROW - 2 : 4 * OBS_C + 11], y = row[EXT ? ROW - 1 : 4 * OBS_C + 12];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const float4 v0 = *reinterpret_cast<const float4*>(row + 32 * s + 8 * g);
@@ -945,8 +951,11 @@ __global__ __launch_bounds__(64 * (EXT ? WAVESB_EXT : WAVESB)) void k_actor_obse
         xr[c][8 * s + 5] = msg_b ? mdr::div_by_lockout(v1.y, L, y) : v1.y;
         xr[c][8 * s + 6] = v1.z;
         xr[c][8 * s + 7] = v1.w;
-        if (store && msg_a) row[32 * s + 8 * g + 1] = xr[c][8 * s + 1];
-        if (store && msg_b) row[32 * s + 8 * g + 5] = xr[c][8 * s + 5];
+        // (rows past the batch's last agent hold zeros - L = 0, a NaN quotient - and the row BEFORE them reads their first floats
+        // against zero weights when the row stride is below 64: they keep their zeros)
+        const bool live_row = !GEN || first_agent + c * 16 + r < a.A;
+        if (store && msg_a && live_row) row[32 * s + 8 * g + 1] = xr[c][8 * s + 1];
+        if (store && msg_b && live_row) row[32 * s + 8 * g + 5] = xr[c][8 * s + 5];
       }
     }
     if (store) {
@@ -992,7 +1001,6 @@ __global__ __launch_bounds__(64 * (EXT ? WAVESB_EXT : WAVESB)) void k_actor_obse
     // ---- layer 1 (F = 51: both k-steps)
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      if (EXT && s >= S1B) continue;
       bf16x8 Bh[NCB], Bl[NCB];
 #pragma unroll
       for (int c = 0; c < NCB; ++c) {
@@ -1089,22 +1097,27 @@ __global__ __launch_bounds__(64 * (EXT ? WAVES16_EXT : WAVES16)) void k_actor_ob
   constexpr int NW = EXT ? WAVES16_EXT : WAVES16;   // waves per workgroup
   static_assert(!EXT || GEN, "the extended form stages through the general windows");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int TILE = 16, ROW = EXT ? OBS_ROW_EXT : OBS_ROW, WIN = TILE * ROW + OBS_PAD;
+  constexpr int TILE = 16;
+  const int ROW = EXT ? o.row : OBS_ROW, WIN = TILE * ROW + OBS_PAD;
   const int S1 = EXT ? a.S1 : 13, F = EXT ? o.own + 4 * o.c : 51;   // lane group g holds features [S1 g, S1 g + S1) of its agent
   float* f1 = lds;                       // [13][64][8]
-  float* f2 = f1 + S1 * 512;             // [S2][64][8]
+  // the extended form runs 16 k-steps of layer 1 whatever F is, over fragments zero-filled behind the packed S1 = ceil(F / 4): a
+  // run-time trip count would cut the unrolled ds_read / MFMA stream into a basic block per k-step
+  constexpr int S1L = EXT ? 16 : 13;
+  float* f2 = f1 + S1L * 512;            // [S2][64][8]
   float* wd = f2 + a.S2 * 512;           // head weights + biases (512 floats reserved)
   const int tid = threadIdx.x;
   float* rows = wd + 512 + (tid >> 6) * WIN;
   uint16_t* table = reinterpret_cast<uint16_t*>(wd + 512 + NW * WIN);   // [TILE * 51] (only when rows are stored)
-  for (int i = tid * 4; i < S1 * 512; i += 64 * NW * 4) *reinterpret_cast<float4*>(f1 + i) = *reinterpret_cast<const float4*>(a.frag1 + i);
+  for (int i = tid * 4; i < S1L * 512; i += 64 * NW * 4)
+    *reinterpret_cast<float4*>(f1 + i) = i < S1 * 512 ? *reinterpret_cast<const float4*>(a.frag1 + i) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   for (int i = tid * 4; i < a.S2 * 512; i += 64 * NW * 4) *reinterpret_cast<float4*>(f2 + i) = *reinterpret_cast<const float4*>(a.frag2 + i);
   for (int i = tid; i < 388; i += 64 * NW) wd[i] = a.wdiff[i];   // (a workgroup of the extended bf16 form has 384 threads)
   const int lane = tid & 63;
   for (int i = lane; i < WIN; i += 64) rows[i] = 0.0f;
   constexpr bool store = STORE;   // rows_out != nullptr (a compile-time variant: the plain form keeps its registers)
   if (store) {
-    if (EXT) observe_build_table_ext<TILE>(table, tid, 64 * NW, o.own, o.c);
+    if (EXT) observe_build_table_ext<TILE>(table, tid, 64 * NW, o.own, o.c, ROW);
     else observe_build_table<TILE>(table, tid, 64 * NW);
   }
   __syncthreads();
@@ -1121,7 +1134,7 @@ __global__ __launch_bounds__(64 * (EXT ? WAVES16_EXT : WAVES16)) void k_actor_ob
   float xr[16];
   auto gather = [&](int64_t first_agent) {
     float* row = rows + r * ROW;
-    const float L = row[EXT ? OBS_L_EXT : 4 * OBS_C + 11], y = row[EXT ? OBS_L_EXT + 1 : 4 * OBS_C + 12];
+    const float L = row[EXT ? ROW - 2 : 4 * OBS_C + 11], y = row[EXT ? ROW - 1 : 4 * OBS_C + 12];
     // the senders' seconds_since_off (float 1 of every message record) become quotients by the RECEIVER's lockout, in place: lane
     // group g takes the messages g, g + 4 and g + 8 of its agent's row - three sites instead of a test on each of the 13 features
 #pragma unroll
@@ -1135,8 +1148,10 @@ __global__ __launch_bounds__(64 * (EXT ? WAVES16_EXT : WAVES16)) void k_actor_ob
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 #pragma unroll
-    for (int s = 0; s < (EXT ? 16 : 13); ++s)
-      if (!EXT || s < S1) xr[s] = row[S1 * g + s];
+    for (int s = 0; s < S1L; ++s) {
+      const float v = row[EXT ? min(S1 * g + s, ROW - 3) : 13 * g + s];   // (clamped: past the lane group's S1 features a finite float against a zero weight)
+      xr[s] = (!EXT || s < S1) ? v : 0.0f;
+    }
     if (store) {
       observe_store_rows<TILE, EXT>(rows, table, a.rows_out + first_agent * F, lane,
                                     GEN ? (int)((a.A - first_agent) < (int64_t)TILE ? (a.A - first_agent) : (int64_t)TILE) : TILE, F);
@@ -1172,8 +1187,7 @@ __global__ __launch_bounds__(64 * (EXT ? WAVES16_EXT : WAVES16)) void k_actor_ob
     for (int mb = 0; mb < MB; ++mb) acc[mb] = bias1[mb * 4];
     // ---- layer 1
 #pragma unroll
-    for (int s = 0; s < (EXT ? 16 : 13); ++s) {
-      if (EXT && s >= S1) continue;
+    for (int s = 0; s < S1L; ++s) {
       const float4 w0 = *reinterpret_cast<const float4*>(f1 + s * 512 + lane * 8);
       const float4 w1 = *reinterpret_cast<const float4*>(f1 + s * 512 + lane * 8 + 4);
       const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
@@ -1317,7 +1331,16 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
   if (F > 64 || c > OBS_MAX_C || c < 0) return MDR_ERR_UNSUPPORTED;
   if (actor->hidden1 <= 0 || actor->hidden2 <= 0 || actor->hidden1 > MDR_ACTOR_MAX_HIDDEN || actor->hidden2 > MDR_ACTOR_MAX_HIDDEN) return MDR_ERR_INVALID;
   const bool lbf = layout == MDR_ACTOR_BF16X3;
-  const int tile = lbf ? 16 * NCB : 16, waves = lbf ? (ext ? WAVESB_EXT : WAVESB) : (ext ? WAVES16_EXT : WAVES16);
+  const int tile = lbf ? 16 * NCB : 16, s1 = steps1(layout, actor->num_state);
+  // row stride of the extended form: the floats the forward reads of a row (bf16: the features; fp32: four lane groups of S1) + L, 1 / L
+  // ... as a multiple of 4 floats that is ODD in units of 4: the 16 lanes of a lane group read the same offset of 16 consecutive
+  // rows, and a stride of 64 floats would put them all on one LDS bank (60 or 68: two lanes per bank)
+  int row = OBS_ROW;
+  if (ext) {
+    row = ((lbf ? F : 4 * s1) + 2 + 3) & ~3;
+    if ((row & 4) == 0) row += 4;
+  }
+  int waves = lbf ? WAVESB : (ext ? WAVES16_EXT : WAVES16);
   if (o.N < c + 1) return MDR_ERR_UNSUPPORTED;   // c distinct circular neighbours
   static const bool force_gen = [] { const char* t = getenv("MDR_OBSERVE_GEN"); return t && t[0] == '1'; }();   // experiment knob
   const bool gen = ext || o.N % 32 != 0 || force_gen;     // tiles that start anywhere in an env / span several: the general staging
@@ -1336,12 +1359,19 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
   a.step_lo = (uint32_t)(step & 0xFFFFFFFFull); a.step_hi = (uint32_t)(step >> 32);
   a.step_dev = step_dev;
   a.greedy = actor->greedy != 0;
-  const size_t window = (size_t)tile * (ext ? OBS_ROW_EXT : OBS_ROW) + OBS_PAD;
-  const size_t lds_bytes = ((size_t)(a.S1 + a.S2) * floats_per_step(layout) + 512 + (size_t)waves * window) * sizeof(float) +
-                           (rows_out ? (size_t)tile * F * sizeof(uint16_t) : 0);
+  ObserveArgs oo = o;
+  oo.row = row;
+  const size_t window = (size_t)tile * row + OBS_PAD;
+  auto lds_need = [&](int w) {
+    const int s1_lds = ext ? (lbf ? 2 : 16) : a.S1;   // the extended form stages layer 1 zero-padded to its full k-step count
+    return ((size_t)(s1_lds + a.S2) * floats_per_step(layout) + 512 + (size_t)w * window) * sizeof(float) + (rows_out ? (size_t)tile * F * sizeof(uint16_t) : 0);
+  };
+  if (ext && lbf)   // the bf16 form keeps two waves per SIMD whatever the count: as many windows as fit beside the weight fragments
+    while (waves > 4 && lds_need(waves) > 160 * 1024) --waves;
+  const size_t lds_bytes = lds_need(waves);
   if (lds_bytes > 160 * 1024) return MDR_ERR_UNSUPPORTED;
   if (ext && (o.f_thermal || o.f_day || o.f_hour || o.f_solar)) {   // the per-env columns, once per env
-    hipLaunchKernelGGL(k_observe_env_extras, dim3((unsigned)((o.E + 255) / 256)), dim3(256), 0, stream, o);
+    hipLaunchKernelGGL(k_observe_env_extras, dim3((unsigned)((o.E + 255) / 256)), dim3(256), 0, stream, oo);
     if (hipGetLastError() != hipSuccess) return MDR_ERR_HIP;
   }
   int dev = 0, cus = 256;
@@ -1351,7 +1381,7 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
   auto launch = [&](auto kernel) -> int {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
       return MDR_ERR_HIP;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * waves), lds_bytes, stream, a, o);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * waves), lds_bytes, stream, a, oo);
     return hipGetLastError() == hipSuccess ? MDR_OK : MDR_ERR_HIP;
   };
   const int mb = blocks16(actor->hidden1, actor->hidden2);
