@@ -286,7 +286,10 @@ def ppo_leg(rk: Ranks, env, args):
            "workload": "%d envs x %d houses per GPU (the C3 batch), Actor %d-100-100-2 random init; observation and policy are ONE kernel "
                        "(mdr_env_actor_sample: the 51 features built in LDS from the compact state); transitions stay on the GPU: "
                        "`transitions` = state (204 B/agent, written on the side by the same kernel) + action + a_prob + reward + return, "
-                       "`no_states` = the same without keeping the states" % (E, N, env.obs_vector_length()),
+                       "`no_states` = the same without keeping the states; during the collection the env steps WITHOUT its seven per-step "
+                       "observation planes (mdr_buffers_t.obs = NULL: 71 algorithmic bytes per house-step instead of the headline's 99 - "
+                       "nothing in the loop reads them) and brings them up to date once at the end" % (E, N, env.obs_vector_length()),
+           "step_kernel_algorithmic_bytes_per_house_step": 71,
            "steps": args.ppo_steps, "n_gpus": rk.world, "scaling": "weak"}
     for prec in ("fp32", "bf16x3"):
         out[prec] = {}

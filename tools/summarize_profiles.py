@@ -75,7 +75,35 @@ def main_r02(rnd):
     print(json.dumps({"c3": c3, "x8": big}, indent=1))
 
 
+def main_r03(rnd):
+    """Round 3 layout: the C3 headline again (gpurun_out/prof_r03, pmc_fetch_r03, pmc_write_r03) and the same kernel without the
+    seven observation planes (prof_r03_noplanes, pmc_*_r03_noplanes: 71 algorithmic bytes per house-step)."""
+    os.makedirs(P, exist_ok=True)
+    shutil.copy(os.path.join(G, "prof_" + rnd, "step_kernel_stats.csv"), os.path.join(P, rnd + "_kernel_stats.csv"))
+    c3 = traffic(os.path.join(G, "prof_" + rnd, "step_kernel_stats.csv"), os.path.join(G, "pmc_fetch_" + rnd, "fetch_counter_collection.csv"),
+                 os.path.join(G, "pmc_write_" + rnd, "write_counter_collection.csv"), 4096 * 1024)
+    with open(os.path.join(P, rnd + "_traffic.json"), "w") as f:
+        json.dump(c3, f, indent=1)
+    out = {"c3": c3}
+    stats = os.path.join(G, "prof_" + rnd + "_noplanes", "np_kernel_stats.csv")
+    if os.path.isfile(stats):
+        shutil.copy(stats, os.path.join(P, rnd + "_kernel_stats_noplanes.csv"))
+        bare = traffic(stats, os.path.join(G, "pmc_fetch_" + rnd + "_noplanes", "fetch_counter_collection.csv"),
+                       os.path.join(G, "pmc_write_" + rnd + "_noplanes", "write_counter_collection.csv"), 4096 * 1024)
+        houses = 4096 * 1024
+        bare.update({"algorithmic_bytes_per_launch": 71 * houses, "algorithmic_write_bytes": 18 * houses,
+                     "traffic_over_algorithmic": bare["hbm_bytes_per_launch"] / (71.0 * houses),
+                     "achieved_GBps_from_rocprof_avg": 71 * houses / bare["avg_ns"],
+                     "note": "mdr_buffers_t.obs == NULL: reads as the headline (53 B/house), writes state 13 + action 1 + reward 4 = 18 B/house"})
+        with open(os.path.join(P, rnd + "_traffic_noplanes.json"), "w") as f:
+            json.dump(bare, f, indent=1)
+        out["noplanes"] = bare
+    print(json.dumps(out, indent=1))
+
+
 def main(rnd):
+    if rnd == "r03":
+        return main_r03(rnd)
     if rnd != "r01":
         return main_r02(rnd)
     os.makedirs(P, exist_ok=True)
