@@ -49,3 +49,32 @@ def test_tables_by_runs_equal_tables_by_entry(signal, temp_mode, dt, E):
         for _, small in smalls:
             small.rollout(65)
         assert big.cursor() == smalls[0][1].cursor()
+
+
+def test_tile_tables_across_midnight_and_at_the_batch_edge():
+    """k_fill_tables_tile (a workgroup per 64 envs, every lattice gradient of the window once): envs whose window runs across
+    midnight - the seconds-of-day and with them the lattice cells start again, those rows draw their gradients directly - and the
+    last, partly filled tile of a batch whose size is not a multiple of 64, against the per-entry kernel."""
+    import mdr_amd
+    E = 100_003
+    cfg = _cfg("perlin", "noisy_sinusoidal_heatwave", 4)
+    big = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=5, table_steps=64)
+    big.reset(episode=1)
+    sod = big.t["t0"] % 86400
+    checked = 0
+    for rounds in range(2):
+        first = sod + big.cursor()[1] * 4                    # seconds of day at row 0 of the current window
+        crossing = torch.nonzero((first % 86400) > 86400 - 200).flatten().cpu().tolist()
+        assert len(crossing) >= 3
+        for off in crossing[:4] + [E - 8, E - 67]:
+            off = min(off, E - 8)
+            small = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=8, device="cuda:0", seed=5, table_steps=64, env_offset=off)
+            small.reset(episode=1)
+            if rounds:
+                small.rollout(65)
+            for name in ("tab_od", "tab_solar", "tab_signal", "tab_abs_noise"):
+                assert torch.equal(small.table(name), big.table(name)[:, off:off + 8]), (rounds, off, name)
+            assert small.cursor() == big.cursor()
+            checked += 1
+        big.rollout(65)
+    assert checked == 12
