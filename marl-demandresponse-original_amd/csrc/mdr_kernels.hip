@@ -407,15 +407,15 @@ __global__ __launch_bounds__(256, MDR_TABLE_RUN_WAVES) void k_fill_tables_runs(T
   }
 }
 
-// The Perlin tables of a TILE of 64 envs by one workgroup, every lattice gradient of the window computed exactly once.  In the runs
-// kernel above a wave holds 64 envs whose start times differ: whenever ANY lane enters a new minute (probability 0.99 per row at
-// dt = 4 s) or a new lattice cell (~1 per octave and row) the whole wave walks the calendar + solar polynomial / the Philox rounds -
-// the caches save little.  Here the work that is shared between rows is split evenly over the lanes first:
+// The tables of a TILE of 64 envs by one workgroup, what rows share computed exactly once.  In the runs kernel above a wave holds
+// 64 envs whose start times differ: whenever ANY lane enters a new minute (probability 0.99 per row at dt = 4 s) or a new lattice
+// cell (~1 per octave and row) the whole wave walks the calendar + solar polynomial / the Philox rounds - the caches save little.
+// Here the shared work is split evenly over the lanes first:
 //   phase 0  per (env, minute of the window): calendar, outdoor sinusoid, solar polynomial, seconds-of-day   -> LDS
-//   phase 1  per (env, octave): the lattice cell of row 0                                                       -> LDS
+//   phase 1  per (env, octave): the lattice cell of row 0                                          (Perlin)   -> LDS
 //   phase 2  per (env, gradient slot): one Philox call - the window needs ceil(span_q) + 2 gradients of octave q
 //            (6 + 9 + 15 + 28 + 54 for the default five octaves and 65 rows, against 650 calls by entry)         -> LDS
-//   phase 3  per (env, row): OD Gaussian, five fades, the stores; lane = env (coalesced rows), wave = a quarter of the rows
+//   phase 3  per (env, row): OD Gaussian, the signal, the stores; lane = env (coalesced rows), wave = a quarter of the rows
 // A row whose cell lies outside the slots (a window across midnight: seconds-of-day start again) draws its gradients directly.
 // Same expressions on the same inputs as k_fill_tables: bit-identical tables (tests/test_gpu_tables.py).
 constexpr int TABLE_TILE_ENVS = 64;
@@ -442,7 +442,9 @@ __global__ __launch_bounds__(256) void k_fill_tables_tile(TableArgs a, TableTile
   const int64_t t_first = t0e + a.j0 * (int64_t)a.dt;
   int64_t m_first = t_first / 60;
   if (t_first - m_first * 60 < 0) m_first -= 1;
+  const int sec_first = (int)(t_first - m_first * 60);     // seconds into the first minute
   const double amp = 0.5 * (a.day_temp - a.night_temp), bias = 0.5 * (a.day_temp + a.night_temp);
+  const bool perlin = a.signal_mode == MDR_SIGNAL_PERLIN;
 
   {   // phase 0
     const double phase = a.phase[e];
@@ -455,22 +457,22 @@ __global__ __launch_bounds__(256) void k_fill_tables_tile(TableArgs a, TableTile
     }
   }
   __syncthreads();
-  for (int q = w; q < a.perlin_octaves; q += 4) {   // phase 1
-    const double sod = (double)(s_sod[0][lane] + (int)(t_first - m_first * 60));
-    const double xx = (sod / a.perlin_period) * ldexp(a.perlin_step, q);
-    s_first[q][lane] = (uint32_t)(int64_t)floor(xx);
-  }
-  __syncthreads();
-  {   // phase 2
-    const int slots = tl.base[a.perlin_octaves];
+  if (perlin) {
+    for (int q = w; q < a.perlin_octaves; q += 4) {   // phase 1
+      const double sod = (double)(s_sod[0][lane] + sec_first);
+      const double xx = (sod / a.perlin_period) * ldexp(a.perlin_step, q);
+      s_first[q][lane] = (uint32_t)(int64_t)floor(xx);
+    }
+    __syncthreads();
+    const int slots = tl.base[a.perlin_octaves];      // phase 2
     int q = 0;
     for (int sl = w; sl < slots; sl += 4) {
       while (sl >= tl.base[q + 1]) ++q;
       const uint32_t li = s_first[q][lane] + (uint32_t)(sl - tl.base[q]);
       s_u[sl * TABLE_TILE_ENVS + lane] = philox4x32_10(eg, li, a.episode, TAG_PERLIN, a.k0, a.k1).x;
     }
+    __syncthreads();
   }
-  __syncthreads();
   if (!live) return;
 
   // phase 3
@@ -479,13 +481,13 @@ __global__ __launch_bounds__(256) void k_fill_tables_tile(TableArgs a, TableTile
   const double ratio = a.ratio[e], max_power = a.max_power[e];
   const double base = a.base_power ? a.base_power[e] : a.avg_power_per_hvac * (double)a.n_total;
   const double w_last = 1.0 / (ldexp(1.0, a.perlin_octaves) - 1.0);
+  // minute slot and seconds into it, carried from row to row (the same integers as floor(t / 60) and t - 60 floor(t / 60))
+  int64_t since = (int64_t)sec_first + (int64_t)r0 * a.dt;
+  int ms = (int)(since / 60);
+  int sec = (int)(since - (int64_t)ms * 60);
   for (int r = r0; r < r1; ++r) {
     const int64_t i = (int64_t)r * a.E + e;
     const int64_t j = a.j0 + r;
-    const int64_t t = t0e + j * (int64_t)a.dt;
-    int64_t m = t / 60;
-    if (t - m * 60 < 0) m -= 1;
-    const int ms = (int)(m - m_first);
     double od;
     if (a.od_ext != nullptr && j < a.od_ext_rows) {
       od = a.od_ext[j * a.E + e];
@@ -498,33 +500,58 @@ __global__ __launch_bounds__(256) void k_fill_tables_tile(TableArgs a, TableTile
     }
     a.tab_od[i] = (float)(od - a.temp_ref);
     a.tab_solar[i] = s_solar[ms][lane];
-    const double sod = (double)(s_sod[ms][lane] + (int)(t - m * 60));
-    const double x = sod / a.perlin_period;
-    double n = 0.0;
-    for (int q = 0; q < a.perlin_octaves; ++q) {
-      const double f = ldexp(a.perlin_step, q);
-      const double wq = (q < a.perlin_octaves - 1) ? ldexp(1.0, -q) : w_last;
-      const double xx = x * f;
-      const double l0 = floor(xx);
-      const double d0 = xx - l0;
-      const double d1 = d0 - 1.0;
-      const uint32_t li = (uint32_t)(int64_t)l0;
-      const uint32_t idx = li - s_first[q][lane];
-      uint32_t u0, u1;
-      if (idx + 1u < (uint32_t)(tl.base[q + 1] - tl.base[q])) {
-        const int sl = tl.base[q] + (int)idx;
-        u0 = s_u[sl * TABLE_TILE_ENVS + lane];
-        u1 = s_u[(sl + 1) * TABLE_TILE_ENVS + lane];
-      } else {
-        u0 = philox4x32_10(eg, li, a.episode, TAG_PERLIN, a.k0, a.k1).x;
-        u1 = philox4x32_10(eg, li + 1u, a.episode, TAG_PERLIN, a.k0, a.k1).x;
+    const double sod = (double)(s_sod[ms][lane] + sec);
+    double sig, abs_noise = 0.0;
+    if (a.signal_mode == MDR_SIGNAL_FLAT) {
+      sig = base;
+    } else if (a.signal_mode == MDR_SIGNAL_SINUSOIDALS) {
+      sig = base;
+      for (int q = 0; q < a.nb_sin; ++q)
+        sig += base * a.sin_ratios[q] * sin(6.283185307179586476925286766559 * sod / a.sin_periods[q]);
+    } else if (a.signal_mode == MDR_SIGNAL_REGULAR_STEPS) {
+      const double ampl = a.steps_amp * (double)a.n_total;
+      const double duty = base / ampl;
+      {
+#pragma clang fp contract(off)
+        const double edge = (1.0 - duty) * a.steps_period;
+        const double x = fmod(sod, a.steps_period) - edge;
+        sig = x >= 0.0 ? ampl : 0.0;
       }
-      const double g0 = 2.0 * u01(u0) - 1.0, g1 = 2.0 * u01(u1) - 1.0;
-      n += wq * (fade5(1.0 - d0) * g0 * d0 + fade5(1.0 + d1) * g1 * d1);
+    } else {
+      const double x = sod / a.perlin_period;
+      double n = 0.0;
+      for (int q = 0; q < a.perlin_octaves; ++q) {
+        const double f = ldexp(a.perlin_step, q);
+        const double wq = (q < a.perlin_octaves - 1) ? ldexp(1.0, -q) : w_last;
+        const double xx = x * f;
+        const double l0 = floor(xx);
+        const double d0 = xx - l0;
+        const double d1 = d0 - 1.0;
+        const uint32_t li = (uint32_t)(int64_t)l0;
+        const uint32_t idx = li - s_first[q][lane];
+        uint32_t u0, u1;
+        if (idx + 1u < (uint32_t)(tl.base[q + 1] - tl.base[q])) {
+          const int sl = tl.base[q] + (int)idx;
+          u0 = s_u[sl * TABLE_TILE_ENVS + lane];
+          u1 = s_u[(sl + 1) * TABLE_TILE_ENVS + lane];
+        } else {
+          u0 = philox4x32_10(eg, li, a.episode, TAG_PERLIN, a.k0, a.k1).x;
+          u1 = philox4x32_10(eg, li + 1u, a.episode, TAG_PERLIN, a.k0, a.k1).x;
+        }
+        const double g0 = 2.0 * u01(u0) - 1.0, g1 = 2.0 * u01(u1) - 1.0;
+        n += wq * (fade5(1.0 - d0) * g0 * d0 + fade5(1.0 + d1) * g1 * d1);
+      }
+      sig = fmax(0.0, base + base * a.perlin_amp * n);
+      abs_noise = fabs(base * a.perlin_amp * n);
     }
-    const double sig = fmax(0.0, base + base * a.perlin_amp * n);
-    if (a.tab_abs_noise != nullptr) a.tab_abs_noise[i] = fabs(base * a.perlin_amp * n);
-    a.tab_signal[i] = fmin(sig * ratio, max_power);
+    if (a.tab_abs_noise != nullptr) a.tab_abs_noise[i] = abs_noise;
+    sig *= ratio;
+    a.tab_signal[i] = fmin(sig, max_power);
+    sec += a.dt;
+    while (sec >= 60) {
+      sec -= 60;
+      ms += 1;
+    }
   }
 }
 
@@ -2119,23 +2146,25 @@ hipError_t launch_tables(const TableArgs& a, hipStream_t s) {
     if (knob >= 0) chunk = knob;
     else if (n >= (int64_t)1 << 19) chunk = (int)std::min<int64_t>(a.rows, n >> 18);
   }
-  // Perlin signal over a batch of many envs: a workgroup per 64 envs, each gradient once (MDR_TABLE_TILE=0: the runs kernel)
+  // A batch of many envs: a workgroup per 64 envs, calendar per minute and Perlin gradient once (MDR_TABLE_TILE=0: the runs kernel)
   static const int tile_knob = [] { const char* t = getenv("MDR_TABLE_TILE"); return t ? atoi(t) : 1; }();
-  if (chunk > 1 && tile_knob && a.signal_mode == MDR_SIGNAL_PERLIN && a.perlin_octaves <= TABLE_RUN_OCTAVES && a.E >= 4096 &&
-      a.perlin_period > 0.0 && a.perlin_step > 0.0) {
+  const bool perlin = a.signal_mode == MDR_SIGNAL_PERLIN;
+  if (chunk > 1 && tile_knob && a.E >= 4096 && a.dt > 0 &&
+      (!perlin || (a.perlin_octaves <= TABLE_RUN_OCTAVES && a.perlin_period > 0.0 && a.perlin_step > 0.0))) {
     TableTile tl{};
     const double window = (double)(a.rows - 1) * (double)a.dt;
     const double minutes = floor(window / 60.0) + 2.0;
     bool fits = minutes <= (double)TABLE_TILE_MAX_MINUTES;
-    for (int q = 0; q < a.perlin_octaves && fits; ++q) {
+    for (int q = 0; perlin && q < a.perlin_octaves && fits; ++q) {
       const double span = window / a.perlin_period * std::ldexp(a.perlin_step, q);
       fits = span < (double)TABLE_TILE_MAX_SLOTS;
-      if (fits) tl.base[q + 1] = tl.base[q] + (int)std::ceil(span) + 3;
+      if (fits) tl.base[q + 1] = tl.base[q] + (int)std::ceil(span) + 2;
     }
-    fits = fits && tl.base[a.perlin_octaves] <= TABLE_TILE_MAX_SLOTS;
+    fits = fits && (!perlin || tl.base[a.perlin_octaves] <= TABLE_TILE_MAX_SLOTS);
     if (fits) {
       tl.minutes = (int)minutes;
-      const size_t lds = (size_t)tl.base[a.perlin_octaves] * TABLE_TILE_ENVS * sizeof(uint32_t);
+      const int slots = perlin ? tl.base[a.perlin_octaves] : 0;
+      const size_t lds = (size_t)slots * TABLE_TILE_ENVS * sizeof(uint32_t);
       static const bool raised = [] {
         return hipFuncSetAttribute((const void*)k_fill_tables_tile, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    TABLE_TILE_MAX_SLOTS * TABLE_TILE_ENVS * (int)sizeof(uint32_t)) == hipSuccess;

@@ -1,7 +1,8 @@
 """The per-env time tables (outdoor temperature env/MA_DemandResponse.py:1057-1081, solar gain utils.py:1277-1350, regulation
 signal env 1236-1316) built by runs of rows per thread - calendar / sinusoid / solar polynomial once per minute, Perlin gradients
-once per lattice cell - must equal the one-thread-per-entry tables bit for bit.  A batch of a few envs takes the per-entry
-kernel, a big batch the runs (mdr_kernels.hip launch_tables); env_offset puts the small batch on the same global envs."""
+once per lattice cell - or by tiles of 64 envs per workgroup (k_fill_tables_tile: windows of at most 8 minutes in batches of
+>= 4096 envs) must equal the one-thread-per-entry tables bit for bit.  A batch of a few envs takes the per-entry kernel, a big
+batch the runs or the tiles (mdr_kernels.hip launch_tables); env_offset puts the small batch on the same global envs."""
 import pytest
 import torch
 
@@ -30,6 +31,8 @@ def _cfg(signal, temp_mode, dt):
     ("sinusoidals", "sinusoidal_hot", 7, 16384),             # runs of 4 rows
     ("regular_steps", "noisy_sinusoidal_cold", 4, 131072),
     ("flat", "constant", 4, 40000),
+    ("sinusoidals", "noisy_sinusoidal_heatwave", 4, 100000),   # the tile kernel without gradient slots
+    ("regular_steps", "sinusoidal_hot", 5, 65536),
 ])
 def test_tables_by_runs_equal_tables_by_entry(signal, temp_mode, dt, E):
     import mdr_amd
