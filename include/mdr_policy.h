@@ -81,6 +81,10 @@ typedef struct mdr_actor {
 } mdr_actor_t;
 
 int64_t mdr_actor_steps1(int32_t layout, int32_t num_state);        /* S1 */
+/* S1 of an actor packed with feature_order = 1 (MDR_FEATURES_OBSERVE) for the exact-fp32 layouts: the k-steps its observe -> act
+ * kernel is compiled for - 13 (num_state <= 52, the default 51 included), 15 (<= 60) or 16 (<= 64); W1 columns past num_state are
+ * zeros.  Every other (layout, order): mdr_actor_steps1.  frag1 then holds S1 * (mdr_actor_frag1_floats / mdr_actor_steps1) units. */
+int64_t mdr_actor_steps1_order(int32_t layout, int32_t num_state, int32_t feature_order);
 int64_t mdr_actor_steps2(int32_t layout, int32_t hidden1);          /* S2 */
 int64_t mdr_actor_frag1_floats(int32_t layout, int32_t num_state);  /* size of frag1 in 4-byte units */
 int64_t mdr_actor_frag2_floats(int32_t layout, int32_t hidden1);    /* size of frag2 in 4-byte units */

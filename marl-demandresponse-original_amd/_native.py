@@ -142,7 +142,7 @@ EXPORTS = (
     "mdr_mailbox_bytes", "mdr_persist_records", "mdr_env_rollout_persistent",
     "mdr_mailbox_alloc", "mdr_mailbox_free", "mdr_mailbox_export", "mdr_mailbox_open", "mdr_mailbox_close", "mdr_mailbox_peek",
     # include/mdr_policy.h
-    "mdr_actor_steps1", "mdr_actor_steps2", "mdr_actor_frag1_floats", "mdr_actor_frag2_floats", "mdr_actor_sample", "mdr_env_actor_sample",
+    "mdr_actor_steps1", "mdr_actor_steps1_order", "mdr_actor_steps2", "mdr_actor_frag1_floats", "mdr_actor_frag2_floats", "mdr_actor_sample", "mdr_env_actor_sample",
     "mdr_discounted_returns",
 )
 
@@ -209,6 +209,7 @@ def load():
         "mdr_env_set_cursor": (C.c_int, [vp, u64, u32, i64, i64]),
         "mdr_env_active_tables": (C.c_int, [vp]),
         "mdr_actor_steps1": (i64, [i32, i32]),
+        "mdr_actor_steps1_order": (i64, [i32, i32, i32]),
         "mdr_actor_steps2": (i64, [i32, i32]),
         "mdr_actor_frag1_floats": (i64, [i32, i32]),
         "mdr_actor_frag2_floats": (i64, [i32, i32]),

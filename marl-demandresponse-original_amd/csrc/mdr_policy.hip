@@ -206,7 +206,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MDR_WAVES16 16
 #endif
 constexpr int WAVES16 = MDR_WAVES16;   // (-DMDR_WAVES16=12: experiment build)
-constexpr int WAVES16_EXT = 12;   // the extended observe -> act form: three waves per SIMD (168 registers; the fp32 forms level off at three waves)
+#ifndef MDR_WAVES16_EXT
+#define MDR_WAVES16_EXT 16
+#endif
+constexpr int WAVES16_EXT = MDR_WAVES16_EXT;   // the extended observe -> act form: four waves per SIMD as the default form (its rows are staged before layer 2, while that layer's accumulators do not exist yet); fewer where the windows do not fit the LDS
 
 // MDR_ACTOR_FRAG16T: the last of the MB blocks holds at most 4 hidden units (the reference's 100 = 6 x 16 + 4) and runs on
 // v_mfma_f32_4x4x1_16B_f32 instead - 16 independent 4x4 outer products, block = lane >> 2: D[v](lane) += A(lane (lane & ~3) + v) *
@@ -586,7 +589,7 @@ struct HouseRegs {
   unsigned fl;
   float sig, pw;
   float Ua, Cm, Ca, Hm, COP, latent;   // EXT: the thermal / hvac columns, already divided by their defaults
-  int e;                               // EXT: the house's env (its per-env columns are fetched when the row is staged)
+  float x_od, x_sd, x_cd, x_sh, x_ch, x_sol;   // EXT: the per-env columns (k_observe_env_extras)
 };
 
 __device__ __forceinline__ const double* observe_sig_row(const mdr::ObserveArgs& o) {
@@ -594,33 +597,137 @@ __device__ __forceinline__ const double* observe_sig_row(const mdr::ObserveArgs&
   return o.sig_now + (int64_t)min(o.cursor[0], o.cursor_max + 1) * o.E;   // as rebase(ObsArgs&) in mdr_kernels.hip
 }
 
-template <int TILE>
+// A load at a 32-bit byte offset from a wave-uniform base (`global_load v, voffset, s[base:base+1]`): the extended forms read up to 15
+// per-house arrays at ONE house index - one offset register instead of a 64-bit address per array (the launcher keeps 4 A below 2^32)
+template <class T>
+__device__ __forceinline__ T ld32(const T* base, uint32_t byte_offset) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_offset);
+}
+
+// the per-house / per-env columns of the extended form (thermal, hvac: per house, divided by their defaults; the rest: k_observe_env_extras)
+__device__ __forceinline__ void observe_load_extras(const mdr::ObserveArgs& o, HouseRegs& r, uint32_t i4, int e) {
+  if (o.f_thermal) {
+    r.x_od = o.env_extra_a[e];
+    r.Ua = ld32(o.Ua, i4) * o.inv_Ua;
+    r.Cm = ld32(o.Cm, i4) * o.inv_Cm;
+    r.Ca = ld32(o.Ca, i4) * o.inv_Ca;
+    r.Hm = ld32(o.Hm, i4) * o.inv_Hm;
+  }
+  if (o.f_hvac) {
+    r.COP = ld32(o.COP, i4) * o.inv_COP;
+    r.latent = ld32(o.latent, i4) * o.inv_latent;
+  }
+  if (o.f_day) {
+    r.x_sd = o.env_extra_a[(int64_t)o.E + e];
+    r.x_cd = o.env_extra_a[2 * (int64_t)o.E + e];
+  }
+  if (o.f_hour) {
+    r.x_sh = o.env_extra_a[3 * (int64_t)o.E + e];
+    r.x_ch = o.env_extra_b[e];
+  }
+  if (o.f_solar) r.x_sol = o.env_extra_b[(int64_t)o.E + e];
+}
+
+// the own features of the extended form in normStateDict order (obs_features() in mdr_kernels.hip), optional ones where they belong;
+// L and 1 / L behind them in the row's last two floats
+__device__ __forceinline__ void observe_write_own_ext(const mdr::ObserveArgs& o, const HouseRegs& r, float* row, int c, int ROW) {
+  const float L = (float)r.lk;
+  float* own = row + 4 * c;
+  int j = 0;
+  own[j++] = (r.Ta + o.obs_tshift) * 0.2f;
+  own[j++] = (r.Tm + o.obs_tshift) * 0.2f;
+  own[j++] = (r.tg + o.obs_tshift) * 0.2f;
+  if (o.f_thermal) own[j++] = r.x_od;
+  own[j++] = r.db;
+  if (o.f_day) {
+    own[j++] = r.x_sd;
+    own[j++] = r.x_cd;
+  }
+  if (o.f_hour) {
+    own[j++] = r.x_sh;
+    own[j++] = r.x_ch;
+  }
+  if (o.f_solar) own[j++] = r.x_sol;
+  own[j++] = r.cap * o.inv_cap;
+  if (o.f_thermal) {
+    own[j++] = r.Ua;
+    own[j++] = r.Cm;
+    own[j++] = r.Ca;
+    own[j++] = r.Hm;
+  }
+  if (o.f_hvac) {
+    own[j++] = r.COP;
+    own[j++] = r.latent;
+  }
+  own[j++] = (r.fl & 1u) ? 1.0f : 0.0f;
+  own[j++] = (r.fl & 2u) ? 1.0f : 0.0f;
+  own[j++] = (float)r.sso / L;
+  own[j++] = L / L;
+  own[j++] = r.sig;
+  own[j++] = r.pw;
+  row[ROW - 2] = L;
+  row[ROW - 1] = 1.0f / L;
+}
+
+// A tile of TILE consecutive agents inside ONE env (N a multiple of the tile): lane l stages the house at window position l, the window
+// being the tile's houses and the c around them (`before` of them in front; the default: 5 + 5)
+template <int TILE, bool EXT = false>
 __device__ __forceinline__ HouseRegs observe_load(const mdr::ObserveArgs& o, const double* sig_row, int e, int h0, int lane) {
+  const int before = EXT ? o.before : OBS_HALO, c = EXT ? o.c : 2 * OBS_HALO;
   HouseRegs r{};
-  if (lane < TILE + 2 * OBS_HALO) {
-    int hh = h0 - OBS_HALO + lane;
+  if (lane < TILE + c) {
+    int hh = h0 - before + lane;
     hh += hh < 0 ? o.N : 0;
     hh -= hh >= o.N ? o.N : 0;
     const int64_t i = (int64_t)e * o.N + hh;
-    r.Ta = o.Ta[i];
-    r.Tm = o.Tm[i];
-    r.tg = o.target[i];
-    r.db = o.deadband[i];
-    r.cap = o.capacity[i];
-    r.pm = o.P_max[i];
-    r.sso = o.sso[i];
-    r.lk = o.lockout[i];
-    r.fl = o.flags[i];
+    if (EXT) {
+      const uint32_t i1 = (uint32_t)i, i4 = i1 << 2;
+      r.Ta = ld32(o.Ta, i4);
+      r.Tm = ld32(o.Tm, i4);
+      r.tg = ld32(o.target, i4);
+      r.db = ld32(o.deadband, i4);
+      r.cap = ld32(o.capacity, i4);
+      r.pm = ld32(o.P_max, i4);
+      r.sso = ld32(o.sso, i4);
+      r.lk = ld32(o.lockout, i4);
+      r.fl = ld32(o.flags, i1);
+      observe_load_extras(o, r, i4, e);
+    } else {
+      r.Ta = o.Ta[i];
+      r.Tm = o.Tm[i];
+      r.tg = o.target[i];
+      r.db = o.deadband[i];
+      r.cap = o.capacity[i];
+      r.pm = o.P_max[i];
+      r.sso = o.sso[i];
+      r.lk = o.lockout[i];
+      r.fl = o.flags[i];
+    }
   }
   r.sig = (float)(sig_row[e] * o.inv_obs_norm);   // utils.py:832-841, per env
   r.pw = (float)(o.P[e] * o.inv_obs_norm);
   return r;
 }
 
-template <int TILE>
+template <int TILE, bool EXT = false, int ROWC = 0>
 __device__ __forceinline__ void observe_stage(const mdr::ObserveArgs& o, const HouseRegs& r, float* rows, int lane) {
-  if (lane >= TILE + 2 * OBS_HALO) return;
   const float4 rec = make_float4((r.Ta - r.tg) * 0.2f, (float)r.sso, ((r.fl & 1u) ? r.pm : 0.0f) * o.inv_norm_reg, r.pm * o.inv_norm_reg);
+  if (EXT) {
+    const int before = o.before, c = o.c;
+    constexpr int ROW = ROWC;
+    if (lane >= TILE + c) return;
+#pragma unroll
+    for (int m = 0; m < OBS_MAX_C; ++m) {
+      if (m >= c) break;
+      const int off = m < before ? m - before : m - before + 1;   // slot m listens to house h + off (env 816-828)
+      const int rr = lane - before - off;                         // ... so this house is slot m of the agent at tile row rr
+      if (rr >= 0 && rr < TILE) *reinterpret_cast<float4*>(rows + rr * ROW + 4 * m) = rec;
+    }
+    const int rr = lane - before;
+    if (rr >= 0 && rr < TILE) observe_write_own_ext(o, r, rows + rr * ROW, c, ROW);
+    return;
+  }
+  if (lane >= TILE + 2 * OBS_HALO) return;
 #pragma unroll
   for (int m = 0; m < OBS_C; ++m) {
     const int rr = lane - m - (m >= OBS_HALO ? 1 : 0);   // the agent this house is sender slot m of (env 816-828)
@@ -677,38 +784,39 @@ __device__ __forceinline__ HouseRegs observe_load_gen(const mdr::ObserveArgs& o,
   }
   if (slot.live) {
     const int64_t i = (int64_t)my_e * o.N + slot.j;
-    r.Ta = o.Ta[i];
-    r.Tm = o.Tm[i];
-    r.tg = o.target[i];
-    r.db = o.deadband[i];
-    r.cap = o.capacity[i];
-    r.pm = o.P_max[i];
-    r.sso = o.sso[i];
-    r.lk = o.lockout[i];
-    r.fl = o.flags[i];
+    if (EXT) {
+      const uint32_t i1 = (uint32_t)i, i4 = i1 << 2;
+      r.Ta = ld32(o.Ta, i4);
+      r.Tm = ld32(o.Tm, i4);
+      r.tg = ld32(o.target, i4);
+      r.db = ld32(o.deadband, i4);
+      r.cap = ld32(o.capacity, i4);
+      r.pm = ld32(o.P_max, i4);
+      r.sso = ld32(o.sso, i4);
+      r.lk = ld32(o.lockout, i4);
+      r.fl = ld32(o.flags, i1);
+      observe_load_extras(o, r, i4, my_e);
+    } else {
+      r.Ta = o.Ta[i];
+      r.Tm = o.Tm[i];
+      r.tg = o.target[i];
+      r.db = o.deadband[i];
+      r.cap = o.capacity[i];
+      r.pm = o.P_max[i];
+      r.sso = o.sso[i];
+      r.lk = o.lockout[i];
+      r.fl = o.flags[i];
+    }
     r.sig = (float)(sig_row[my_e] * o.inv_obs_norm);
     r.pw = (float)(o.P[my_e] * o.inv_obs_norm);
-    if (EXT) {
-      r.e = my_e;
-      if (o.f_thermal) {
-        r.Ua = o.Ua[i] * o.inv_Ua;
-        r.Cm = o.Cm[i] * o.inv_Cm;
-        r.Ca = o.Ca[i] * o.inv_Ca;
-        r.Hm = o.Hm[i] * o.inv_Hm;
-      }
-      if (o.f_hvac) {
-        r.COP = o.COP[i] * o.inv_COP;
-        r.latent = o.latent[i] * o.inv_latent;
-      }
-    }
   }
   return r;
 }
 
-template <bool EXT = false>
+template <bool EXT = false, int ROWC = 0>
 __device__ __forceinline__ void observe_stage_gen(const mdr::ObserveArgs& o, const HouseRegs& r, const SegSlot& slot, float* rows) {
   if (!slot.live) return;
-  const int ROW = EXT ? o.row : OBS_ROW;
+  const int ROW = ROWC ? ROWC : (EXT ? o.row : OBS_ROW);   // (the fp32 extended forms know their stride at compile time)
   const int before = EXT ? o.before : OBS_HALO, c = EXT ? o.c : OBS_C;
   const float4 rec = make_float4((r.Ta - r.tg) * 0.2f, (float)r.sso, ((r.fl & 1u) ? r.pm : 0.0f) * o.inv_norm_reg, r.pm * o.inv_norm_reg);
 #pragma unroll
@@ -723,45 +831,7 @@ __device__ __forceinline__ void observe_stage_gen(const mdr::ObserveArgs& o, con
   }
   const int k = slot.j - slot.hs;
   if (EXT) {
-    if (k >= 0 && k < slot.len) {   // the own features in normStateDict order (obs_features() in mdr_kernels.hip), optional ones where they belong
-      const float L = (float)r.lk;
-      float* row = rows + (slot.rb + k) * ROW;
-      float* own = row + 4 * c;
-      int j = 0;
-      own[j++] = (r.Ta + o.obs_tshift) * 0.2f;
-      own[j++] = (r.Tm + o.obs_tshift) * 0.2f;
-      own[j++] = (r.tg + o.obs_tshift) * 0.2f;
-      if (o.f_thermal) own[j++] = o.env_extra_a[r.e];
-      own[j++] = r.db;
-      if (o.f_day) {
-        own[j++] = o.env_extra_a[(int64_t)o.E + r.e];
-        own[j++] = o.env_extra_a[2 * (int64_t)o.E + r.e];
-      }
-      if (o.f_hour) {
-        own[j++] = o.env_extra_a[3 * (int64_t)o.E + r.e];
-        own[j++] = o.env_extra_b[r.e];
-      }
-      if (o.f_solar) own[j++] = o.env_extra_b[(int64_t)o.E + r.e];
-      own[j++] = r.cap * o.inv_cap;
-      if (o.f_thermal) {
-        own[j++] = r.Ua;
-        own[j++] = r.Cm;
-        own[j++] = r.Ca;
-        own[j++] = r.Hm;
-      }
-      if (o.f_hvac) {
-        own[j++] = r.COP;
-        own[j++] = r.latent;
-      }
-      own[j++] = (r.fl & 1u) ? 1.0f : 0.0f;
-      own[j++] = (r.fl & 2u) ? 1.0f : 0.0f;
-      own[j++] = (float)r.sso / L;
-      own[j++] = L / L;
-      own[j++] = r.sig;
-      own[j++] = r.pw;
-      row[ROW - 2] = L;
-      row[ROW - 1] = 1.0f / L;
-    }
+    if (k >= 0 && k < slot.len) observe_write_own_ext(o, r, rows + (slot.rb + k) * ROW, c, ROW);
     return;
   }
   if (k >= 0 && k < slot.len) {
@@ -1092,25 +1162,31 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
 }
 
 // ---- exact-fp32 form (v_mfma_f32_16x16x4_f32): 16 agents per wavefront, lane group g holds features [13 g, 13 g + 13) of its agent
-template <int MB, bool STORE, bool GEN, bool TAIL, bool EXT = false>
-__global__ __launch_bounds__(64 * (EXT ? WAVES16_EXT : WAVES16)) void k_actor_observe16(ActorArgs a, mdr::ObserveArgs o) {
-  constexpr int NW = EXT ? WAVES16_EXT : WAVES16;   // waves per workgroup
-  static_assert(!EXT || GEN, "the extended form stages through the general windows");
+// EXTK = 0: the default observation; 13 | 15 | 16: the extended form specialised for that many k-steps of layer 1 (features up to
+// 52 | 60 | 64) - the k-steps, the row stride and with it all window addressing are compile-time values as in the default form.
+constexpr int observe16_row(int extk) { return extk == 0 ? OBS_ROW : (((4 * extk + 2 + 3) & ~3) | 4); }   // 4 S1 + 2 floats as 4 x odd: 60 | 68 | 68
+template <int MB, bool STORE, bool GEN, bool TAIL, int EXTK = 0>
+__global__ __launch_bounds__(64 * (EXTK ? WAVES16_EXT : WAVES16)) void k_actor_observe16(ActorArgs a, mdr::ObserveArgs o) {
+  constexpr bool EXT = EXTK != 0;
+  const int NW = EXT ? (int)(blockDim.x >> 6) : WAVES16;   // waves per workgroup (the extended form: as many of its 16 as the windows leave room for)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TILE = 16;
-  const int ROW = EXT ? o.row : OBS_ROW, WIN = TILE * ROW + OBS_PAD;
-  const int S1 = EXT ? a.S1 : 13, F = EXT ? o.own + 4 * o.c : 51;   // lane group g holds features [S1 g, S1 g + S1) of its agent
-  float* f1 = lds;                       // [13][64][8]
-  // the extended form runs 16 k-steps of layer 1 whatever F is, over fragments zero-filled behind the packed S1 = ceil(F / 4): a
-  // run-time trip count would cut the unrolled ds_read / MFMA stream into a basic block per k-step
-  constexpr int S1L = EXT ? 16 : 13;
+  constexpr int ROW = observe16_row(EXTK), WIN = TILE * ROW + OBS_PAD;
+  // lane group g holds features [S1L g, S1L g + S1L) of its agent: actors in observe order are packed with exactly the 13 | 15 | 16
+  // k-steps of their form (steps1_order below; weights past F are zeros, the row floats they meet are the zeros the window starts with)
+  constexpr int S1L = EXT ? EXTK : 13;
+#ifndef MDR_EXT_STAGE_Q
+#define MDR_EXT_STAGE_Q -1
+#endif
+  constexpr int STAGE_Q = EXT ? MDR_EXT_STAGE_Q : 8;   // the k-step of layer 2 before which the next tile's rows are staged
+  const int F = EXT ? o.own + 4 * o.c : 51;
+  float* f1 = lds;                       // [S1L][64][8]
   float* f2 = f1 + S1L * 512;            // [S2][64][8]
   float* wd = f2 + a.S2 * 512;           // head weights + biases (512 floats reserved)
   const int tid = threadIdx.x;
   float* rows = wd + 512 + (tid >> 6) * WIN;
   uint16_t* table = reinterpret_cast<uint16_t*>(wd + 512 + NW * WIN);   // [TILE * 51] (only when rows are stored)
-  for (int i = tid * 4; i < S1L * 512; i += 64 * NW * 4)
-    *reinterpret_cast<float4*>(f1 + i) = i < S1 * 512 ? *reinterpret_cast<const float4*>(a.frag1 + i) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  for (int i = tid * 4; i < S1L * 512; i += 64 * NW * 4) *reinterpret_cast<float4*>(f1 + i) = *reinterpret_cast<const float4*>(a.frag1 + i);
   for (int i = tid * 4; i < a.S2 * 512; i += 64 * NW * 4) *reinterpret_cast<float4*>(f2 + i) = *reinterpret_cast<const float4*>(a.frag2 + i);
   for (int i = tid; i < 388; i += 64 * NW) wd[i] = a.wdiff[i];   // (a workgroup of the extended bf16 form has 384 threads)
   const int lane = tid & 63;
@@ -1148,10 +1224,7 @@ __global__ __launch_bounds__(64 * (EXT ? WAVES16_EXT : WAVES16)) void k_actor_ob
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 #pragma unroll
-    for (int s = 0; s < S1L; ++s) {
-      const float v = row[EXT ? min(S1 * g + s, ROW - 3) : 13 * g + s];   // (clamped: past the lane group's S1 features a finite float against a zero weight)
-      xr[s] = (!EXT || s < S1) ? v : 0.0f;
-    }
+    for (int s = 0; s < S1L; ++s) xr[s] = row[S1L * g + s];
     if (store) {
       observe_store_rows<TILE, EXT>(rows, table, a.rows_out + first_agent * F, lane,
                                     GEN ? (int)((a.A - first_agent) < (int64_t)TILE ? (a.A - first_agent) : (int64_t)TILE) : TILE, F);
@@ -1161,10 +1234,10 @@ __global__ __launch_bounds__(64 * (EXT ? WAVES16_EXT : WAVES16)) void k_actor_ob
   if (wave < a.ntiles) {
     if (GEN) {
       const HouseRegs first = observe_load_gen<TILE, EXT>(o, sig_row, tc.e, tc.h0, wave * TILE, a.A, lane, slot);
-      observe_stage_gen<EXT>(o, first, slot, rows);
+      observe_stage_gen<EXT, EXT ? ROW : 0>(o, first, slot, rows);
     } else {
-      const HouseRegs first = observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
-      observe_stage<TILE>(o, first, rows, lane);
+      const HouseRegs first = observe_load<TILE, EXT>(o, sig_row, tc.e, tc.h0, lane);
+      observe_stage<TILE, EXT, EXT ? ROW : 0>(o, first, rows, lane);
     }
     observe_window_fence();
     gather(wave * TILE);
@@ -1181,7 +1254,7 @@ __global__ __launch_bounds__(64 * (EXT ? WAVES16_EXT : WAVES16)) void k_actor_ob
     const bool more = t + nwaves < a.ntiles;
     tc.next();
     HouseRegs nxt{};
-    if (more) nxt = GEN ? observe_load_gen<TILE, EXT>(o, sig_row, tc.e, tc.h0, (t + nwaves) * TILE, a.A, lane, slot) : observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
+    if (more) nxt = GEN ? observe_load_gen<TILE, EXT>(o, sig_row, tc.e, tc.h0, (t + nwaves) * TILE, a.A, lane, slot) : observe_load<TILE, EXT>(o, sig_row, tc.e, tc.h0, lane);
     f32x4 acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[mb] = bias1[mb * 4];
@@ -1195,15 +1268,20 @@ __global__ __launch_bounds__(64 * (EXT ? WAVES16_EXT : WAVES16)) void k_actor_ob
       for (int mb = 0; mb < MB; ++mb) acc[mb] = mb == MB - 1 ? mma16<TAIL>(w[mb], xr[s], acc[mb]) : mma16<false>(w[mb], xr[s], acc[mb]);
     }
     if (TAIL) acc[MB - 1] = sum_lane_groups(acc[MB - 1]);
-    // ---- layer 2; the next tile's rows are staged after a few k-steps, read back at the end
+    // ---- layer 2; the next tile's rows are staged after a few k-steps, read back at the end (STAGE_Q < 0: before the layer starts,
+    // while the accumulators of layer 2 do not exist yet)
+    if (STAGE_Q < 0 && more) {
+      if (GEN) observe_stage_gen<EXT, EXT ? ROW : 0>(o, nxt, slot, rows);
+      else observe_stage<TILE, EXT, EXT ? ROW : 0>(o, nxt, rows, lane);
+    }
     f32x4 out[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) out[mb] = bias2[mb * 4];
 #pragma unroll
     for (int q = 0; q < 4 * MB; ++q) {
-      if (q == 8 && more) {
-        if (GEN) observe_stage_gen<EXT>(o, nxt, slot, rows);
-        else observe_stage<TILE>(o, nxt, rows, lane);
+      if (q == STAGE_Q && more) {
+        if (GEN) observe_stage_gen<EXT, EXT ? ROW : 0>(o, nxt, slot, rows);
+        else observe_stage<TILE, EXT, EXT ? ROW : 0>(o, nxt, rows, lane);
       }
       if (q < a.S2) {
         const float b = relu(TAIL && q >= 4 * (MB - 1) ? pick_register(acc[MB - 1], g) : acc[q >> 2][q & 3]);   // tail: k-index g is unit 96 + g
@@ -1271,6 +1349,14 @@ int steps1(int layout, int num_state) {
   return layout == MDR_ACTOR_FRAG16 || layout == MDR_ACTOR_FRAG16T ? (num_state + 3) / 4 : (num_state + 2) / 2;   // FRAG16: no constant-1 feature
 }
 
+// Actors packed in observe order (mdr_actor_t.feature_order = 1) for the exact-fp32 forms carry exactly the k-steps of layer 1 that
+// their observe -> act kernel is compiled for: 13 (up to 52 features; the default 51), 15 (up to 60) or 16 (up to 64).
+int steps1_order(int layout, int num_state, int order) {
+  const int s = steps1(layout, num_state);
+  if (order != 1 || (layout != MDR_ACTOR_FRAG16 && layout != MDR_ACTOR_FRAG16T) || s > 16) return s;
+  return s <= 13 ? 13 : (s <= 15 ? 15 : 16);
+}
+
 int steps2(int layout, int hidden1) {
   if (layout == MDR_ACTOR_BF16X3) return 4;                           // k-steps of two 16-row blocks each: all 8 stored blocks
   if (layout == MDR_ACTOR_FRAG16 || layout == MDR_ACTOR_FRAG16T) return 4 * (hidden1 / 16) + (hidden1 % 16 + 3) / 4;   // a partial last block is stored transposed: its first ceil(rem / 4) registers hold it
@@ -1331,19 +1417,20 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
   if (F > 64 || c > OBS_MAX_C || c < 0) return MDR_ERR_UNSUPPORTED;
   if (actor->hidden1 <= 0 || actor->hidden2 <= 0 || actor->hidden1 > MDR_ACTOR_MAX_HIDDEN || actor->hidden2 > MDR_ACTOR_MAX_HIDDEN) return MDR_ERR_INVALID;
   const bool lbf = layout == MDR_ACTOR_BF16X3;
-  const int tile = lbf ? 16 * NCB : 16, s1 = steps1(layout, actor->num_state);
+  const int tile = lbf ? 16 * NCB : 16, s1 = steps1_order(layout, actor->num_state, actor->feature_order);
   // row stride of the extended form: the floats the forward reads of a row (bf16: the features; fp32: four lane groups of S1) + L, 1 / L
   // ... as a multiple of 4 floats that is ODD in units of 4: the 16 lanes of a lane group read the same offset of 16 consecutive
   // rows, and a stride of 64 floats would put them all on one LDS bank (60 or 68: two lanes per bank)
   int row = OBS_ROW;
+  const int extk = !ext || lbf ? 0 : s1;   // the fp32 form's compile-time k-steps of layer 1: 13 | 15 | 16
   if (ext) {
-    row = ((lbf ? F : 4 * s1) + 2 + 3) & ~3;
+    row = ((lbf ? F : 4 * extk) + 2 + 3) & ~3;
     if ((row & 4) == 0) row += 4;
   }
   int waves = lbf ? WAVESB : (ext ? WAVES16_EXT : WAVES16);
   if (o.N < c + 1) return MDR_ERR_UNSUPPORTED;   // c distinct circular neighbours
   static const bool force_gen = [] { const char* t = getenv("MDR_OBSERVE_GEN"); return t && t[0] == '1'; }();   // experiment knob
-  const bool gen = ext || o.N % 32 != 0 || force_gen;     // tiles that start anywhere in an env / span several: the general staging
+  const bool gen = (ext && lbf) || o.N % 32 != 0 || force_gen;     // tiles that start anywhere in an env / span several: the general staging
   if (gen && observe_window_lanes(o.N, c, tile) > 64) return MDR_ERR_UNSUPPORTED;
   ActorArgs a{};
   a.frag1 = static_cast<const float*>(actor->frag1); a.frag2 = static_cast<const float*>(actor->frag2); a.wdiff = actor->wdiff;
@@ -1353,8 +1440,8 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
   a.A = (int64_t)o.E * o.N;
   a.ntiles = (a.A + tile - 1) / tile;
   if (a.ntiles > 0x7FFFFFFF) return MDR_ERR_UNSUPPORTED;   // the kernels count tiles in 32 bits
-  if (ext && o.defect_prob > 0.0f && a.A > 0x7FFFFFFF) return MDR_ERR_UNSUPPORTED;   // the defect draws take (env, house) from a 32-bit agent index
-  a.F = actor->num_state; a.S1 = steps1(layout, actor->num_state); a.S2 = steps2(layout, actor->hidden1);
+  if (ext && a.A > 0x3FFFFFFF) return MDR_ERR_UNSUPPORTED;   // the extended forms address a house's arrays by one 32-bit byte offset (and draw link defects from a 32-bit agent index)
+  a.F = actor->num_state; a.S1 = s1; a.S2 = steps2(layout, actor->hidden1);
   a.k0 = (uint32_t)(seed & 0xFFFFFFFFull); a.k1 = (uint32_t)(seed >> 32);
   a.step_lo = (uint32_t)(step & 0xFFFFFFFFull); a.step_hi = (uint32_t)(step >> 32);
   a.step_dev = step_dev;
@@ -1363,11 +1450,13 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
   oo.row = row;
   const size_t window = (size_t)tile * row + OBS_PAD;
   auto lds_need = [&](int w) {
-    const int s1_lds = ext ? (lbf ? 2 : 16) : a.S1;   // the extended form stages layer 1 zero-padded to its full k-step count
+    const int s1_lds = ext ? (lbf ? 2 : extk) : a.S1;   // the extended form stages layer 1 zero-padded to its full k-step count
     return ((size_t)(s1_lds + a.S2) * floats_per_step(layout) + 512 + (size_t)w * window) * sizeof(float) + (rows_out ? (size_t)tile * F * sizeof(uint16_t) : 0);
   };
   if (ext && lbf)   // the bf16 form keeps two waves per SIMD whatever the count: as many windows as fit beside the weight fragments
     while (waves > 4 && lds_need(waves) > 160 * 1024) --waves;
+  if (ext && !lbf)  // the fp32 form: whole waves per SIMD
+    while (waves > 8 && lds_need(waves) > 160 * 1024) waves -= 4;
   const size_t lds_bytes = lds_need(waves);
   if (lds_bytes > 160 * 1024) return MDR_ERR_UNSUPPORTED;
   if (ext && (o.f_thermal || o.f_day || o.f_hour || o.f_solar)) {   // the per-env columns, once per env
@@ -1390,9 +1479,15 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
       if (mb == 7) return rows_out ? launch(k_actor_observe_bf16<7, true, true, true>) : launch(k_actor_observe_bf16<7, false, true, true>);
       return rows_out ? launch(k_actor_observe_bf16<8, true, true, true>) : launch(k_actor_observe_bf16<8, false, true, true>);
     }
-    if (layout == MDR_ACTOR_FRAG16T) return rows_out ? launch(k_actor_observe16<7, true, true, true, true>) : launch(k_actor_observe16<7, false, true, true, true>);
-    if (mb == 7) return rows_out ? launch(k_actor_observe16<7, true, true, false, true>) : launch(k_actor_observe16<7, false, true, false, true>);
-    return rows_out ? launch(k_actor_observe16<8, true, true, false, true>) : launch(k_actor_observe16<8, false, true, false, true>);
+    if (extk != 13 && extk != 15 && extk != 16) return MDR_ERR_UNSUPPORTED;
+#define MDR_OBSERVE16_EXT_G(MBV, TAILV, GENV)                                                                                                        \
+  (extk == 13 ? (rows_out ? launch(k_actor_observe16<MBV, true, GENV, TAILV, 13>) : launch(k_actor_observe16<MBV, false, GENV, TAILV, 13>))   \
+   : extk == 15 ? (rows_out ? launch(k_actor_observe16<MBV, true, GENV, TAILV, 15>) : launch(k_actor_observe16<MBV, false, GENV, TAILV, 15>)) \
+                : (rows_out ? launch(k_actor_observe16<MBV, true, GENV, TAILV, 16>) : launch(k_actor_observe16<MBV, false, GENV, TAILV, 16>)))
+    // (the whole-tile staging for the reference's [100, 100] actor; other hidden sizes take the general windows whatever N is)
+    if (layout == MDR_ACTOR_FRAG16T) return gen ? MDR_OBSERVE16_EXT_G(7, true, true) : MDR_OBSERVE16_EXT_G(7, true, false);
+    return mb == 7 ? MDR_OBSERVE16_EXT_G(7, false, true) : MDR_OBSERVE16_EXT_G(8, false, true);
+#undef MDR_OBSERVE16_EXT_G
   }
 #define MDR_OBSERVE_VARIANT(KERNEL, ...)                                                                     \
   (rows_out ? (gen ? launch(KERNEL<__VA_ARGS__, true, true>) : launch(KERNEL<__VA_ARGS__, true, false>))   \
@@ -1412,6 +1507,9 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
 extern "C" {
 
 int64_t mdr_actor_steps1(int32_t layout, int32_t num_state) { return (layout_ok(layout) && num_state > 0) ? steps1(layout, num_state) : -1; }
+int64_t mdr_actor_steps1_order(int32_t layout, int32_t num_state, int32_t feature_order) {
+  return (layout_ok(layout) && num_state > 0) ? steps1_order(layout, num_state, feature_order) : -1;
+}
 int64_t mdr_actor_steps2(int32_t layout, int32_t hidden1) {
   return (layout_ok(layout) && hidden1 > 0 && hidden1 <= MDR_ACTOR_MAX_HIDDEN) ? steps2(layout, hidden1) : -1;
 }

@@ -73,7 +73,7 @@ class FusedActor:
         self.greedy = bool(greedy)      # argmax instead of a draw: the reference's DQNAgent.act on a DQN_network
         self.num_state, self.hidden1, self.hidden2 = int(F), int(H1), int(H2)
         self.device = torch.device(device)
-        S1 = int(self._lib.mdr_actor_steps1(self.layout, F))
+        S1 = int(self._lib.mdr_actor_steps1_order(self.layout, F, self.feature_order))   # observe order, fp32: 13 | 15 | 16 (zero-padded)
         S2 = int(self._lib.mdr_actor_steps2(self.layout, H1))
         if S1 < 0 or S2 < 0:
             raise ValueError("unknown layout %r" % (layout,))
@@ -125,7 +125,7 @@ class FusedActor:
         self._frag2 = frag2.contiguous().to(self.device)
         self._wdiff = wdiff.contiguous().to(self.device)
         assert self._wdiff.numel() == (128 if self.layout == FRAG32 else 388)
-        assert self._frag1.numel() == self._lib.mdr_actor_frag1_floats(self.layout, F)
+        assert self._frag1.numel() * self._lib.mdr_actor_steps1(self.layout, F) == self._lib.mdr_actor_frag1_floats(self.layout, F) * S1
         assert self._frag2.numel() == self._lib.mdr_actor_frag2_floats(self.layout, H1)
         self._desc = MdrActor(C.sizeof(MdrActor), self.layout, F, H1, H2, int(self.greedy), self.feature_order, self.observe_msg_floats, self._frag1.data_ptr(), self._frag2.data_ptr(),
                               self._wdiff.data_ptr())

@@ -30,6 +30,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="4096x1024")
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--cases", default="", help="comma-separated case indices (default: all); the default shape (0) is the reference time")
+    ap.add_argument("--precisions", default="fp32,bf16x3")
+    ap.add_argument("--observe-only", action="store_true", help="skip the rows + actor comparison (profiling runs)")
     args = ap.parse_args()
     import mdr_amd
     from mdr_amd.rollout import ActorMLP, collect_ppo_rollout
@@ -38,6 +41,8 @@ def main():
              ("every state column F=63", ("hour", "day", "solar_gain", "thermal", "hvac"), 10, 0.0), ("6 neighbours F=35", (), 6, 0.0),
              ("thermal + hvac, 10 % defects F=58", ("thermal", "hvac"), 10, 0.1))
     base = {}
+    if args.cases:
+        cases = tuple(cases[int(i)] for i in args.cases.split(","))
     for name, flags, c, defects in cases:
         cfg = mdr_amd.default_config()
         env_prop = cfg["default_env_prop"]
@@ -54,14 +59,15 @@ def main():
         torch.manual_seed(0)
         actor = ActorMLP(env.obs_vector_length()).to("cuda:0")
         row = {"shape": args.shape, "observation": name, "F": env.obs_vector_length()}
-        for prec in ("fp32", "bf16x3"):
-            for key, observe in (("observe_act", True), ("rows_then_actor", False)):
+        for prec in args.precisions.split(","):
+            for key, observe in ((("observe_act", True),) if args.observe_only else (("observe_act", True), ("rows_then_actor", False))):
                 collect_ppo_rollout(env, actor, 3, store_states=False, policy_precision=prec, observe_act=observe)
                 us = timeit(lambda: collect_ppo_rollout(env, actor, args.steps, store_states=False, policy_precision=prec, observe_act=observe)) / args.steps
                 row["%s_%s_us" % (key, prec)] = round(us, 1)
             if name.startswith("default"):
                 base[prec] = row["observe_act_%s_us" % prec]
-            row["vs_default_%s" % prec] = round(row["observe_act_%s_us" % prec] / base[prec], 3)
+            if prec in base:
+                row["vs_default_%s" % prec] = round(row["observe_act_%s_us" % prec] / base[prec], 3)
         print(json.dumps(row), flush=True)
         del env
         torch.cuda.empty_cache()
