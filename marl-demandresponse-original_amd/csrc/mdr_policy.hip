@@ -714,7 +714,7 @@ __device__ __forceinline__ void observe_stage(const mdr::ObserveArgs& o, const H
   const float4 rec = make_float4((r.Ta - r.tg) * 0.2f, (float)r.sso, ((r.fl & 1u) ? r.pm : 0.0f) * o.inv_norm_reg, r.pm * o.inv_norm_reg);
   if (EXT) {
     const int before = o.before, c = o.c;
-    constexpr int ROW = ROWC;
+    const int ROW = ROWC ? ROWC : o.row;   // (the fp32 forms know their stride at compile time)
     if (lane >= TILE + c) return;
 #pragma unroll
     for (int m = 0; m < OBS_MAX_C; ++m) {
@@ -957,7 +957,6 @@ struct TileCursor {
 template <int MB, bool STORE, bool GEN, bool EXT = false>
 __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a, mdr::ObserveArgs o) {
   const int NW = EXT ? (int)(blockDim.x >> 6) : WAVESB;   // waves per workgroup: the extended form takes as many as its windows leave room for (6 .. 8; two per SIMD either way)
-  static_assert(!EXT || GEN, "the extended form stages through the general windows");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int S2B = (MB + 1) / 2, TILE = 16 * NCB;
   const int ROW = EXT ? o.row : OBS_ROW, WIN = TILE * ROW + OBS_PAD;
@@ -1040,8 +1039,8 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
       const HouseRegs first = observe_load_gen<TILE, EXT>(o, sig_row, tc.e, tc.h0, (int64_t)wave * TILE, a.A, lane, slot);
       observe_stage_gen<EXT>(o, first, slot, rows);
     } else {
-      const HouseRegs first = observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
-      observe_stage<TILE>(o, first, rows, lane);
+      const HouseRegs first = observe_load<TILE, EXT>(o, sig_row, tc.e, tc.h0, lane);
+      observe_stage<TILE, EXT>(o, first, rows, lane);
     }
     observe_window_fence();
     gather((int64_t)wave * TILE);
@@ -1062,7 +1061,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
     const bool more = t + nwaves < ntiles;
     tc.next();
     HouseRegs nxt{};
-    if (more) nxt = GEN ? observe_load_gen<TILE, EXT>(o, sig_row, tc.e, tc.h0, (int64_t)(t + nwaves) * TILE, a.A, lane, slot) : observe_load<TILE>(o, sig_row, tc.e, tc.h0, lane);
+    if (more) nxt = GEN ? observe_load_gen<TILE, EXT>(o, sig_row, tc.e, tc.h0, (int64_t)(t + nwaves) * TILE, a.A, lane, slot) : observe_load<TILE, EXT>(o, sig_row, tc.e, tc.h0, lane);
     f32x4 acc[NCB][MB];
 #pragma unroll
     for (int c = 0; c < NCB; ++c)
@@ -1101,7 +1100,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
     for (int s = 0; s < S2B; ++s) {
       if (s == 1 && more) {
         if (GEN) observe_stage_gen<EXT>(o, nxt, slot, rows);
-        else observe_stage<TILE>(o, nxt, rows, lane);
+        else observe_stage<TILE, EXT>(o, nxt, rows, lane);
       }
       bf16x8 Bh[NCB], Bl[NCB];
 #pragma unroll
@@ -1430,7 +1429,7 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
   int waves = lbf ? WAVESB : (ext ? WAVES16_EXT : WAVES16);
   if (o.N < c + 1) return MDR_ERR_UNSUPPORTED;   // c distinct circular neighbours
   static const bool force_gen = [] { const char* t = getenv("MDR_OBSERVE_GEN"); return t && t[0] == '1'; }();   // experiment knob
-  const bool gen = (ext && lbf) || o.N % 32 != 0 || force_gen;     // tiles that start anywhere in an env / span several: the general staging
+  const bool gen = o.N % 32 != 0 || force_gen;     // tiles that start anywhere in an env / span several: the general staging
   if (gen && observe_window_lanes(o.N, c, tile) > 64) return MDR_ERR_UNSUPPORTED;
   ActorArgs a{};
   a.frag1 = static_cast<const float*>(actor->frag1); a.frag2 = static_cast<const float*>(actor->frag2); a.wdiff = actor->wdiff;
@@ -1476,8 +1475,11 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
   const int mb = blocks16(actor->hidden1, actor->hidden2);
   if (ext) {   // optional state columns / c != 10 / link defects: the general staging with run-time row shape
     if (lbf) {
-      if (mb == 7) return rows_out ? launch(k_actor_observe_bf16<7, true, true, true>) : launch(k_actor_observe_bf16<7, false, true, true>);
-      return rows_out ? launch(k_actor_observe_bf16<8, true, true, true>) : launch(k_actor_observe_bf16<8, false, true, true>);
+#define MDR_OBSERVE_BF16_EXT(MBV)                                                                                                    \
+  (gen ? (rows_out ? launch(k_actor_observe_bf16<MBV, true, true, true>) : launch(k_actor_observe_bf16<MBV, false, true, true>))    \
+       : (rows_out ? launch(k_actor_observe_bf16<MBV, true, false, true>) : launch(k_actor_observe_bf16<MBV, false, false, true>)))
+      return mb == 7 ? MDR_OBSERVE_BF16_EXT(7) : MDR_OBSERVE_BF16_EXT(8);
+#undef MDR_OBSERVE_BF16_EXT
     }
     if (extk != 13 && extk != 15 && extk != 16) return MDR_ERR_UNSUPPORTED;
 #define MDR_OBSERVE16_EXT_G(MBV, TAILV, GENV)                                                                                                        \
