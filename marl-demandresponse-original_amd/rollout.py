@@ -100,10 +100,6 @@ def _observe_act_supported(env, actor) -> bool:
             and actor.fc[0].in_features == F)
 
 
-def _has_defects(env) -> bool:
-    return float(env.config["default_env_prop"]["cluster_prop"]["comm_defect_prob"]) > 0.0
-
-
 def _fusable(actor) -> bool:
     fc = getattr(actor, "fc", None)
     if fc is None or len(fc) != 3 or not all(isinstance(m, nn.Linear) for m in fc):
@@ -144,8 +140,8 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
     ``seed`` with the env's step counter in the counter; otherwise torch GEMMs + ``torch.multinomial``.
     ``policy_precision="bf16x3"`` runs the fused kernel on bf16 matrix instructions with every operand split into a
     bf16 head and tail (16 significand bits; probabilities within ~1e-5 of the fp32 forward) - about 2.7x faster.
-    ``observe_act`` (default: for the reference's default observation - 51 features, 10 circular neighbours - and, with the
-    bf16x3 policy, for every shape the kernels cover: optional state columns, up to 13 circular neighbours, link defects):
+    ``observe_act`` (default: for every shape the kernels cover - the reference's default observation of 51 features and 10
+    circular neighbours, optional state columns, up to 13 circular neighbours, link defects):
     observation and policy are ONE kernel (``FusedActor.sample_env``): the 51 features of every agent are built in LDS from the
     compact state and fed to the matrix cores from there; with ``store_states`` the same kernel copies the rows into the
     transition buffer on the side (written once, never read back by the policy), without it they are not materialised at all.
@@ -170,11 +166,10 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
     if fused is None:
         fused = generator is None and _fusable(actor)
     if observe_act is None:
-        # the default observation: always; the extended shapes (optional state columns, another neighbour count, link defects) where
-        # the one-kernel form is the faster one - the split-bf16 policy (r03, 4096 x 1024: 665 against 854 us per step at F = 58); in
-        # exact fp32 their staging costs what the rows kernel costs (1514 against 1509 us)
-        observe_act = bool(fused) and _observe_act_supported(env, actor) and (
-            policy_precision == "bf16x3" or (env.obs_vector_length() == 51 and not _has_defects(env)))
+        # every shape the one-kernel form covers (the default observation; optional state columns, another neighbour count, link
+        # defects): it is the faster one in both precisions (r03, 4096 x 1024, F = 58: 1338 against 1507 us per step in exact fp32,
+        # 634 against 860 us with the split-bf16 policy)
+        observe_act = bool(fused) and _observe_act_supported(env, actor)
     if observe_act and not fused:
         raise ValueError("observe_act needs the fused policy")
     if fused:
