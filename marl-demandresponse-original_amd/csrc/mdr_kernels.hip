@@ -427,7 +427,10 @@ struct TableTile {
   int minutes;                       // minute slots per env
 };
 
-__global__ __launch_bounds__(256) void k_fill_tables_tile(TableArgs a, TableTile tl) {
+#ifndef MDR_TABLE_TILE_WAVES
+#define MDR_TABLE_TILE_WAVES 4
+#endif
+__global__ __launch_bounds__(256, MDR_TABLE_TILE_WAVES) void k_fill_tables_tile(TableArgs a, TableTile tl) {
   extern __shared__ uint32_t s_u[];                               // [slots][64] Philox words of the gradients
   __shared__ uint32_t s_first[TABLE_RUN_OCTAVES][TABLE_TILE_ENVS];
   __shared__ double s_odb[TABLE_TILE_MAX_MINUTES][TABLE_TILE_ENVS];
