@@ -81,3 +81,25 @@ def test_tile_tables_across_midnight_and_at_the_batch_edge():
             checked += 1
         big.rollout(65)
     assert checked == 12
+
+
+def test_tile_tables_take_an_outdoor_temperature_table():
+    """mdr_env_set_od_table rows (the reference's recorded draws, env 1057-1081 replaced) through the tile kernel: rows the table
+    covers come from it, the rows behind it from the model, as the per-entry kernel has them."""
+    import mdr_amd
+    E = 8192
+    cfg = _cfg("perlin", "noisy_sinusoidal_heatwave", 4)
+    g = torch.Generator().manual_seed(3)
+    od = 20.0 + 10.0 * torch.rand((100, E), generator=g, dtype=torch.float64)      # covers the first window and part of the second
+    big = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=9, table_steps=64)
+    big.set_od_table(od)
+    big.reset(episode=0)
+    off = 4100
+    small = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=8, device="cuda:0", seed=9, table_steps=64, env_offset=off)
+    small.set_od_table(od[:, off:off + 8])
+    small.reset(episode=0)
+    for rounds in range(3):
+        for name in ("tab_od", "tab_solar", "tab_signal", "tab_abs_noise"):
+            assert torch.equal(small.table(name), big.table(name)[:, off:off + 8]), (rounds, name)
+        big.rollout(65)
+        small.rollout(65)
