@@ -961,17 +961,26 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
   constexpr int S2B = (MB + 1) / 2, TILE = 16 * NCB;
   const int ROW = EXT ? o.row : OBS_ROW, WIN = TILE * ROW + OBS_PAD;
   const int F = EXT ? o.own + 4 * o.c : 51;
-  uint4* f1 = reinterpret_cast<uint4*>(lds);                    // [2][8][2][64] fragments of 8 bf16
+  // the packed fragments hold 8 row blocks per k-step; the extended form keeps only the MB it uses in LDS (MB = 7: 12 KB less, which
+  // is what lets eight 68-float windows fit beside them)
+  constexpr int BLK = EXT ? MB : 8, KSTEP = BLK * 128;          // row blocks / uint4 per k-step in LDS
+  uint4* f1 = reinterpret_cast<uint4*>(lds);                    // [2][BLK][2][64] fragments of 8 bf16
   const int S1B = EXT ? a.S1 : 2;                               // k-steps of layer 1: 32 features each (the extended form: one for F <= 32)
-  uint4* f2 = f1 + 2 * 1024;                                    // [S2B][8][2][64] (f1: both k-steps, the second zero-filled when S1B = 1)
-  float* wd = reinterpret_cast<float*>(f2 + S2B * 1024);        // head weights + biases (512 floats reserved)
+  uint4* f2 = f1 + 2 * KSTEP;                                   // [S2B][BLK][2][64] (f1: both k-steps, the second zero-filled when S1B = 1)
+  float* wd = reinterpret_cast<float*>(f2 + S2B * KSTEP);       // head weights + biases (512 floats reserved)
   const int tid = threadIdx.x;
   float* rows = wd + 512 + (tid >> 6) * WIN;                    // this wave's window
   uint16_t* table = reinterpret_cast<uint16_t*>(wd + 512 + NW * WIN);   // [TILE * 51] (only when rows are stored)
   const uint4* g1 = reinterpret_cast<const uint4*>(a.frag1);
   const uint4* g2 = reinterpret_cast<const uint4*>(a.frag2);
-  for (int i = tid; i < 2 * 1024; i += 64 * NW) f1[i] = i < S1B * 1024 ? g1[i] : uint4{0u, 0u, 0u, 0u};
-  for (int i = tid; i < S2B * 1024; i += 64 * NW) f2[i] = g2[i];
+  for (int i = tid; i < 2 * KSTEP; i += 64 * NW) {
+    const int st = i / KSTEP, in = i - st * KSTEP;               // k-step, offset inside it (in < BLK * 128: the first BLK blocks)
+    f1[i] = st < S1B ? g1[st * 1024 + in] : uint4{0u, 0u, 0u, 0u};
+  }
+  for (int i = tid; i < S2B * KSTEP; i += 64 * NW) {
+    const int st = i / KSTEP, in = i - st * KSTEP;
+    f2[i] = g2[st * 1024 + in];
+  }
   for (int i = tid; i < 388; i += 64 * NW) wd[i] = a.wdiff[i];   // (a workgroup of the extended bf16 form has 384 threads)
   const int lane = tid & 63;
   for (int i = lane; i < WIN; i += 64) rows[i] = 0.0f;          // pads are read (against zero weights): they must be finite
@@ -1080,8 +1089,8 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
       }
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        const bf16x8 Ah = __builtin_bit_cast(bf16x8, f1[((s * 8 + mb) * 2 + 0) * 64 + lane]);
-        const bf16x8 Al = __builtin_bit_cast(bf16x8, f1[((s * 8 + mb) * 2 + 1) * 64 + lane]);
+        const bf16x8 Ah = __builtin_bit_cast(bf16x8, f1[((s * BLK + mb) * 2 + 0) * 64 + lane]);
+        const bf16x8 Al = __builtin_bit_cast(bf16x8, f1[((s * BLK + mb) * 2 + 1) * 64 + lane]);
 #pragma unroll
         for (int c = 0; c < NCB; ++c) {
           acc[c][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh[c], acc[c][mb], 0, 0, 0);
@@ -1115,8 +1124,8 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
       }
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        const bf16x8 Ah = __builtin_bit_cast(bf16x8, f2[((s * 8 + mb) * 2 + 0) * 64 + lane]);
-        const bf16x8 Al = __builtin_bit_cast(bf16x8, f2[((s * 8 + mb) * 2 + 1) * 64 + lane]);
+        const bf16x8 Ah = __builtin_bit_cast(bf16x8, f2[((s * BLK + mb) * 2 + 0) * 64 + lane]);
+        const bf16x8 Al = __builtin_bit_cast(bf16x8, f2[((s * BLK + mb) * 2 + 1) * 64 + lane]);
 #pragma unroll
         for (int c = 0; c < NCB; ++c) {
           out[c][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh[c], out[c][mb], 0, 0, 0);
@@ -1450,7 +1459,9 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
   const size_t window = (size_t)tile * row + OBS_PAD;
   auto lds_need = [&](int w) {
     const int s1_lds = ext ? (lbf ? 2 : extk) : a.S1;   // the extended form stages layer 1 zero-padded to its full k-step count
-    return ((size_t)(s1_lds + a.S2) * floats_per_step(layout) + 512 + (size_t)w * window) * sizeof(float) + (rows_out ? (size_t)tile * F * sizeof(uint16_t) : 0);
+    size_t per_step = (size_t)floats_per_step(layout);
+    if (ext && lbf) per_step = per_step * (size_t)blocks16(actor->hidden1, actor->hidden2) / 8;   // ... and only the row blocks it uses
+    return ((size_t)(s1_lds + a.S2) * per_step + 512 + (size_t)w * window) * sizeof(float) + (rows_out ? (size_t)tile * F * sizeof(uint16_t) : 0);
   };
   if (ext && lbf)   // the bf16 form keeps two waves per SIMD whatever the count: as many windows as fit beside the weight fragments
     while (waves > 4 && lds_need(waves) > 160 * 1024) --waves;
