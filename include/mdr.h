@@ -64,9 +64,13 @@ typedef enum mdr_penalty_mode {
 
 typedef enum mdr_action_source {
   MDR_ACTIONS_EXTERNAL = 0, /* read uint8 actions[E][N] (truthy = ON), ClusterHouses.step 1026-1033 */
-  MDR_ACTIONS_BANGBANG = 1  /* on iff house_temp > target (agents/bangbang_controllers.py:41-61),
+  MDR_ACTIONS_BANGBANG = 1, /* on iff house_temp > target (BangBangController, agents/bangbang_controllers.py:41-61),
                                evaluated in-kernel on the pre-step observation; the chosen action is
                                written to actions[E][N] when that pointer is not NULL */
+  MDR_ACTIONS_DEADBAND = 2, /* off below target - deadband / 2, on above target + deadband / 2, else what the HVAC is doing
+                               (hvac_turned_on): DeadbandBangBangController and BasicController, agents/bangbang_controllers.py:13-38,
+                               64-88 (the same rule twice); in-kernel like MDR_ACTIONS_BANGBANG */
+  MDR_ACTIONS_ALWAYS_ON = 3 /* AlwaysOnController, agents/bangbang_controllers.py:1-10 (the lockout still applies) */
 } mdr_action_source;
 
 /* Flat restatement of the config.py entries the path consumes. */
@@ -295,6 +299,11 @@ typedef struct mdr_rollout_out {
 /* Shapes without an env-per-workgroup kernel (N > 2048, or N > 512 with N % 4 != 0) are run as single steps with the
  * same accumulators (same results, no fusion).  Returns MDR_ERR_UNSUPPORTED for sharded houses: use mdr_env_rollout. */
 int mdr_env_rollout_fused(mdr_env_t *env, uint8_t *actions, int32_t nb_steps, const mdr_rollout_out_t *out, void *stream);
+
+/* The controller of the closed-loop rollouts that take no action_source (mdr_env_rollout_fused, mdr_env_rollout_persistent):
+ * MDR_ACTIONS_BANGBANG (the default), MDR_ACTIONS_DEADBAND or MDR_ACTIONS_ALWAYS_ON - the reference's
+ * agents/bangbang_controllers.py classes as main-deploy.py:57-104 drives them.  -1 for anything else. */
+int mdr_env_set_controller(mdr_env_t *env, int action_source);
 
 /* Sharded houses (one env spans several devices).  Houses interact only through the cluster power sum (env 1042-1050)
  * and the common penalty sum / max (env 274-321): step_begin updates the local houses and leaves the local

@@ -455,6 +455,23 @@ class BatchedDemandResponseEnv:
         self._step(self.t["actions"].data_ptr(), nat.ACTIONS_BANGBANG)
         return self.t["obs"], self.t["reward"], self.done, {"cluster_hvac_power": self.t["P"]}
 
+    def set_controller(self, kind: str = "bangbang") -> None:
+        """The rule-based controller the closed loops apply in-kernel when no actions are handed over (``step_controller``,
+        ``rollout``, ``rollout_fused``, ``rollout_persistent``) - the classes of agents/bangbang_controllers.py as main-deploy.py
+        drives them: "bangbang" (BangBangController: on iff hotter than the target; the default), "deadband" / "basic"
+        (DeadbandBangBangController == BasicController: off below target - deadband / 2, on above target + deadband / 2, otherwise
+        what the HVAC is doing), "always_on" (AlwaysOnController)."""
+        if kind not in nat.CONTROLLERS:
+            raise ValueError("unknown controller %r (one of %s)" % (kind, ", ".join(sorted(nat.CONTROLLERS))))
+        rc = self._lib.mdr_env_set_controller(self._handle, nat.CONTROLLERS[kind])
+        nat.check(self._lib, self._handle, rc, "mdr_env_set_controller")
+        self._controller = nat.CONTROLLERS[kind]
+
+    def step_controller(self):
+        """One step with the controller of ``set_controller`` evaluated in-kernel; the actions taken land in ``self.t['actions']``."""
+        self._step(self.t["actions"].data_ptr(), getattr(self, "_controller", nat.ACTIONS_BANGBANG))
+        return self.t["obs"], self.t["reward"], self.done, {"cluster_hvac_power": self.t["P"]}
+
     SHARD_GRAPH_UNROLLS = (16, 4)      # steps per captured graph (a graph launch costs ~10 us, a hop between its nodes ~2 us); leftovers before a table refill go 4 at a time, then singly
 
     def _rollout_sharded_graph(self, nb_steps: int, ptr: int, source: int) -> None:
@@ -497,14 +514,16 @@ class BatchedDemandResponseEnv:
             done += reps * unroll
 
     def rollout(self, nb_steps: int, actions: Optional[torch.Tensor] = None):
-        """nb_steps consecutive launches without returning to Python (bang-bang unless ``actions`` is given)."""
+        """nb_steps consecutive launches without returning to Python (the controller of ``set_controller`` - bang-bang by default -
+        unless ``actions`` is given)."""
+        ctl = getattr(self, "_controller", nat.ACTIONS_BANGBANG)
         if self.sharded:
-            source = nat.ACTIONS_EXTERNAL if actions is not None else nat.ACTIONS_BANGBANG
+            source = nat.ACTIONS_EXTERNAL if actions is not None else ctl
             if self.graph_mode and self.spec.base_power_mode != 1 and getattr(self._exchange(), "capturable", False):
                 return self._rollout_sharded_graph(int(nb_steps), self._actions_ptr(actions), source)
             self._steps_sharded(int(nb_steps), self._actions_ptr(actions), source)
             return
-        src = nat.ACTIONS_EXTERNAL if actions is not None else nat.ACTIONS_BANGBANG
+        src = nat.ACTIONS_EXTERNAL if actions is not None else ctl
         with torch.cuda.device(self.device):
             rc = self._lib.mdr_env_rollout(self._handle, C.c_void_p(self._actions_ptr(actions)), src, int(nb_steps), self._stream())
             nat.check(self._lib, self._handle, rc, "mdr_env_rollout")
@@ -937,6 +956,8 @@ class BatchedDemandResponseEnv:
         if getattr(self, "_links_forced", False):
             other.set_comm_links(self._links_global)
         other.episode = self.episode      # 'random_fixed' derives its link table from (seed, episode)
+        if hasattr(self, "_controller"):
+            other.set_controller(next(k for k, v in nat.CONTROLLERS.items() if v == self._controller))
         if self.episode >= 0:
             other.load_state_dict(self.state_dict())
         return other

@@ -44,6 +44,7 @@ struct mdr_env {
   int64_t prefetch_j0 = -1;
   hipStream_t side = nullptr;
   hipEvent_t ev_fill = nullptr, ev_free = nullptr;
+  int controller = MDR_ACTIONS_BANGBANG;   // the rule the rollouts without an action_source apply (mdr_env_set_controller)
   uint32_t mailbox_tag = 1;     // persistent rollout: tag of the next step pushed through the mailbox (counts over the handle's life; 0 = never written)
   std::string err;
 };
@@ -346,7 +347,7 @@ int step_args(mdr_env* env, uint8_t* actions, int action_source, hipStream_t s, 
   const mdr_config_t& c = env->cfg;
   if (!env->bound) return fail(env, MDR_ERR_UNBOUND, "buffers not bound");
   if (!env->has_tables) return fail(env, MDR_ERR_UNBOUND, "no episode: call reset/load_episode and begin_episode first");
-  if (action_source != MDR_ACTIONS_EXTERNAL && action_source != MDR_ACTIONS_BANGBANG)
+  if (action_source < MDR_ACTIONS_EXTERNAL || action_source > MDR_ACTIONS_ALWAYS_ON)
     return fail(env, MDR_ERR_INVALID, "unknown action_source");
   if (action_source == MDR_ACTIONS_EXTERNAL && !actions) return fail(env, MDR_ERR_INVALID, "actions is NULL");
   if (actions && c.nb_houses % 4 == 0 && ((uintptr_t)actions & 3u) != 0)  // uchar4 accesses when N % 4 == 0
@@ -768,11 +769,11 @@ int mdr_env_rollout_fused(mdr_env_t* env, uint8_t* actions, int32_t nb_steps, co
   if (!mdr::rollout_fused_supported(env->rollout_plan)) {
     // no env-per-workgroup kernel for this shape (N > 2048, or N > 512 with N % 4 != 0): single steps, same accumulators
     for (int32_t i = 0; i < nb_steps; ++i) {
-      int rc = mdr_env_step(env, actions, MDR_ACTIONS_BANGBANG, stream);
+      int rc = mdr_env_step(env, actions, env->controller, stream);
       if (rc != MDR_OK) return rc;
       if (!out) continue;
       mdr::StepArgs a;
-      rc = step_args(env, actions, MDR_ACTIONS_BANGBANG, (hipStream_t)stream, &a);   // rows of the new time index
+      rc = step_args(env, actions, env->controller, (hipStream_t)stream, &a);   // rows of the new time index
       if (rc != MDR_OK) return rc;
       mdr::RolloutArgs r{};
       r.nsteps = 1;
@@ -788,7 +789,7 @@ int mdr_env_rollout_fused(mdr_env_t* env, uint8_t* actions, int32_t nb_steps, co
   int32_t done = 0;
   while (done < nb_steps) {
     mdr::StepArgs a;
-    int rc = step_args(env, actions, MDR_ACTIONS_BANGBANG, (hipStream_t)stream, &a);   // refills the tables if the cursor left them
+    int rc = step_args(env, actions, env->controller, (hipStream_t)stream, &a);   // refills the tables if the cursor left them
     if (rc != MDR_OK) return rc;
     int64_t room = env->cfg.table_steps - (env->k - env->j0);   // steps the current tables still cover
     if (interp_mode(env)) room = std::min<int64_t>(room, env->interp_steps - (env->k - env->j0));   // stop at the next update
@@ -808,6 +809,14 @@ int mdr_env_rollout_fused(mdr_env_t* env, uint8_t* actions, int32_t nb_steps, co
     rc = interp_boundary(env, (hipStream_t)stream, out ? out->sq_signal_error_sum : nullptr);
     if (rc != MDR_OK) return rc;
   }
+  return MDR_OK;
+}
+
+int mdr_env_set_controller(mdr_env_t* env, int action_source) {
+  if (!env) return MDR_ERR_INVALID;
+  if (action_source != MDR_ACTIONS_BANGBANG && action_source != MDR_ACTIONS_DEADBAND && action_source != MDR_ACTIONS_ALWAYS_ON)
+    return fail(env, MDR_ERR_INVALID, "controller: MDR_ACTIONS_BANGBANG, MDR_ACTIONS_DEADBAND or MDR_ACTIONS_ALWAYS_ON");
+  env->controller = action_source;
   return MDR_OK;
 }
 
@@ -859,7 +868,7 @@ int mdr_env_rollout_persistent(mdr_env_t* env, uint8_t* actions, int32_t nb_step
   int32_t done = 0;
   while (done < nb_steps) {
     mdr::StepArgs a;
-    int rc = step_args(env, actions, MDR_ACTIONS_BANGBANG, s, &a);   // refills the tables if the cursor left them
+    int rc = step_args(env, actions, env->controller, s, &a);   // refills the tables if the cursor left them
     if (rc != MDR_OK) return rc;
     const int64_t room = c.table_steps - (env->k - env->j0);
     mdr::RolloutArgs r{};

@@ -776,7 +776,7 @@ __global__ __launch_bounds__(THREADS) void k_rollout_fused(StepArgs a, RolloutAr
         float p = 0.0f, ps = 0.0f, te = 0.0f;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          const bool cmd = hs[t][v].Ta > hs[t][v].target;   // agents/bangbang_controllers.py:49-59
+          const bool cmd = controller_cmd(a.action_source, hs[t][v].Ta, hs[t][v].target, hs[t][v].deadband, hs[t][v].flags);   // agents/bangbang_controllers.py
           act[t][v] = cmd ? 1u : 0u;
           o[t][v] = house_step(hs[t][v], cmd, od_old, solar, a.dt);
           hs[t][v].Ta = o[t][v].Ta;
@@ -930,8 +930,8 @@ __global__ __launch_bounds__(256) void k_step_single_house(StepArgs a) {
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     HouseIn h{Ta[v], Tm[v], sso[v], fl[v], k01[v], s0[v], k10[v], s1[v], iu[v], q[v], pm[v], tg[v], db[v], lk[v]};
-    const bool cmd = (a.action_source == MDR_ACTIONS_BANGBANG) ? (Ta[v] > tg[v]) : (act[v] != 0u);
-    if (a.action_source == MDR_ACTIONS_BANGBANG) act[v] = cmd ? 1u : 0u;
+    const bool cmd = (a.action_source == MDR_ACTIONS_EXTERNAL) ? (act[v] != 0u) : controller_cmd(a.action_source, Ta[v], tg[v], db[v], fl[v]);
+    if (a.action_source != MDR_ACTIONS_EXTERNAL) act[v] = cmd ? 1u : 0u;
     o[v] = house_step(h, cmd, od[v], solar[v], a.dt);
     nTa[v] = o[v].Ta;
     nTm[v] = o[v].Tm;
@@ -948,7 +948,7 @@ __global__ __launch_bounds__(256) void k_step_single_house(StepArgs a) {
   store_vec<4>(a.Tm, e0, nTm);
   store_vec<4>(a.sso, e0, nsso);
   store_bytes<4>(a.flags, e0, nfl);
-  if (a.action_source == MDR_ACTIONS_BANGBANG && a.actions != nullptr) store_bytes<4>(a.actions, e0, act);
+  if (a.action_source != MDR_ACTIONS_EXTERNAL && a.actions != nullptr) store_bytes<4>(a.actions, e0, act);
   store_obs_local<4>(a, e0, o, lk);
   store_out<4>(a.reward, e0, rew);
   if (a.obs != nullptr) {
@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs r
       float p = 0.0f, ps = 0.0f, te = 0.0f;
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        const bool cmd = hs[v].Ta > hs[v].target;
+        const bool cmd = controller_cmd(a.action_source, hs[v].Ta, hs[v].target, hs[v].deadband, hs[v].flags);
         act[v] = cmd ? 1u : 0u;
         o[v] = house_step(hs[v], cmd, er.od, er.solar, a.dt);
         hs[v].Ta = o[v].Ta;

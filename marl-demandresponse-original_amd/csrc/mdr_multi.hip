@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_rollout_multi(StepArgs a, RolloutArgs r
       for (int v = 0; v < 4; ++v) {
         if (v >= m.nv) continue;
         const bool first = m.q[v] == m.q[0];
-        const bool cmd = hs[v].Ta > hs[v].target;
+        const bool cmd = controller_cmd(a.action_source, hs[v].Ta, hs[v].target, hs[v].deadband, hs[v].flags);
         act[v] = cmd ? 1u : 0u;
         o[v] = house_step(hs[v], cmd, first ? od_a : od_b, first ? so_a : so_b, a.dt);
         hs[v].Ta = o[v].Ta;
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void k_rollout_packed(StepArgs a, RolloutArgs 
       float p = 0.0f, ps = 0.0f, te = 0.0f;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const bool cmd = hs[v].Ta > hs[v].target;
+        const bool cmd = controller_cmd(a.action_source, hs[v].Ta, hs[v].target, hs[v].deadband, hs[v].flags);
         act[v] = cmd ? 1u : 0u;
         o[v] = house_step(hs[v], cmd, od, solar, a.dt);
         hs[v].Ta = o[v].Ta;

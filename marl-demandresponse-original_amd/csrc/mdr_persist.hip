@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
         float p = 0.0f, ps = 0.0f, te = 0.0f;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          const bool cmd = hs[v].Ta > hs[v].target;   // agents/bangbang_controllers.py:49-59
+          const bool cmd = controller_cmd(a.action_source, hs[v].Ta, hs[v].target, hs[v].deadband, hs[v].flags);   // agents/bangbang_controllers.py
           act[v] = cmd ? 1u : 0u;
           const HouseOut o = house_step(hs[v], cmd, od_old, solar, a.dt);
           hs[v].Ta = o.Ta;

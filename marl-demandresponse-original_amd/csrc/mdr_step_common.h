@@ -145,6 +145,17 @@ __device__ __forceinline__ void store_bytes(uint8_t* __restrict__ p, int64_t i, 
 
 // Loads VEC houses starting at flat index i, steps them, stores the new state, returns outputs.  od_old[v] / solar[v]: the table
 // values of house v's env (one env per call in most kernels; k_step_multi's lanes may hold the end of one env and the start of the next).
+// The reference's rule-based controllers on the pre-step observation (agents/bangbang_controllers.py): BangBangController 41-61,
+// DeadbandBangBangController 13-38 == BasicController 64-88, AlwaysOnController 1-10.  `src` is wave-uniform.
+__device__ __forceinline__ bool controller_cmd(int src, float Ta, float target, float deadband, unsigned flags) {
+  if (src == MDR_ACTIONS_BANGBANG) return Ta > target;
+  if (src == MDR_ACTIONS_DEADBAND) {
+    const float half = 0.5f * deadband;
+    return Ta < target - half ? false : (Ta > target + half ? true : (flags & 1u) != 0u);
+  }
+  return true;   // MDR_ACTIONS_ALWAYS_ON
+}
+
 template <int VEC>
 __device__ __forceinline__ void step_vec_rows(const StepArgs& a, int64_t i, const float* od_old, const float* solar, HouseOut* out, int* lockout) {
   float Ta[VEC], Tm[VEC], k01[VEC], s0[VEC], k10[VEC], s1[VEC], iu[VEC], q[VEC], pm[VEC], tg[VEC], db[VEC];
@@ -171,9 +182,9 @@ __device__ __forceinline__ void step_vec_rows(const StepArgs& a, int64_t i, cons
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
     HouseIn h{Ta[v], Tm[v], sso[v], fl[v], k01[v], s0[v], k10[v], s1[v], iu[v], q[v], pm[v], tg[v], db[v], lockout[v]};
-    // BangBangController.act (agents/bangbang_controllers.py:49-59) on the pre-step observation
-    const bool cmd = (a.action_source == MDR_ACTIONS_BANGBANG) ? (Ta[v] > tg[v]) : (act[v] != 0u);
-    if (a.action_source == MDR_ACTIONS_BANGBANG) act[v] = cmd ? 1u : 0u;
+    // the in-kernel controllers act on the pre-step observation (agents/bangbang_controllers.py)
+    const bool cmd = (a.action_source == MDR_ACTIONS_EXTERNAL) ? (act[v] != 0u) : controller_cmd(a.action_source, Ta[v], tg[v], db[v], fl[v]);
+    if (a.action_source != MDR_ACTIONS_EXTERNAL) act[v] = cmd ? 1u : 0u;
     out[v] = house_step(h, cmd, od_old[v], solar[v], a.dt);
     nTa[v] = out[v].Ta;
     nTm[v] = out[v].Tm;
@@ -189,7 +200,7 @@ __device__ __forceinline__ void step_vec_rows(const StepArgs& a, int64_t i, cons
 #endif
   store_vec<VEC>(a.sso, i, nsso);
   store_bytes<VEC>(a.flags, i, nfl);
-  if (a.action_source == MDR_ACTIONS_BANGBANG && a.actions != nullptr) store_bytes<VEC>(a.actions, i, act);
+  if (a.action_source != MDR_ACTIONS_EXTERNAL && a.actions != nullptr) store_bytes<VEC>(a.actions, i, act);
 }
 
 template <int VEC>

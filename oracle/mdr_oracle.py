@@ -819,3 +819,13 @@ class OracleEnv:
     def bangbang_actions(self):
         """agents/bangbang_controllers.py:41-61: on iff house_temp > target."""
         return self.Ta > self.target
+
+    def deadband_actions(self):
+        """agents/bangbang_controllers.py:13-38 (DeadbandBangBangController) == 64-88 (BasicController): off below
+        target - deadband / 2, on above target + deadband / 2, else hvac_turned_on."""
+        half = self.deadband / 2
+        return np.where(self.Ta < self.target - half, False, np.where(self.Ta > self.target + half, True, self.on.astype(bool)))
+
+    def always_on_actions(self):
+        """agents/bangbang_controllers.py:1-10 (AlwaysOnController)."""
+        return np.ones(self.Ta.shape, dtype=bool)

@@ -76,7 +76,7 @@ _loaded = {}
 
 
 def load_reference():
-    """Returns a namespace dict: MADemandResponseEnv, config_dict, utils, BangBangController."""
+    """Returns a namespace dict: MADemandResponseEnv, config_dict, utils and the rule-based controllers of agents/bangbang_controllers.py."""
     if _loaded:
         return _loaded
     if not available():
@@ -89,9 +89,11 @@ def load_reference():
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
     from env.MA_DemandResponse import MADemandResponseEnv, HVAC  # noqa: E402
-    from agents.bangbang_controllers import BangBangController    # noqa: E402
+    from agents.bangbang_controllers import (AlwaysOnController, BangBangController, BasicController,   # noqa: E402
+                                             DeadbandBangBangController)
     from config import config_dict                                # noqa: E402
     import utils as ref_utils                                     # noqa: E402
     _loaded.update(MADemandResponseEnv=MADemandResponseEnv, HVAC=HVAC, config_dict=config_dict,
-                   utils=ref_utils, BangBangController=BangBangController)
+                   utils=ref_utils, BangBangController=BangBangController, DeadbandBangBangController=DeadbandBangBangController,
+                   BasicController=BasicController, AlwaysOnController=AlwaysOnController)
     return _loaded

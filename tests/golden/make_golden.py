@@ -174,6 +174,11 @@ def run_scenario(name, patches, seed, T, policy, perlin=False, norm_steps=(0, 1,
     for t in range(T):
         if policy == "bangbang":
             a = ref["utils"].get_actions(actors, obs)
+        elif policy in ("deadband", "basic", "always_on"):      # the reference's other rule-based controllers, acting on its own obs
+            cls = {"deadband": "DeadbandBangBangController", "basic": "BasicController", "always_on": "AlwaysOnController"}[policy]
+            others = {i: ref[cls]({"id": i}, cfg) for i in range(N)}
+            # (AlwaysOnController.act returns True whatever it is handed; the other two index obs by their id themselves)
+            a = {i: others[i].act(obs) for i in range(N)}
         elif policy == "on":
             a = {i: True for i in range(N)}
         elif policy == "off":
@@ -406,7 +411,20 @@ def main():
         perlin=True, extra=gx)
     # N == 1 (config.py's literal default nb_agents) and no neighbours
     run_scenario("s9_single_house", {CL + "nb_agents": 1, PG + "signal_mode": "sinusoidals"}, 61, 200, "bangbang")
+    main_controllers()
+
+
+def main_controllers():
+    """Only the S14 fixtures (python tests/golden/make_golden.py s14): added in round 3, the others stay as they were generated."""
+    # S14: the other controllers of agents/bangbang_controllers.py in the loop (deadbands of 1-2 degrees so that the hold band is visited)
+    run_scenario("s14_controller_deadband", {CL + "nb_agents": 12, PG + "signal_mode": "sinusoidals", "default_house_prop.deadband": 1.0,
+                                             "noise_house_prop.noise_mode": "big_noise", "default_hvac_prop.lockout_noise": 10}, 71, 600, "deadband")
+    run_scenario("s14_controller_basic", {CL + "nb_agents": 6, PG + "signal_mode": "flat", "default_house_prop.deadband": 2.0}, 72, 400, "basic")
+    run_scenario("s14_controller_always_on", {CL + "nb_agents": 5, PG + "signal_mode": "flat"}, 73, 150, "always_on")
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["s14"]:
+        main_controllers()
+    else:
+        main()

@@ -1,0 +1,117 @@
+"""The reference's rule-based controllers evaluated in-kernel (agents/bangbang_controllers.py: BangBangController 41-61,
+DeadbandBangBangController 13-38 == BasicController 64-88, AlwaysOnController 1-10; main-deploy.py:57-104 drives them): the
+closed loop on the device against the S14 fixtures - the reference env under the reference's own controller objects - and the
+rollout forms (single launches, fused, split, persistent) against single steps."""
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+KIND = {"s14_controller_deadband": "deadband", "s14_controller_basic": "basic", "s14_controller_always_on": "always_on"}
+
+
+def _env_for(g):
+    import mdr_amd
+    env = mdr_amd.BatchedDemandResponseEnv(g.config, nb_envs=1, device="cuda:0", seed=g.seed, table_steps=64)
+    env.load_episode(g.params(), od_table=g.od_table(), seed=g.seed, episode=0)
+    return env
+
+
+@pytest.mark.parametrize("name", sorted(KIND))
+def test_closed_loop_reproduces_the_reference_under_its_own_controller(name):
+    """No actions are fed: the kernel decides from its own fp32 state.  Actions, HVAC state and power bit for bit, temperatures and
+    rewards to the tolerances of the recorded-action fixtures (a decision within fp32 noise of a band edge would fork the
+    trajectory: these fixtures hold none - the assertion on the actions would say so)."""
+    g = gu.Golden(name)
+    a = g.a
+    env = _env_for(g)
+    env.set_controller(KIND[name])
+    for t in range(g.T):
+        _, reward, _, info = env.step_controller()
+        assert np.array_equal(env.t["actions"][0].cpu().numpy(), a["actions"][t]), t
+        fl = env.t["flags"][0].cpu().numpy()
+        assert np.array_equal(fl & 1, a["on"][t]) and np.array_equal((fl >> 1) & 1, a["lock"][t]), t
+        assert info["cluster_hvac_power"][0].item() == a["P"][t]
+        np.testing.assert_allclose(env.house_temp()[0].cpu().numpy(), a["Ta"][t], rtol=1e-5, atol=0)
+        np.testing.assert_allclose(reward[0].cpu().numpy(), a["reward"][t], rtol=1e-5, atol=1e-5)
+
+
+def _cfg(n, deadband=1.5, mode="individual_L2"):
+    import mdr_amd
+    cfg = mdr_amd.default_config()
+    env = cfg["default_env_prop"]
+    env["cluster_prop"]["nb_agents"] = n
+    env["power_grid_prop"]["base_power_mode"] = "constant"
+    env["power_grid_prop"]["signal_mode"] = "sinusoidals"
+    env["reward_prop"]["temp_penalty_mode"] = mode
+    cfg["default_house_prop"]["deadband"] = deadband
+    cfg["noise_house_prop"]["noise_mode"] = "big_noise"
+    cfg["noise_hvac_prop"]["noise_mode"] = "big_noise"
+    return cfg
+
+
+STATE = ("Ta", "Tm", "sso", "flags", "actions", "reward", "obs", "P")
+
+
+@pytest.mark.parametrize("kind", ["deadband", "always_on"])
+@pytest.mark.parametrize("E,N", [(64, 1024), (3, 20000), (4096, 50), (2000, 20), (512, 36)])
+def test_rollouts_apply_the_controller_as_single_steps_do(kind, E, N):
+    """rollout (one launch per step / split / multi / packed forms by shape) and rollout_fused under a controller end bit for bit
+    where T step_controller() calls end; and the rule itself, on the kernel's own pre-step state."""
+    import mdr_amd
+    cfg = _cfg(N)
+    envs = [mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=13, table_steps=16) for _ in range(3)]
+    for e in envs:
+        e.reset(episode=1)
+        e.set_controller(kind)
+    one, roll, fused = envs
+    T = 37
+    for t in range(T):
+        Ta, tg, db, on = one.t["Ta"].clone(), one.t["target"], one.t["deadband"], (one.t["flags"] & 1).bool()
+        one.step_controller()
+        want = torch.ones_like(on) if kind == "always_on" else torch.where(Ta < tg - 0.5 * db, torch.zeros_like(on),
+                                                                           torch.where(Ta > tg + 0.5 * db, torch.ones_like(on), on))
+        assert torch.equal(one.t["actions"].bool(), want), t
+    roll.rollout(T)
+    got = fused.rollout_fused(T)
+    for name in STATE:
+        assert torch.equal(roll.t[name], one.t[name]), name
+        if got is not None:
+            assert torch.equal(fused.t[name], one.t[name]), name
+    if kind == "deadband":      # the hold band is in play: neither everything on nor the plain bang-bang rule
+        bang = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=13, table_steps=16)
+        bang.reset(episode=1)
+        bang.rollout(T)
+        assert not torch.equal(bang.t["flags"], one.t["flags"])
+
+
+def test_persistent_rollout_applies_the_controller():
+    import mdr_amd
+    cfg = _cfg(20000, mode="mixture")
+    a = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=2, device="cuda:0", seed=5, table_steps=16)
+    b = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=2, device="cuda:0", seed=5, table_steps=16)
+    for e in (a, b):
+        e.reset(episode=0)
+        e.set_controller("deadband")
+    a.rollout(40)
+    b.rollout_persistent(40)
+    for name in STATE:
+        assert torch.equal(a.t[name], b.t[name]), name
+
+
+def test_deepcopy_keeps_the_controller_and_unknown_names_are_refused():
+    import copy
+    import mdr_amd
+    env = mdr_amd.BatchedDemandResponseEnv(_cfg(64), nb_envs=4, device="cuda:0", seed=1)
+    env.reset(episode=0)
+    with pytest.raises(ValueError):
+        env.set_controller("mpc")
+    env.set_controller("deadband")
+    env.rollout(5)
+    twin = copy.deepcopy(env)
+    env.rollout(9)
+    twin.rollout(9)
+    assert torch.equal(env.t["Ta"], twin.t["Ta"]) and torch.equal(env.t["flags"], twin.t["flags"])

@@ -65,6 +65,25 @@ def test_bangbang_rule_matches_recorded_actions():
         env.step(g.a["actions"][t][None, :])
 
 
+@pytest.mark.parametrize("name,rule", [("s14_controller_deadband", "deadband_actions"), ("s14_controller_basic", "deadband_actions"),
+                                       ("s14_controller_always_on", "always_on_actions")])
+def test_other_controllers_match_recorded_actions(name, rule):
+    """agents/bangbang_controllers.py: DeadbandBangBangController 13-38, BasicController 64-88 (the same rule), AlwaysOnController
+    1-10, restated in OracleEnv and held to the actions the reference's own controller objects took in the S14 fixtures."""
+    g = gu.Golden(name)
+    env = replay(g)
+    held = 0
+    for t in range(g.T):
+        act = getattr(env, rule)()[0]
+        np.testing.assert_array_equal(act.astype(np.uint8), g.a["actions"][t])
+        if rule == "deadband_actions":
+            half = env.deadband[0] / 2
+            held += int(np.sum((env.Ta[0] >= env.target[0] - half) & (env.Ta[0] <= env.target[0] + half)))
+        env.step(g.a["actions"][t][None, :])
+    if rule == "deadband_actions":
+        assert held > 50          # the hold band (keep what the HVAC is doing) is visited
+
+
 def test_dynamic_obs_columns_match_normStateDict():
     """The 7 columns the kernels emit are entries 0,1,5,6,7,9,10 of the default normStateDict vector
     (utils.py:800-841; entry 2 = target, 3 = deadband, 4 = capacity ratio, 8 = constant 1)."""
