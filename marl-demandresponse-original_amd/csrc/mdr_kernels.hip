@@ -702,7 +702,8 @@ __device__ __forceinline__ EnvRow window_get(const EnvRow& w, int src_lane) {
 // ---- (1b) multi-step closed loop: the same workgroup-per-env mapping, but the houses stay in registers for
 // `nsteps` steps (bang-bang rule in-kernel).  Per step only the env's table scalars are read; the state is read
 // once and written once per launch.  One barrier per step (LDS partials are double-buffered by step parity).
-template <int VEC, int TILES, int THREADS, bool WINDOW>
+// (BB: the bang-bang rule compiled in - the default controller; the other rules go through controller_cmds)
+template <int VEC, int TILES, int THREADS, bool WINDOW, bool BB>
 __global__ __launch_bounds__(THREADS) void k_rollout_fused(StepArgs a, RolloutArgs ro) {
   __shared__ double lds[2][3 * (THREADS / 64)];
   const bool need_pen = a.penalty_mode != MDR_PENALTY_INDIVIDUAL_L2;   // common penalty modes need the env's penalty sum / max
@@ -774,9 +775,11 @@ __global__ __launch_bounds__(THREADS) void k_rollout_fused(StepArgs a, RolloutAr
     for (int t = 0; t < TILES; ++t) {
       if (live[t]) {
         float p = 0.0f, ps = 0.0f, te = 0.0f;
+        bool cmds[VEC];
+        controller_cmds<VEC>(BB ? MDR_ACTIONS_BANGBANG : a.action_source, hs[t], cmds);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          const bool cmd = controller_cmd(a.action_source, hs[t][v].Ta, hs[t][v].target, hs[t][v].deadband, hs[t][v].flags);   // agents/bangbang_controllers.py
+          const bool cmd = cmds[v];
           act[t][v] = cmd ? 1u : 0u;
           o[t][v] = house_step(hs[t][v], cmd, od_old, solar, a.dt);
           hs[t][v].Ta = o[t][v].Ta;
@@ -927,11 +930,27 @@ __global__ __launch_bounds__(256) void k_step_single_house(StepArgs a) {
   float nTa[4], nTm[4], rew[4], c5[4], c6[4];
   int nsso[4];
   unsigned nfl[4];
+  bool cmds[4];   // three wave-uniform arms (see step_vec_rows)
+  if (a.action_source == MDR_ACTIONS_EXTERNAL) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) cmds[v] = act[v] != 0u;
+  } else if (a.action_source == MDR_ACTIONS_BANGBANG) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      cmds[v] = Ta[v] > tg[v];
+      act[v] = cmds[v] ? 1u : 0u;
+    }
+  } else {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      cmds[v] = controller_cmd(a.action_source, Ta[v], tg[v], db[v], fl[v]);
+      act[v] = cmds[v] ? 1u : 0u;
+    }
+  }
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     HouseIn h{Ta[v], Tm[v], sso[v], fl[v], k01[v], s0[v], k10[v], s1[v], iu[v], q[v], pm[v], tg[v], db[v], lk[v]};
-    const bool cmd = (a.action_source == MDR_ACTIONS_EXTERNAL) ? (act[v] != 0u) : controller_cmd(a.action_source, Ta[v], tg[v], db[v], fl[v]);
-    if (a.action_source != MDR_ACTIONS_EXTERNAL) act[v] = cmd ? 1u : 0u;
+    const bool cmd = cmds[v];
     o[v] = house_step(h, cmd, od[v], solar[v], a.dt);
     nTa[v] = o[v].Ta;
     nTm[v] = o[v].Tm;
@@ -960,7 +979,7 @@ __global__ __launch_bounds__(256) void k_step_single_house(StepArgs a) {
 
 // ---- (2b) multi-step closed loop for small envs: GROUP lanes per env, VEC houses per lane (the same mapping and the
 // same reduction tree as k_step_group, so both end bit for bit in the same state), no LDS, no barrier
-template <int GROUP, int VEC, bool WINDOW>
+template <int GROUP, int VEC, bool WINDOW, bool BB>
 __global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs ro) {
   const bool need_pen = a.penalty_mode != MDR_PENALTY_INDIVIDUAL_L2;
   const bool want_rsum = ro.reward_sum != nullptr;
@@ -1029,9 +1048,11 @@ __global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs r
     Red3 acc{0.0, 0.0, 0.0f};
     if (active) {
       float p = 0.0f, ps = 0.0f, te = 0.0f;
+      bool cmds[VEC];
+      controller_cmds<VEC>(BB ? MDR_ACTIONS_BANGBANG : a.action_source, hs, cmds);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        const bool cmd = controller_cmd(a.action_source, hs[v].Ta, hs[v].target, hs[v].deadband, hs[v].flags);
+        const bool cmd = cmds[v];
         act[v] = cmd ? 1u : 0u;
         o[v] = house_step(hs[v], cmd, er.od, er.solar, a.dt);
         hs[v].Ta = o[v].Ta;
@@ -2358,13 +2379,19 @@ bool rollout_fused_supported(const StepPlan& p) { return p.kind == STEP_GROUP ||
 hipError_t launch_rollout_fused(const StepArgs& a, const RolloutArgs& r, const StepPlan& p, hipStream_t s) {
   if (!rollout_fused_supported(p)) return hipErrorInvalidValue;
   if (p.kind == STEP_MULTI || p.kind == STEP_PACKED) return launch_rollout_multi(a, r, p, s);
+  const bool bb = a.action_source == MDR_ACTIONS_BANGBANG;
   if (p.kind == STEP_GROUP) {
     const int64_t lanes = (int64_t)a.E * p.threads;
     const dim3 gg((unsigned)((lanes + 255) / 256)), b(256);
     const bool win = lanes < (int64_t)64 * 8 * 256;   // fewer than ~8 wavefronts per CU: latency-bound
-#define MDR_ROLLGV(G, V)                                                          \
-  if (win) hipLaunchKernelGGL((k_rollout_group<G, V, true>), gg, b, 0, s, a, r); \
-  else hipLaunchKernelGGL((k_rollout_group<G, V, false>), gg, b, 0, s, a, r);
+#define MDR_ROLLGV(G, V)                                                                    \
+  if (bb) {                                                                                 \
+    if (win) hipLaunchKernelGGL((k_rollout_group<G, V, true, true>), gg, b, 0, s, a, r);    \
+    else hipLaunchKernelGGL((k_rollout_group<G, V, false, true>), gg, b, 0, s, a, r);       \
+  } else {                                                                                  \
+    if (win) hipLaunchKernelGGL((k_rollout_group<G, V, true, false>), gg, b, 0, s, a, r);   \
+    else hipLaunchKernelGGL((k_rollout_group<G, V, false, false>), gg, b, 0, s, a, r);      \
+  }
 #define MDR_ROLLG(G)                      \
   if (p.vec == 4) { MDR_ROLLGV(G, 4) }    \
   else if (p.vec == 2) { MDR_ROLLGV(G, 2) } \
@@ -2386,9 +2413,14 @@ hipError_t launch_rollout_fused(const StepArgs& a, const RolloutArgs& r, const S
   const dim3 g((unsigned)a.E);
   const bool win = (int64_t)a.E * p.threads < (int64_t)64 * 8 * 256;
 #define MDR_ROLL(V, T, TH)                                                                  \
-  do {                                                                                      \
-    if (win) hipLaunchKernelGGL((k_rollout_fused<V, T, TH, true>), g, dim3(TH), 0, s, a, r); \
-    else hipLaunchKernelGGL((k_rollout_fused<V, T, TH, false>), g, dim3(TH), 0, s, a, r);    \
+  do {                                                                                                  \
+    if (bb) {                                                                                           \
+      if (win) hipLaunchKernelGGL((k_rollout_fused<V, T, TH, true, true>), g, dim3(TH), 0, s, a, r);    \
+      else hipLaunchKernelGGL((k_rollout_fused<V, T, TH, false, true>), g, dim3(TH), 0, s, a, r);       \
+    } else {                                                                                            \
+      if (win) hipLaunchKernelGGL((k_rollout_fused<V, T, TH, true, false>), g, dim3(TH), 0, s, a, r);   \
+      else hipLaunchKernelGGL((k_rollout_fused<V, T, TH, false, false>), g, dim3(TH), 0, s, a, r);      \
+    }                                                                                                   \
   } while (0)
   if (p.vec == 4) {
     if (p.threads == 64) { if (p.tiles == 1) MDR_ROLL(4, 1, 64); else MDR_ROLL(4, 2, 64); }

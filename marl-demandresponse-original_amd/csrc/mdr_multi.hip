@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_step_multi(StepArgs a) {
 }
 
 // The closed loop on the same mapping: houses in registers for nsteps steps (k_rollout_group's counterpart).
-template <int GROUP, int ENVS>
+template <int GROUP, int ENVS, bool BB>   // BB: the bang-bang rule compiled in (mdr_kernels.hip k_rollout_fused)
 __global__ __launch_bounds__(256) void k_rollout_multi(StepArgs a, RolloutArgs ro) {
   const bool need_pen = a.penalty_mode != MDR_PENALTY_INDIVIDUAL_L2;
   const bool want_rsum = ro.reward_sum != nullptr;
@@ -204,11 +204,13 @@ __global__ __launch_bounds__(256) void k_rollout_multi(StepArgs a, RolloutArgs r
       float te[ENVS];
 #pragma unroll
       for (int k = 0; k < ENVS; ++k) te[k] = 0.0f;
+      bool cmds[4];
+      controller_cmds<4>(BB ? MDR_ACTIONS_BANGBANG : a.action_source, hs, cmds);
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         if (v >= m.nv) continue;
         const bool first = m.q[v] == m.q[0];
-        const bool cmd = controller_cmd(a.action_source, hs[v].Ta, hs[v].target, hs[v].deadband, hs[v].flags);
+        const bool cmd = cmds[v];
         act[v] = cmd ? 1u : 0u;
         o[v] = house_step(hs[v], cmd, first ? od_a : od_b, first ? so_a : so_b, a.dt);
         hs[v].Ta = o[v].Ta;
@@ -398,6 +400,7 @@ __global__ __launch_bounds__(256) void k_step_packed(StepArgs a) {
   cursor_done(a);
 }
 
+template <bool BB>
 __global__ __launch_bounds__(256) void k_rollout_packed(StepArgs a, RolloutArgs ro) {
   const bool need_pen = a.penalty_mode != MDR_PENALTY_INDIVIDUAL_L2;
   const bool want_rsum = ro.reward_sum != nullptr;
@@ -452,9 +455,11 @@ __global__ __launch_bounds__(256) void k_rollout_packed(StepArgs a, RolloutArgs 
     Red3 acc{0.0, 0.0, 0.0f};
     if (active) {
       float p = 0.0f, ps = 0.0f, te = 0.0f;
+      bool cmds[4];
+      controller_cmds<4>(BB ? MDR_ACTIONS_BANGBANG : a.action_source, hs, cmds);
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const bool cmd = controller_cmd(a.action_source, hs[v].Ta, hs[v].target, hs[v].deadband, hs[v].flags);
+        const bool cmd = cmds[v];
         act[v] = cmd ? 1u : 0u;
         o[v] = house_step(hs[v], cmd, od, solar, a.dt);
         hs[v].Ta = o[v].Ta;
@@ -544,15 +549,30 @@ hipError_t launch_step_multi(const StepArgs& a, const StepPlan& p, hipStream_t s
   return hipGetLastError();
 }
 
+#undef MDR_MULTI_DISPATCH
+
+#define MDR_MULTI_ROLLOUT(BBV)                                                                             \
+  switch (p.tiles * 100 + p.threads) {                                                                     \
+    case 204: hipLaunchKernelGGL((k_rollout_multi<4, 2, BBV>), g, b, 0, s, a, r); break;                   \
+    case 208: hipLaunchKernelGGL((k_rollout_multi<8, 2, BBV>), g, b, 0, s, a, r); break;                   \
+    case 216: hipLaunchKernelGGL((k_rollout_multi<16, 2, BBV>), g, b, 0, s, a, r); break;                  \
+    case 232: hipLaunchKernelGGL((k_rollout_multi<32, 2, BBV>), g, b, 0, s, a, r); break;                  \
+    case 264: hipLaunchKernelGGL((k_rollout_multi<64, 2, BBV>), g, b, 0, s, a, r); break;                  \
+    default: return hipErrorInvalidValue;                                                                  \
+  }
+
 hipError_t launch_rollout_multi(const StepArgs& a, const RolloutArgs& r, const StepPlan& p, hipStream_t s) {
   const dim3 g((unsigned)multi_blocks(a.E, p)), b(256);
+  const bool bb = a.action_source == MDR_ACTIONS_BANGBANG;
   if (p.kind == STEP_PACKED) {
-    hipLaunchKernelGGL(k_rollout_packed, g, b, 0, s, a, r);
+    if (bb) hipLaunchKernelGGL(k_rollout_packed<true>, g, b, 0, s, a, r);
+    else hipLaunchKernelGGL(k_rollout_packed<false>, g, b, 0, s, a, r);
     return hipGetLastError();
   }
-  MDR_MULTI_DISPATCH(k_rollout_multi, a, r)
+  if (bb) { MDR_MULTI_ROLLOUT(true) }
+  else { MDR_MULTI_ROLLOUT(false) }
   return hipGetLastError();
 }
-#undef MDR_MULTI_DISPATCH
+#undef MDR_MULTI_ROLLOUT
 
 }  // namespace mdr

@@ -66,7 +66,8 @@ __device__ __forceinline__ bool abort_raised(const PersistArgs& m) {
   return granule_load<SYS>((const gu64*)m.box[m.rank]) != 0ull;
 }
 
-template <int VEC, bool SYS>
+// BB: the bang-bang rule compiled in (the default controller; the general rule costs this latency-bound loop 0.3 us per step)
+template <int VEC, bool SYS, bool BB>
 __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutArgs ro, PersistArgs m) {
   const int D = m.depth;   // steps the houses run ahead of the totals (<= PERSIST_MAX_DEPTH)
   // dynamic LDS: [D + 1][256][VEC] floats - each house's own penalty of the steps in flight - then the env's table rows of this
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
         float p = 0.0f, ps = 0.0f, te = 0.0f;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          const bool cmd = controller_cmd(a.action_source, hs[v].Ta, hs[v].target, hs[v].deadband, hs[v].flags);   // agents/bangbang_controllers.py
+          const bool cmd = BB ? hs[v].Ta > hs[v].target : controller_cmd(a.action_source, hs[v].Ta, hs[v].target, hs[v].deadband, hs[v].flags);   // agents/bangbang_controllers.py
           act[v] = cmd ? 1u : 0u;
           const HouseOut o = house_step(hs[v], cmd, od_old, solar, a.dt);
           hs[v].Ta = o.Ta;
@@ -425,24 +426,30 @@ static hipError_t persist_capacity(K kernel, size_t lds, int64_t* blocks) {
   return hipSuccess;
 }
 
-hipError_t persist_resident_blocks(int vec, bool sys, int depth, int64_t* blocks) {
+hipError_t persist_resident_blocks(int vec, bool sys, int depth, int64_t* blocks) {   // (the general-controller forms: they hold the most registers)
   const size_t lds = persist_lds_bytes(vec, depth);
-  if (vec == 4) return sys ? persist_capacity(k_rollout_persist<4, true>, lds, blocks) : persist_capacity(k_rollout_persist<4, false>, lds, blocks);
-  return sys ? persist_capacity(k_rollout_persist<1, true>, lds, blocks) : persist_capacity(k_rollout_persist<1, false>, lds, blocks);
+  if (vec == 4) return sys ? persist_capacity(k_rollout_persist<4, true, false>, lds, blocks) : persist_capacity(k_rollout_persist<4, false, false>, lds, blocks);
+  return sys ? persist_capacity(k_rollout_persist<1, true, false>, lds, blocks) : persist_capacity(k_rollout_persist<1, false, false>, lds, blocks);
 }
 
 hipError_t launch_rollout_persist(const StepArgs& a, const RolloutArgs& r, const PersistArgs& m, bool sys, hipStream_t s) {
   if (m.depth < 1 || m.depth > PERSIST_MAX_DEPTH || r.nsteps < 1 || r.nsteps > PERSIST_MAX_STEPS) return hipErrorInvalidValue;
   const dim3 g((unsigned)(m.nrec[m.rank] + 1), (unsigned)a.E), b(256);
-  if (a.N % 4 == 0) {
-    const size_t lds = persist_lds_bytes(4, m.depth, r.nsteps);
-    if (sys) hipLaunchKernelGGL((k_rollout_persist<4, true>), g, b, lds, s, a, r, m);
-    else hipLaunchKernelGGL((k_rollout_persist<4, false>), g, b, lds, s, a, r, m);
-  } else {
-    const size_t lds = persist_lds_bytes(1, m.depth, r.nsteps);
-    if (sys) hipLaunchKernelGGL((k_rollout_persist<1, true>), g, b, lds, s, a, r, m);
-    else hipLaunchKernelGGL((k_rollout_persist<1, false>), g, b, lds, s, a, r, m);
-  }
+  const bool bb = a.action_source == MDR_ACTIONS_BANGBANG;
+#define MDR_PERSIST_LAUNCH(VECV)                                                                                      \
+  do {                                                                                                                \
+    const size_t lds = persist_lds_bytes(VECV, m.depth, r.nsteps);                                                    \
+    if (sys) {                                                                                                        \
+      if (bb) hipLaunchKernelGGL((k_rollout_persist<VECV, true, true>), g, b, lds, s, a, r, m);                       \
+      else hipLaunchKernelGGL((k_rollout_persist<VECV, true, false>), g, b, lds, s, a, r, m);                         \
+    } else {                                                                                                          \
+      if (bb) hipLaunchKernelGGL((k_rollout_persist<VECV, false, true>), g, b, lds, s, a, r, m);                      \
+      else hipLaunchKernelGGL((k_rollout_persist<VECV, false, false>), g, b, lds, s, a, r, m);                        \
+    }                                                                                                                 \
+  } while (0)
+  if (a.N % 4 == 0) MDR_PERSIST_LAUNCH(4);
+  else MDR_PERSIST_LAUNCH(1);
+#undef MDR_PERSIST_LAUNCH
   return hipGetLastError();
 }
 

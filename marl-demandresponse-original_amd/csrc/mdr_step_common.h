@@ -148,12 +148,29 @@ __device__ __forceinline__ void store_bytes(uint8_t* __restrict__ p, int64_t i, 
 // The reference's rule-based controllers on the pre-step observation (agents/bangbang_controllers.py): BangBangController 41-61,
 // DeadbandBangBangController 13-38 == BasicController 64-88, AlwaysOnController 1-10.  `src` is wave-uniform.
 __device__ __forceinline__ bool controller_cmd(int src, float Ta, float target, float deadband, unsigned flags) {
-  if (src == MDR_ACTIONS_BANGBANG) return Ta > target;
-  if (src == MDR_ACTIONS_DEADBAND) {
-    const float half = 0.5f * deadband;
-    return Ta < target - half ? false : (Ta > target + half ? true : (flags & 1u) != 0u);
+#if defined(MDR_CONTROLLER_BANGBANG_ONLY) && MDR_CONTROLLER_BANGBANG_ONLY   // experiment build: what the other two rules cost the bang-bang loop
+  return Ta > target;
+#endif
+  // one straight-line form for the three rules (the rollout kernels run this in their latency-bound inner loop): the band is
+  // [target - h, target + h] with h = deadband / 2 for the deadband rule and 0 otherwise; inside the band (edges included) the
+  // deadband rule keeps what the HVAC is doing, bang-bang says off (its band is the single point Ta == target)
+  const float h = (src == MDR_ACTIONS_DEADBAND ? 0.5f : 0.0f) * deadband;
+  const bool above = Ta > target + h, below = Ta < target - h;
+  const bool keep = src == MDR_ACTIONS_DEADBAND && (flags & 1u) != 0u;
+  return above || (!below && keep) || src == MDR_ACTIONS_ALWAYS_ON;
+}
+
+// The commands of a lane's VEC houses.  The bang-bang rule - the default of every closed loop - sits behind a wave-uniform BRANCH
+// of its own: computed through the general form it cost the vector-bound rollout kernels 7-9 % (r03: fused rollout 6.6 -> 7.2 us).
+template <int VEC>
+__device__ __forceinline__ void controller_cmds(int src, const HouseIn* hs, bool* cmd) {
+  if (src == MDR_ACTIONS_BANGBANG) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) cmd[v] = hs[v].Ta > hs[v].target;   // agents/bangbang_controllers.py:49-59
+  } else {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) cmd[v] = controller_cmd(src, hs[v].Ta, hs[v].target, hs[v].deadband, hs[v].flags);
   }
-  return true;   // MDR_ACTIONS_ALWAYS_ON
 }
 
 template <int VEC>
@@ -179,12 +196,28 @@ __device__ __forceinline__ void step_vec_rows(const StepArgs& a, int64_t i, cons
   float nTa[VEC], nTm[VEC];
   int nsso[VEC];
   unsigned nfl[VEC];
+  // the in-kernel controllers act on the pre-step observation (agents/bangbang_controllers.py); three wave-uniform arms
+  bool cmds[VEC];
+  if (a.action_source == MDR_ACTIONS_EXTERNAL) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) cmds[v] = act[v] != 0u;
+  } else if (a.action_source == MDR_ACTIONS_BANGBANG) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      cmds[v] = Ta[v] > tg[v];
+      act[v] = cmds[v] ? 1u : 0u;
+    }
+  } else {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      cmds[v] = controller_cmd(a.action_source, Ta[v], tg[v], db[v], fl[v]);
+      act[v] = cmds[v] ? 1u : 0u;
+    }
+  }
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
     HouseIn h{Ta[v], Tm[v], sso[v], fl[v], k01[v], s0[v], k10[v], s1[v], iu[v], q[v], pm[v], tg[v], db[v], lockout[v]};
-    // the in-kernel controllers act on the pre-step observation (agents/bangbang_controllers.py)
-    const bool cmd = (a.action_source == MDR_ACTIONS_EXTERNAL) ? (act[v] != 0u) : controller_cmd(a.action_source, Ta[v], tg[v], db[v], fl[v]);
-    if (a.action_source != MDR_ACTIONS_EXTERNAL) act[v] = cmd ? 1u : 0u;
+    const bool cmd = cmds[v];
     out[v] = house_step(h, cmd, od_old[v], solar[v], a.dt);
     nTa[v] = out[v].Ta;
     nTm[v] = out[v].Tm;
