@@ -67,6 +67,18 @@ __device__ __forceinline__ bool abort_raised(const PersistArgs& m) {
 }
 
 // BB: the bang-bang rule compiled in (the default controller; the general rule costs this latency-bound loop 0.3 us per step)
+// Experiment build -DMDR_PERSIST_TRACE=1 (tools/scratch): cycle stamps of house workgroup 0 / the reducer of env 0 into the
+// power-trace buffer, 8 per step: where a step of the pipeline spends its time.  Never in the product library.
+#if defined(MDR_PERSIST_TRACE) && MDR_PERSIST_TRACE
+#define MDR_STAMP(buf, step, slot, on) \
+  do { if ((on) && (buf) != nullptr) reinterpret_cast<unsigned long long*>(buf)[(int64_t)(step) * 16 + (slot)] = (unsigned long long)clock64(); } while (0)
+#define MDR_NOTE(buf, step, slot, on, value) \
+  do { if ((on) && (buf) != nullptr) reinterpret_cast<unsigned long long*>(buf)[(int64_t)(step) * 16 + (slot)] = (unsigned long long)(value); } while (0)
+#else
+#define MDR_STAMP(buf, step, slot, on) do { } while (0)
+#define MDR_NOTE(buf, step, slot, on, value) do { } while (0)
+#endif
+
 template <int VEC, bool SYS, bool BB>
 __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutArgs ro, PersistArgs m) {
   const int D = m.depth;   // steps the houses run ahead of the totals (<= PERSIST_MAX_DEPTH)
@@ -143,7 +155,8 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
       const int g_now = (s == T) ? 2 : ng;
       Red3 acc{0.0, 0.0, 0.0f};
       bool failed = false;
-      for (uint32_t spins = 0;;) {
+      uint32_t spins = 0;
+      for (;;) {
         acc = Red3{0.0, 0.0, 0.0f};
         bool ok = true;
 #pragma unroll
@@ -179,10 +192,13 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
         __builtin_amdgcn_s_sleep(1);
         fetch(s);
       }
+      MDR_STAMP(ro.power_trace, s, 8, tid == 0 && e == 0);
+      MDR_NOTE(ro.power_trace, s, 11, tid == 0 && e == 0, spins);
       if (s < last) fetch(s + 1);   // in flight across the reduction and the publication below
       if (failed) lds_fail[s & 1] = 1;
       tot = block_reduce<256>(acc, lds_part[s & 1]);   // one barrier: the failure flag rides on it
       if (lds_fail[s & 1]) return;
+      MDR_STAMP(ro.power_trace, s, 9, tid == 0 && e == 0);
       if (s == T) {
         if (tid == 0) ro.sq_temp_error_sum[e] += tot.sum_p;
         break;
@@ -193,9 +209,12 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
                                     : __float_as_uint(tot.max_pen);
         granule_store<SYS>(own + tot_offset(m, a.E, slot, e) + tid, tag, v);
       }
+      MDR_STAMP(ro.power_trace, s, 10, tid == 0 && e == 0);
       if (tid == 0) {
         const int64_t row = (int64_t)s * a.E + e;
+#if !(defined(MDR_PERSIST_TRACE) && MDR_PERSIST_TRACE)
         if (ro.power_trace) ro.power_trace[row] = tot.sum_p;
+#endif
         const double d = row_sig_new[s] - tot.sum_p;
         serr += d * d;
         P_last = tot.sum_p;
@@ -246,6 +265,14 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
       hs[v] = HouseIn{Ta[v], Tm[v], sso[v], fl[v], k01[v], s0[v], k10[v], s1[v], iu[v], q[v], pm[v], tg[v], db[v], lk[v]};
     if (ro.reward_sum) load_vec<VEC>(ro.reward_sum, i, rsum);   // continue the caller's running sum in step order
   }
+  // The state and parameters must have ARRIVED before the loop: a wait for them inside it (hipcc puts one where a register is first
+  // used) is, from the second iteration on, a wait for the record granules and the totals request in flight - the counter cannot tell.
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    asm volatile("" : "+v"(hs[v].Ta), "+v"(hs[v].Tm), "+v"(hs[v].sso), "+v"(hs[v].flags), "+v"(hs[v].k01), "+v"(hs[v].s0), "+v"(hs[v].k10));
+    asm volatile("" : "+v"(hs[v].s1), "+v"(hs[v].inv_Ua), "+v"(hs[v].Q_hvac), "+v"(hs[v].P_max), "+v"(hs[v].target), "+v"(hs[v].deadband),
+                 "+v"(hs[v].lockout), "+v"(rsum[v]));
+  }
   double terr = 0.0;
   Red3 tot{0.0, 0.0, 0.0f};
   float sig_term = 0.0f;
@@ -253,6 +280,8 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
   bool have_pre = false;
   for (int it = 0, ring = 0; it < T + D; ++it, ring = (ring == D ? 0 : ring + 1)) {   // ring = it mod (D + 1)
     const int par = it & 1;
+    const bool tr = tid == 0 && blk == 0 && e == 0 && it < T;
+    MDR_STAMP(ro.power_trace, it, 0, tr);
     // the step `it` itself: needs nothing from the other workgroups
     Red3 acc{0.0, 0.0, 0.0f};
     if (it < T) {
@@ -290,15 +319,19 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
         lds_part[par][8 + wave] = (double)acc.max_pen;
       }
     }
-    // wave 0 picks up the totals of step it - D (published by the reducer D steps of work ago); the load was issued an
-    // iteration earlier, so its latency lies behind that iteration's arithmetic and barrier
+    MDR_STAMP(ro.power_trace, it, 1, tr);
+    // wave 0 picks up the totals of step it - D (published by the reducer D steps of work ago); the load was issued at the end
+    // of the iteration before, so its latency lies behind this iteration's arithmetic
     if (wave == 0 && it >= D) {
       const uint32_t tag = m.tag_base + (uint32_t)(it - D);
-      const gu64* src = own + tot_offset(m, a.E, (int)(tag % PERSIST_SLOTS), e) + lane;
+      // (lanes past the granules that travel read the last one of them: every lane loads, no lane patches its register - a
+      // constant moved into the register of a load in flight would cost a wait for everything in flight)
+      const gu64* src = own + tot_offset(m, a.E, (int)(tag % PERSIST_SLOTS), e) + min(lane, ng - 1);
       uint32_t val = 0;
       bool failed = false;
-      unsigned long long x = have_pre ? pre : (lane < ng ? granule_load<SYS>(src) : ((unsigned long long)tag << 32));
-      for (uint32_t spins = 0;;) {
+      unsigned long long x = have_pre ? pre : granule_load<SYS>(src);
+      uint32_t spins = 0;
+      for (;;) {
         val = (uint32_t)x;
         if (__all((uint32_t)(x >> 32) == tag)) break;
         ++spins;
@@ -308,16 +341,12 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
           break;
         }
         __builtin_amdgcn_s_sleep(1);
-        x = lane < ng ? granule_load<SYS>(src) : ((unsigned long long)tag << 32);
+        x = granule_load<SYS>(src);
       }
-      have_pre = it + 1 < T + D;
-      if (have_pre) {
-        const uint32_t nxt = tag + 1u;
-        pre = lane < ng ? granule_load<SYS>(own + tot_offset(m, a.E, (int)(nxt % PERSIST_SLOTS), e) + lane) : ((unsigned long long)nxt << 32);
-      }
+      MDR_NOTE(ro.power_trace, it, 6, tr, spins);
       const int v0 = __builtin_amdgcn_readlane((int)val, 0), v1 = __builtin_amdgcn_readlane((int)val, 1);
-      const int v2 = __builtin_amdgcn_readlane((int)val, 2), v3 = __builtin_amdgcn_readlane((int)val, 3);
-      const int v4 = __builtin_amdgcn_readlane((int)val, 4);
+      const int v2 = need_pen ? __builtin_amdgcn_readlane((int)val, 2) : 0, v3 = need_pen ? __builtin_amdgcn_readlane((int)val, 3) : 0;
+      const int v4 = need_pen ? __builtin_amdgcn_readlane((int)val, 4) : 0;   // (granules that did not travel: zeros)
       if (lane == 0) {
         lds_tot[par][0] = __hiloint2double(v1, v0);
         lds_tot[par][1] = __hiloint2double(v3, v2);
@@ -325,7 +354,9 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
         if (failed) lds_fail[par] = 1;
       }
     }
+    MDR_STAMP(ro.power_trace, it, 2, tr);
     __syncthreads();
+    MDR_STAMP(ro.power_trace, it, 3, tr);
     if (lds_fail[par]) return;
     if (it < T) {
       // this workgroup's record: the same arithmetic as block_reduce (every thread re-adds the wave partials in order)
@@ -348,6 +379,7 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
           if (r < m.world) granule_store<SYS>((gu64*)m.box[r] + off, tag, v);
       }
     }
+    MDR_STAMP(ro.power_trace, it, 4, tr);
     if (it >= D) {   // rewards of step it - D, in step order
       const int64_t row = (int64_t)(it - D) * a.E + e;
       tot.sum_p = lds_tot[par][0];
@@ -360,6 +392,17 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
         for (int v = 0; v < VEC; ++v) rsum[v] = __fadd_rn(rsum[v], reward_value(a, pen_old[v], tot.sum_pen, tot.max_pen, sig_term));
       }
     }
+    // the totals the NEXT iteration picks up, requested as the last memory operation of this one: issued any earlier - next to
+    // the pick-up above - hipcc's wait for the pick-up's own register (one counter, retired in order, unknown trip count of the
+    // spin) became a wait for this load too, and the request never overlapped anything
+    if (wave == 0) {
+      have_pre = it + 1 >= D && it + 1 < T + D;
+      if (have_pre) {
+        const uint32_t nxt = m.tag_base + (uint32_t)(it + 1 - D);
+        pre = granule_load<SYS>(own + tot_offset(m, a.E, (int)(nxt % PERSIST_SLOTS), e) + min(lane, ng - 1));
+      }
+    }
+    MDR_STAMP(ro.power_trace, it, 5, tr);
   }
   if (T <= 0) return;
   if (want_terr) {   // pseudo-step T: this workgroup's squared temperature error travels as one more record
