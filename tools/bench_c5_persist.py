@@ -15,6 +15,8 @@ shares = [int(s) for s in os.environ.get("SHARES", "1000000,500000,250000,125000
 for share in shares:
     cfg = bench.c3_config(mdr_amd)
     cfg["default_env_prop"]["cluster_prop"]["nb_agents"] = share
+    if os.environ.get("PENALTY"):
+        cfg["default_env_prop"]["reward_prop"]["temp_penalty_mode"] = os.environ["PENALTY"]
     row = {"houses_on_rank": share, "steps": K}
     for name, fn in (("split_rollout", lambda e: e.rollout(K)),
                      ("persistent", lambda e: e.rollout_persistent(K, check=False)),
