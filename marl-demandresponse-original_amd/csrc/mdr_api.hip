@@ -858,7 +858,12 @@ int mdr_env_rollout_persistent(mdr_env_t* env, uint8_t* actions, int32_t nb_step
   int64_t resident = 0;
   hipError_t e = mdr::persist_resident_blocks(c.nb_houses % 4 == 0 ? 4 : 1, sys, depth, &resident);
   if (e != hipSuccess) return hip_fail(env, e, "occupancy query");
-  const int64_t grid = (mine + 1) * c.nb_envs;
+  int64_t all_records = 0;
+  for (int r = 0; r < mb->world; ++r) all_records += mb->records[r];
+  int reducers = std::min(mdr::persist_reducers(all_records), depth);
+  // (their partial sums of the squared signal error go through `partials`, the split path's scratch: [E][...][3] doubles, idle here)
+  if (reducers > 1 && (!env->buf.partials || (int64_t)reducers > mdr_partials_per_env(c.nb_houses) * 3)) reducers = 1;
+  const int64_t grid = (mine + reducers) * c.nb_envs;
   if (grid * mb->co_resident > resident) {
     char msg[200];
     snprintf(msg, sizeof msg, "persistent rollout: %lld workgroups x %d co-resident launches exceed the %lld the device holds at once",
@@ -890,8 +895,12 @@ int mdr_env_rollout_persistent(mdr_env_t* env, uint8_t* actions, int32_t nb_step
     m.tag_base = env->mailbox_tag;
     m.spin_limit = mb->spin_limit ? mb->spin_limit : (1u << 20);
     m.depth = depth;
+    m.reducers = reducers;
+    m.serr_part = reducers > 1 ? env->buf.partials : nullptr;   // [reducers][E] doubles of the split path's scratch (idle here)
     e = mdr::launch_rollout_persist(a, r, m, sys, s);
     if (e != hipSuccess) return hip_fail(env, e, "rollout_persist");
+    e = mdr::launch_persist_combine(m, c.nb_envs, r.sq_signal_error_sum, s);
+    if (e != hipSuccess) return hip_fail(env, e, "persist_combine");
     env->mailbox_tag += (uint32_t)r.nsteps + 1u;   // + the pseudo-step that carries the squared temperature errors
     env->k += r.nsteps;
     done += r.nsteps;

@@ -202,10 +202,15 @@ struct PersistArgs {
   uint32_t tag_base;                // tag of this launch's step 0 (steps are counted over the life of the handle)
   uint32_t spin_limit;
   int32_t depth;                    // steps the houses run ahead of the totals, 1 .. PERSIST_MAX_DEPTH
+  int32_t reducers;                 // reducer workgroups per env, 1 .. PERSIST_MAX_REDUCERS: reducer j takes the steps s with s % reducers == j
+  double* serr_part;                // [reducers][E] squared-signal-error partial sums (reducers > 1; the host adds them up in order)
 };
+constexpr int PERSIST_MAX_REDUCERS = 4;
+int persist_reducers(int64_t records_of_all_ranks);
 int64_t persist_mailbox_granules(int E, int world, int stride);
 hipError_t persist_resident_blocks(int vec, bool system_scope, int depth, int64_t* blocks);   // workgroups of the kernel the device holds at once
 hipError_t launch_rollout_persist(const StepArgs& a, const RolloutArgs& r, const PersistArgs& m, bool system_scope, hipStream_t s);
+hipError_t launch_persist_combine(const PersistArgs& m, int E, double* sq_signal_error_sum, hipStream_t s);   // reducers > 1: adds the partial sums
 
 enum StepKind { STEP_FUSED = 0, STEP_GROUP = 1, STEP_SPLIT = 2, STEP_SINGLE = 3, STEP_MULTI = 4, STEP_PACKED = 5 };   // STEP_MULTI: `tiles` envs share a group of `threads` lanes; STEP_PACKED: `tiles` whole envs of `threads` lanes each per wavefront (mdr_multi.hip)
 struct StepPlan {

@@ -8,7 +8,8 @@
 //                                into the mailbox of EVERY rank (its own included) - 8-byte granules {tag, 32 data bits}, each
 //                                written by ONE write-through store (sc1; sc0 sc1 towards a peer device), so a granule is its
 //                                own flag and needs no fence (cdna_hip_programming.md Guideline 16, R2);
-//   reducer workgroup of env e   (one per env and rank, blockIdx.x == nblk) polls the world * records granule sets of the
+//   reducer workgroups of env e  (blockIdx.x >= nblk; reducer j of R takes the steps s with s % R == j - one suffices while a
+//                                thread holds one record, four share the work at 977) poll the world * records granule sets of the
 //                                step, re-sums them in the fixed order of k_step_finish (thread t: ranks in order, records
 //                                t, t + 256, ...; then the workgroup tree) - the totals are bit-identical on every rank and
 //                                to the records path - and publishes the totals as granules; it also keeps the per-env
@@ -24,6 +25,7 @@
 //
 // Reference: env/MA_DemandResponse.py:1005-1055 (ClusterHouses.step), 234-373 (rewards); main-deploy.py:99-148 (the loop).
 #include <algorithm>
+#include <cstdlib>
 
 #include "mdr_device.h"
 #include "mdr_kernels.h"
@@ -113,8 +115,9 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
   }
   __syncthreads();
 
-  if (blk == nblk) {
-    // ---------------------------------------------------------------- reducer of env e on this rank
+  if (blk >= nblk) {
+    // ---------------------------------------------------------------- reducer j of env e on this rank: the steps s = j, j + R, ...
+    const int R = m.reducers, j = blk - nblk;
     double serr = 0.0, P_last = 0.0;
     Red3 tot{0.0, 0.0, 0.0f};
     const int last = want_terr ? T : T - 1;   // the pseudo-step T carries the workgroups' squared temperature errors
@@ -148,8 +151,8 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
         for (int g = 0; g < PERSIST_G; ++g)
           x[k][g] = (have[k] && g < g_now) ? granule_load<SYS>(base + off[k] + g) : ((unsigned long long)tag << 32);
     };
-    fetch(0);
-    for (int s = 0; s <= last; ++s) {
+    if (j <= last) fetch(j);
+    for (int s = j; s <= last; s += R) {
       const uint32_t tag = m.tag_base + (uint32_t)s;
       const int slot = (int)(tag % PERSIST_SLOTS);
       const int g_now = (s == T) ? 2 : ng;
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
       }
       MDR_STAMP(ro.power_trace, s, 8, tid == 0 && e == 0);
       MDR_NOTE(ro.power_trace, s, 11, tid == 0 && e == 0, spins);
-      if (s < last) fetch(s + 1);   // in flight across the reduction and the publication below
+      if (s + R <= last) fetch(s + R);   // in flight across the reduction and the publication below
       if (failed) lds_fail[s & 1] = 1;
       tot = block_reduce<256>(acc, lds_part[s & 1]);   // one barrier: the failure flag rides on it
       if (lds_fail[s & 1]) return;
@@ -221,8 +224,11 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
       }
     }
     if (tid == 0 && T > 0) {
-      a.P[e] = P_last;
-      if (ro.sq_signal_error_sum) ro.sq_signal_error_sum[e] += serr;
+      if ((T - 1) % R == j) a.P[e] = P_last;     // the reducer of the last step
+      if (ro.sq_signal_error_sum) {
+        if (R == 1) ro.sq_signal_error_sum[e] += serr;
+        else m.serr_part[(int64_t)j * a.E + e] = serr;   // launch_persist_combine adds the partial sums in reducer order
+      }
     }
     return;
   }
@@ -446,6 +452,29 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
   if (ro.reward_sum) store_vec<VEC>(ro.reward_sum, i, rsum);
 }
 
+// One reducer while a thread holds at most one record of a step, then one more per 256 records (977 records - 1,000,000 houses on
+// one rank, or 8 ranks x 123 - take four): a reducer's step is a round of device-scope loads past the L2s plus a workgroup
+// reduction, ~1.5 us at four records per thread, and the houses wait for it; the reducers take the steps in turn.
+int persist_reducers(int64_t records_of_all_ranks) {
+  static const int knob = [] { const char* t = getenv("MDR_PERSIST_REDUCERS"); return t ? atoi(t) : 0; }();
+  if (knob >= 1) return std::min(knob, PERSIST_MAX_REDUCERS);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(PERSIST_MAX_REDUCERS, (records_of_all_ranks + 255) / 256));
+}
+
+__global__ __launch_bounds__(256) void k_persist_combine(const double* part, int R, int E, double* out) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  double sum = 0.0;
+  for (int j = 0; j < R; ++j) sum += part[(int64_t)j * E + e];
+  out[e] += sum;
+}
+
+hipError_t launch_persist_combine(const PersistArgs& m, int E, double* sq_signal_error_sum, hipStream_t s) {
+  if (m.reducers <= 1 || sq_signal_error_sum == nullptr) return hipSuccess;
+  hipLaunchKernelGGL(k_persist_combine, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, m.serr_part, m.reducers, E, sq_signal_error_sum);
+  return hipGetLastError();
+}
+
 int64_t persist_mailbox_granules(int E, int world, int stride) {
   return PERSIST_HDR + (int64_t)PERSIST_SLOTS * E * world * stride * PERSIST_G + (int64_t)PERSIST_SLOTS * E * PERSIST_TOT;
 }
@@ -477,7 +506,9 @@ hipError_t persist_resident_blocks(int vec, bool sys, int depth, int64_t* blocks
 
 hipError_t launch_rollout_persist(const StepArgs& a, const RolloutArgs& r, const PersistArgs& m, bool sys, hipStream_t s) {
   if (m.depth < 1 || m.depth > PERSIST_MAX_DEPTH || r.nsteps < 1 || r.nsteps > PERSIST_MAX_STEPS) return hipErrorInvalidValue;
-  const dim3 g((unsigned)(m.nrec[m.rank] + 1), (unsigned)a.E), b(256);
+  if (m.reducers < 1 || m.reducers > PERSIST_MAX_REDUCERS || m.reducers > m.depth) return hipErrorInvalidValue;
+  if (m.reducers > 1 && r.sq_signal_error_sum != nullptr && m.serr_part == nullptr) return hipErrorInvalidValue;
+  const dim3 g((unsigned)(m.nrec[m.rank] + m.reducers), (unsigned)a.E), b(256);
   const bool bb = a.action_source == MDR_ACTIONS_BANGBANG;
 #define MDR_PERSIST_LAUNCH(VECV)                                                                                      \
   do {                                                                                                                \

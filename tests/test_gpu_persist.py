@@ -50,6 +50,8 @@ def _stepwise(env, T):
     (2, 4099, "common_L2", 21),           # nb_houses % 4 != 0: one house per lane, 256-house records
     (1, 1500, "common_max", 19),          # two workgroups: also serves envs the fused rollout kernel covers
     (4, 300, "individual_L2", 18),        # one house workgroup per env
+    (1, 300000, "mixture", 35),           # 293 records: two reducer workgroups take the steps in turn, partial error sums combined
+    (1, 800000, "individual_L2", 33),     # 782 records: four reducers
 ])
 def test_persistent_rollout_equals_single_steps(E, N, mode, T):
     import mdr_amd
