@@ -279,6 +279,20 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
     asm volatile("" : "+v"(hs[v].s1), "+v"(hs[v].inv_Ua), "+v"(hs[v].Q_hvac), "+v"(hs[v].P_max), "+v"(hs[v].target), "+v"(hs[v].deadband),
                  "+v"(hs[v].lockout), "+v"(rsum[v]));
   }
+  // A single wavefront issues one instruction every four cycles whatever its kind: this loop is bound by its INSTRUCTION COUNT on the
+  // busiest wave (r03 trace: 840 per step, half of them scalar address arithmetic and spilled-pointer reloads).  So: what changes from
+  // step to step in an address is the slot alone - each lane keeps its destination at slot 0 and adds slot * stride - and the
+  // exchange is spread over the waves: wave 0 picks the totals up, wave 1 pushes the record - lane L = (destination rank, granule).
+  constexpr int PUSH_WAVE = 1;
+  const int64_t rec_slot_stride = (int64_t)a.E * m.world * m.stride * PERSIST_G;   // granules from a slot to the next
+  const int64_t tot_slot_stride = (int64_t)a.E * PERSIST_TOT;
+  const int push_r = lane / ng, push_g = lane - (lane / ng) * ng;
+  const bool pusher = wave == PUSH_WAVE && push_r < m.world;
+  gu64* push_base = nullptr;
+#pragma unroll
+  for (int r = 0; r < MDR_MAX_SHARDS; ++r)
+    if (pusher && push_r == r) push_base = (gu64*)m.box[r] + rec_offset(m, a.E, 0, e, m.rank, blk) + push_g;
+  const gu64* const tot_base = own + tot_offset(m, a.E, 0, e) + min(lane, ng - 1);
   double terr = 0.0;
   Red3 tot{0.0, 0.0, 0.0f};
   float sig_term = 0.0f;
@@ -332,7 +346,7 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
       const uint32_t tag = m.tag_base + (uint32_t)(it - D);
       // (lanes past the granules that travel read the last one of them: every lane loads, no lane patches its register - a
       // constant moved into the register of a load in flight would cost a wait for everything in flight)
-      const gu64* src = own + tot_offset(m, a.E, (int)(tag % PERSIST_SLOTS), e) + min(lane, ng - 1);
+      const gu64* src = tot_base + (int64_t)(tag % PERSIST_SLOTS) * tot_slot_stride;
       uint32_t val = 0;
       bool failed = false;
       unsigned long long x = have_pre ? pre : granule_load<SYS>(src);
@@ -364,8 +378,9 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
     __syncthreads();
     MDR_STAMP(ro.power_trace, it, 3, tr);
     if (lds_fail[par]) return;
-    if (it < T) {
-      // this workgroup's record: the same arithmetic as block_reduce (every thread re-adds the wave partials in order)
+    if (it < T && wave == PUSH_WAVE) {
+      // this workgroup's record: the same arithmetic as block_reduce (the wave partials re-added in order), pushed by ONE store -
+      // lane (rank r, granule g) writes granule g of the record into rank r's mailbox
       Red3 rec{0.0, 0.0, 0.0f};
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
@@ -373,16 +388,12 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
         rec.sum_pen += lds_part[par][4 + w];
         rec.max_pen = fmaxf(rec.max_pen, (float)lds_part[par][8 + w]);
       }
-      if (wave == 0 && lane < ng) {
+      if (pusher) {
         const uint32_t tag = m.tag_base + (uint32_t)it;
-        const int slot = (int)(tag % PERSIST_SLOTS);
-        const uint32_t v = lane == 0 ? (uint32_t)__double2loint(rec.sum_p) : lane == 1 ? (uint32_t)__double2hiint(rec.sum_p)
-                         : lane == 2 ? (uint32_t)__double2loint(rec.sum_pen) : lane == 3 ? (uint32_t)__double2hiint(rec.sum_pen)
-                                     : __float_as_uint(rec.max_pen);
-        const int64_t off = rec_offset(m, a.E, slot, e, m.rank, blk) + lane;
-#pragma unroll
-        for (int r = 0; r < MDR_MAX_SHARDS; ++r)
-          if (r < m.world) granule_store<SYS>((gu64*)m.box[r] + off, tag, v);
+        const uint32_t v = push_g == 0 ? (uint32_t)__double2loint(rec.sum_p) : push_g == 1 ? (uint32_t)__double2hiint(rec.sum_p)
+                         : push_g == 2 ? (uint32_t)__double2loint(rec.sum_pen) : push_g == 3 ? (uint32_t)__double2hiint(rec.sum_pen)
+                                       : __float_as_uint(rec.max_pen);
+        granule_store<SYS>(push_base + (int64_t)(tag % PERSIST_SLOTS) * rec_slot_stride, tag, v);
       }
     }
     MDR_STAMP(ro.power_trace, it, 4, tr);
@@ -405,7 +416,7 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
       have_pre = it + 1 >= D && it + 1 < T + D;
       if (have_pre) {
         const uint32_t nxt = m.tag_base + (uint32_t)(it + 1 - D);
-        pre = granule_load<SYS>(own + tot_offset(m, a.E, (int)(nxt % PERSIST_SLOTS), e) + min(lane, ng - 1));
+        pre = granule_load<SYS>(tot_base + (int64_t)(nxt % PERSIST_SLOTS) * tot_slot_stride);
       }
     }
     MDR_STAMP(ro.power_trace, it, 5, tr);
