@@ -56,16 +56,16 @@ __device__ __forceinline__ int64_t tot_offset(const PersistArgs& m, int E, int s
 
 enum : uint32_t { PERSIST_FAIL_TOTALS = 1, PERSIST_FAIL_RECORDS = 2 };
 
-// error word (granule 0 of every rank's header): {tag | kind << 28 | workgroup}; a spinner that finds it set leaves as well
+// error word (granule 0 of every rank's header): {tag | kind << 28 | workgroup}; a spinner that finds it set leaves as well.
+// Lane r < world keeps rank r's header address (`abort_ptr`): the eight mailbox pointers then need not stay live in scalar
+// registers across the step loops for the sake of this cold path (they were spilled to vector lanes and reloaded every step).
 template <bool SYS>
-__device__ __forceinline__ void raise_abort(const PersistArgs& m, uint32_t tag, uint32_t kind) {
-#pragma unroll
-  for (int r = 0; r < MDR_MAX_SHARDS; ++r)
-    if (r < m.world) granule_store<SYS>((gu64*)m.box[r], tag, (kind << 28) | (blockIdx.x & 0x0FFFFFFFu));
+__device__ __forceinline__ void raise_abort(gu64* abort_ptr, uint32_t tag, uint32_t kind) {
+  if (abort_ptr != nullptr) granule_store<SYS>(abort_ptr, tag, (kind << 28) | (blockIdx.x & 0x0FFFFFFFu));
 }
 template <bool SYS>
-__device__ __forceinline__ bool abort_raised(const PersistArgs& m) {
-  return granule_load<SYS>((const gu64*)m.box[m.rank]) != 0ull;
+__device__ __forceinline__ bool abort_raised(const gu64* own) {
+  return granule_load<SYS>(own) != 0ull;
 }
 
 // BB: the bang-bang rule compiled in (the default controller; the general rule costs this latency-bound loop 0.3 us per step)
@@ -99,11 +99,16 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
   __shared__ int s_nrec[MDR_MAX_SHARDS];
   const bool need_pen = a.penalty_mode != MDR_PENALTY_INDIVIDUAL_L2;
   const int ng = need_pen ? PERSIST_G : 2;   // granules that travel: the power sum alone unless a common penalty mode needs the rest
-  const int e = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int e = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and known to be: the wave's roles below become scalar branches
   const int nblk = m.nrec[m.rank];
   const int T = ro.nsteps;
   const bool want_terr = ro.sq_temp_error_sum != nullptr;
   gu64* const own = (gu64*)m.box[m.rank];
+  gu64* abort_ptr = nullptr;
+#pragma unroll
+  for (int r = 0; r < MDR_MAX_SHARDS; ++r)
+    if (r < m.world && lane == r) abort_ptr = (gu64*)m.box[r];
   if (tid < MDR_MAX_SHARDS) s_nrec[tid] = tid < m.world ? m.nrec[tid] : 0;
   if (tid < 2) lds_fail[tid] = 0;
   for (int t = tid; t < ro.nsteps; t += 256) {
@@ -187,9 +192,9 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
         }
         if (ok) break;
         ++spins;
-        if (spins > m.spin_limit || ((spins & 63u) == 0u && abort_raised<SYS>(m))) {
+        if (spins > m.spin_limit || ((spins & 63u) == 0u && abort_raised<SYS>(own))) {
           failed = true;
-          if (spins > m.spin_limit) raise_abort<SYS>(m, tag, PERSIST_FAIL_RECORDS);
+          if (spins > m.spin_limit) raise_abort<SYS>(abort_ptr, tag, PERSIST_FAIL_RECORDS);
           break;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -355,9 +360,9 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
         val = (uint32_t)x;
         if (__all((uint32_t)(x >> 32) == tag)) break;
         ++spins;
-        if (spins > m.spin_limit || ((spins & 63u) == 0u && abort_raised<SYS>(m))) {
+        if (spins > m.spin_limit || ((spins & 63u) == 0u && abort_raised<SYS>(own))) {
           failed = true;
-          if (spins > m.spin_limit && lane == 0) raise_abort<SYS>(m, tag, PERSIST_FAIL_TOTALS);
+          if (spins > m.spin_limit) raise_abort<SYS>(abort_ptr, tag, PERSIST_FAIL_TOTALS);
           break;
         }
         __builtin_amdgcn_s_sleep(1);
