@@ -344,11 +344,47 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
         lds_part[par][8 + wave] = (double)acc.max_pen;
       }
     }
-    MDR_STAMP(ro.power_trace, it, 1, tr);
-    // wave 0 picks up the totals of step it - D (published by the reducer D steps of work ago); the load was issued at the end
-    // of the iteration before, so its latency lies behind this iteration's arithmetic
-    if (wave == 0 && it >= D) {
-      const uint32_t tag = m.tag_base + (uint32_t)(it - D);
+    MDR_STAMP(ro.power_trace, it, 2, tr);
+    __syncthreads();   // the wave partials of step `it`; and what wave 0 picked up at the end of the iteration before (lds_tot / lds_fail [par])
+    MDR_STAMP(ro.power_trace, it, 3, tr);
+    if (lds_fail[par]) return;
+    if (it < T && wave == PUSH_WAVE) {
+      // this workgroup's record: the same arithmetic as block_reduce (the wave partials re-added in order), pushed by ONE store -
+      // lane (rank r, granule g) writes granule g of the record into rank r's mailbox
+      Red3 rec{0.0, 0.0, 0.0f};
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        rec.sum_p += lds_part[par][w];
+        rec.sum_pen += lds_part[par][4 + w];
+        rec.max_pen = fmaxf(rec.max_pen, (float)lds_part[par][8 + w]);
+      }
+      if (pusher) {
+        const uint32_t tag = m.tag_base + (uint32_t)it;
+        const uint32_t v = push_g == 0 ? (uint32_t)__double2loint(rec.sum_p) : push_g == 1 ? (uint32_t)__double2hiint(rec.sum_p)
+                         : push_g == 2 ? (uint32_t)__double2loint(rec.sum_pen) : push_g == 3 ? (uint32_t)__double2hiint(rec.sum_pen)
+                                       : __float_as_uint(rec.max_pen);
+        granule_store<SYS>(push_base + (int64_t)(tag % PERSIST_SLOTS) * rec_slot_stride, tag, v);
+      }
+    }
+    MDR_STAMP(ro.power_trace, it, 4, tr);
+    if (it >= D) {   // rewards of step it - D, in step order
+      tot.sum_p = lds_tot[par][0];
+      tot.sum_pen = lds_tot[par][1];
+      tot.max_pen = (float)lds_tot[par][2];
+      sig_term = signal_term(a, tot.sum_p, row_sig_old[it - D]);
+      if (live) load_vec<VEC>(lds_hist, ((int64_t)(ring == D ? 0 : ring + 1) * 256 + tid) * VEC, pen_old);   // slot of step it - D
+      if (ro.reward_sum != nullptr && live) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) rsum[v] = __fadd_rn(rsum[v], reward_value(a, pen_old[v], tot.sum_pen, tot.max_pen, sig_term));
+      }
+    }
+    // Wave 0, at the END of the iteration: it picks up the totals the NEXT iteration's rewards need (step it + 1 - D; published by the
+    // reducer D - 1 steps of work ago) and leaves them in LDS behind that iteration's barrier, then requests the totals after them.
+    // A request thus has a whole iteration - compute, barrier, rewards - before its pick-up: a device-scope load is ~2000 cycles
+    // away, and picked up in the middle of the next iteration (r03, first form) wave 0 stood ~700 of them at the wait.
+    if (wave == 0 && it + 1 >= D && it + 1 < T + D) {
+      const int nxt_par = par ^ 1;
+      const uint32_t tag = m.tag_base + (uint32_t)(it + 1 - D);
       // (lanes past the granules that travel read the last one of them: every lane loads, no lane patches its register - a
       // constant moved into the register of a load in flight would cost a wait for everything in flight)
       const gu64* src = tot_base + (int64_t)(tag % PERSIST_SLOTS) * tot_slot_stride;
@@ -373,56 +409,13 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
       const int v2 = need_pen ? __builtin_amdgcn_readlane((int)val, 2) : 0, v3 = need_pen ? __builtin_amdgcn_readlane((int)val, 3) : 0;
       const int v4 = need_pen ? __builtin_amdgcn_readlane((int)val, 4) : 0;   // (granules that did not travel: zeros)
       if (lane == 0) {
-        lds_tot[par][0] = __hiloint2double(v1, v0);
-        lds_tot[par][1] = __hiloint2double(v3, v2);
-        lds_tot[par][2] = (double)__int_as_float(v4);
-        if (failed) lds_fail[par] = 1;
+        lds_tot[nxt_par][0] = __hiloint2double(v1, v0);
+        lds_tot[nxt_par][1] = __hiloint2double(v3, v2);
+        lds_tot[nxt_par][2] = (double)__int_as_float(v4);
+        if (failed) lds_fail[nxt_par] = 1;
       }
-    }
-    MDR_STAMP(ro.power_trace, it, 2, tr);
-    __syncthreads();
-    MDR_STAMP(ro.power_trace, it, 3, tr);
-    if (lds_fail[par]) return;
-    if (it < T && wave == PUSH_WAVE) {
-      // this workgroup's record: the same arithmetic as block_reduce (the wave partials re-added in order), pushed by ONE store -
-      // lane (rank r, granule g) writes granule g of the record into rank r's mailbox
-      Red3 rec{0.0, 0.0, 0.0f};
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        rec.sum_p += lds_part[par][w];
-        rec.sum_pen += lds_part[par][4 + w];
-        rec.max_pen = fmaxf(rec.max_pen, (float)lds_part[par][8 + w]);
-      }
-      if (pusher) {
-        const uint32_t tag = m.tag_base + (uint32_t)it;
-        const uint32_t v = push_g == 0 ? (uint32_t)__double2loint(rec.sum_p) : push_g == 1 ? (uint32_t)__double2hiint(rec.sum_p)
-                         : push_g == 2 ? (uint32_t)__double2loint(rec.sum_pen) : push_g == 3 ? (uint32_t)__double2hiint(rec.sum_pen)
-                                       : __float_as_uint(rec.max_pen);
-        granule_store<SYS>(push_base + (int64_t)(tag % PERSIST_SLOTS) * rec_slot_stride, tag, v);
-      }
-    }
-    MDR_STAMP(ro.power_trace, it, 4, tr);
-    if (it >= D) {   // rewards of step it - D, in step order
-      const int64_t row = (int64_t)(it - D) * a.E + e;
-      tot.sum_p = lds_tot[par][0];
-      tot.sum_pen = lds_tot[par][1];
-      tot.max_pen = (float)lds_tot[par][2];
-      sig_term = signal_term(a, tot.sum_p, row_sig_old[it - D]);
-      if (live) load_vec<VEC>(lds_hist, ((int64_t)(ring == D ? 0 : ring + 1) * 256 + tid) * VEC, pen_old);   // slot of step it - D
-      if (ro.reward_sum != nullptr && live) {
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) rsum[v] = __fadd_rn(rsum[v], reward_value(a, pen_old[v], tot.sum_pen, tot.max_pen, sig_term));
-      }
-    }
-    // the totals the NEXT iteration picks up, requested as the last memory operation of this one: issued any earlier - next to
-    // the pick-up above - hipcc's wait for the pick-up's own register (one counter, retired in order, unknown trip count of the
-    // spin) became a wait for this load too, and the request never overlapped anything
-    if (wave == 0) {
-      have_pre = it + 1 >= D && it + 1 < T + D;
-      if (have_pre) {
-        const uint32_t nxt = m.tag_base + (uint32_t)(it + 1 - D);
-        pre = granule_load<SYS>(tot_base + (int64_t)(nxt % PERSIST_SLOTS) * tot_slot_stride);
-      }
+      have_pre = it + 2 < T + D;
+      if (have_pre) pre = granule_load<SYS>(tot_base + (int64_t)((tag + 1u) % PERSIST_SLOTS) * tot_slot_stride);
     }
     MDR_STAMP(ro.power_trace, it, 5, tr);
   }
