@@ -1948,36 +1948,70 @@ __global__ __launch_bounds__(TILE) void k_obs_rows_default(ObsArgs a) {
   // boundary; the up-to-3 leading floats are covered by the group at o = lead - 4 through the scalar branch below
   const int lead = (int)(((16u - ((uint32_t)(uintptr_t)dst & 15u)) & 15u) >> 2);
   const bool multi = t.nenv > 1;
-  auto element = [&](int oo) {
-    const int r = (int)(((uint32_t)oo * 20561u) >> 20);   // == oo / 51 for every oo < 13107 (checked exhaustively)
-    const int f = oo - r * F;
+  // element (row r, feature f) of the tile; a thread's groups of four lie TILE * 4 floats apart = 20 rows and 4 features (1024 = 20 * 51
+  // + 4), so (r, f) of a group's first float is carried from group to group instead of divided out of its offset each time
+  auto element_rf = [&](int r, int f) {
     if (f < OWN) return ownbuf[r * OWNP + f];
     const int g = f - OWN;
     const int el = multi ? (int)(((uint32_t)r * a.magic_n) >> 20) : 0;
     if ((g & 3) == 1) return quot[r * C + (g >> 2)];
     return msg[4 * (r + C * el) + g + (g >= 20 ? 4 : 0)];
   };
-  if (lead == 0) {   // aligned tile (always the case when N * F % 4 == 0): no edge handling inside the loop
-    for (int o = tid * 4; o < total; o += TILE * 4) {
-      float v[4];
+  static_assert(TILE * 4 == 20 * F + 4, "the (row, feature) step of a thread's store grid");
+  const int last = total - 1;
+  const int rl = (int)(((uint32_t)last * 20561u) >> 20), fl = last - rl * F;   // the tile's last element (clamp target of the edge groups)
+  auto group = [&](int r, int f, float* v) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = element(min(o + q, total - 1));
+    for (int q = 0; q < 4; ++q) {
+      int rq = r, fq = f + q;
+      if (fq >= F) {
+        fq -= F;
+        ++rq;
+      }
+      const bool past = rq > rl || (rq == rl && fq > fl);
+      v[q] = element_rf(past ? rl : rq, past ? fl : fq);
+    }
+  };
+  if (lead == 0) {   // aligned tile (always the case when N * F % 4 == 0): no edge handling inside the loop
+    int o = tid * 4;
+    int r = (int)(((uint32_t)o * 20561u) >> 20), f = o - r * F;   // == o / 51, o % 51 for every o < 13107 (checked exhaustively)
+    for (; o < total; o += TILE * 4) {
+      float v[4];
+      group(r, f, v);
       if (o + 3 < total) {
         store_out<4>(dst, o, v);
       } else {
         for (int q = 0; q < 4 && o + q < total; ++q) dst[o + q] = v[q];
       }
+      r += 20;
+      f += 4;
+      if (f >= F) {
+        f -= F;
+        ++r;
+      }
     }
   } else {
-    for (int o = lead - 4 + tid * 4; o < total; o += TILE * 4) {
+    int o = lead - 4 + tid * 4;
+    if (o < 0) {   // the leading partial group (thread 0 only): its floats at o + q >= 0
+      for (int q = 0; q < 4; ++q)
+        if (o + q >= 0 && o + q < total) dst[o + q] = element_rf(0, o + q);   // (lead <= 3 floats: row 0, features 0 .. 2)
+      o += TILE * 4;
+    }
+    int r = (int)(((uint32_t)o * 20561u) >> 20), f = o - r * F;
+    for (; o < total; o += TILE * 4) {
       float v[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = element(min(max(o + q, 0), total - 1));
-      if (o >= 0 && o + 3 < total) {
+      group(r, f, v);
+      if (o + 3 < total) {
         store_out<4>(dst, o, v);
       } else {
         for (int q = 0; q < 4; ++q)
-          if (o + q >= 0 && o + q < total) dst[o + q] = v[q];
+          if (o + q < total) dst[o + q] = v[q];
+      }
+      r += 20;
+      f += 4;
+      if (f >= F) {
+        f -= F;
+        ++r;
       }
     }
   }
