@@ -94,18 +94,33 @@ __global__ __launch_bounds__(256) void k_load_envs(EpisodeArgs a, mdr_episode_t 
   a.b.ratio[e] = ep.ratio ? ep.ratio[e] : a.artificial_ratio;
 }
 
-// Local sum of max consumption per env (ClusterHouses.__init__, env 796-802) in a fixed order; P <- 0.
-__global__ __launch_bounds__(256) void k_env_max_power(EpisodeArgs a) {
+// Local sum of max consumption per env (ClusterHouses.__init__, env 796-802); P <- 0.  The sum is EXACT in fp64 whatever the order
+// (fp32 addends within a factor of 8 of each other: 24 + log2(N) significant bits), so an env of more than 65,536 houses is summed by
+// several workgroups through atomic adds - one workgroup took 0.98 ms for 1,000,000 houses at every episode start.
+constexpr int MAX_POWER_CHUNK = 65536;
+__global__ __launch_bounds__(256) void k_env_max_power(EpisodeArgs a, int chunks) {
   __shared__ double lds[3 * 4];
-  const int e = blockIdx.x;
+  const int e = blockIdx.x / chunks, c = blockIdx.x - e * chunks;
   const float* p = a.b.P_max + (int64_t)e * a.N;
+  const int lo = c * MAX_POWER_CHUNK, hi = chunks == 1 ? a.N : min(a.N, lo + MAX_POWER_CHUNK);
   Red3 v{0.0, 0.0, 0.0f};
-  for (int i = threadIdx.x; i < a.N; i += 256) v.sum_p += (double)p[i];
+  for (int i = lo + threadIdx.x; i < hi; i += 256) v.sum_p += (double)p[i];
   v = block_reduce<256>(v, lds);
   if (threadIdx.x == 0) {
-    a.b.max_power[e] = v.sum_p;
+    if (chunks == 1) a.b.max_power[e] = v.sum_p;
+    else atomicAdd(&a.b.max_power[e], v.sum_p);   // (zeroed by the launcher)
     a.b.P[e] = 0.0;
   }
+}
+
+static hipError_t launch_max_power(const EpisodeArgs& a, hipStream_t s) {
+  const int chunks = a.N > MAX_POWER_CHUNK ? (a.N + MAX_POWER_CHUNK - 1) / MAX_POWER_CHUNK : 1;
+  if (chunks > 1) {
+    const hipError_t e = hipMemsetAsync(a.b.max_power, 0, (size_t)a.E * sizeof(double), s);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k_env_max_power, dim3((unsigned)((int64_t)a.E * chunks)), dim3(256), 0, s, a, chunks);
+  return hipGetLastError();
 }
 
 // Observation planes right after reset (MADemandResponseEnv.reset, env 163-170): every HVAC is off
@@ -2126,16 +2141,14 @@ hipError_t launch_sample(const EpisodeArgs& a, hipStream_t s) {
   const int64_t n = (int64_t)a.E * a.N;
   hipLaunchKernelGGL(k_sample_houses, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_sample_envs, dim3((unsigned)((a.E + 255) / 256)), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_env_max_power, dim3((unsigned)a.E), dim3(256), 0, s, a);
-  return hipGetLastError();
+  return launch_max_power(a, s);
 }
 
 hipError_t launch_load(const EpisodeArgs& a, const mdr_episode_t& ep, hipStream_t s) {
   const int64_t n = (int64_t)a.E * a.N;
   hipLaunchKernelGGL(k_load_houses, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, ep);
   hipLaunchKernelGGL(k_load_envs, dim3((unsigned)((a.E + 255) / 256)), dim3(256), 0, s, a, ep);
-  hipLaunchKernelGGL(k_env_max_power, dim3((unsigned)a.E), dim3(256), 0, s, a);
-  return hipGetLastError();
+  return launch_max_power(a, s);
 }
 
 hipError_t launch_interp_base(const InterpArgs& a, hipStream_t s) {
