@@ -341,6 +341,17 @@ class LocalShardGroup:
             self._finish()
         return [(e.t["obs"], e.t["reward"]) for e in self.shards]
 
+    def step_controller(self, kind: str = "bangbang"):
+        """One step of every shard under a rule-based controller evaluated in-kernel (BatchedDemandResponseEnv.set_controller)."""
+        from . import _native as nat
+        if kind not in nat.CONTROLLERS:
+            raise ValueError("unknown controller %r" % (kind,))
+        for env in self.shards:
+            self._begin(env, env.t["actions"].data_ptr(), nat.CONTROLLERS[kind])
+        if self.nb_shards > 1:
+            self._finish()
+        return [(e.t["obs"], e.t["reward"]) for e in self.shards]
+
     def ranges(self, env):
         return [(e.house_offset, e.nb_houses) for e in self.shards], self.shards.index(env)
 

@@ -115,3 +115,33 @@ def test_deepcopy_keeps_the_controller_and_unknown_names_are_refused():
     env.rollout(9)
     twin.rollout(9)
     assert torch.equal(env.t["Ta"], twin.t["Ta"]) and torch.equal(env.t["flags"], twin.t["flags"])
+
+
+def test_sharded_steps_and_odd_house_counts_under_the_deadband_controller():
+    """The records path of sharded houses (three in-process shards) and the persistent rollout with one house per lane
+    (nb_houses % 4 != 0) apply the controller as the unsharded single steps do."""
+    import mdr_amd
+    from mdr_amd.sharding import LocalShardGroup
+    N = 14001
+    cfg = _cfg(N, mode="common_L2")
+    whole = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=2, device="cuda:0", seed=21, table_steps=16)
+    whole.reset(episode=0)
+    whole.set_controller("deadband")
+    group = LocalShardGroup(cfg, nb_envs=2, nb_shards=3, seed=21, table_steps=16)
+    group.reset(episode=0)
+    per = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=2, device="cuda:0", seed=21, table_steps=16)
+    per.reset(episode=0)
+    per.set_controller("deadband")
+    for _ in range(20):
+        whole.step_controller()
+        group.step_controller("deadband")
+    per.rollout_persistent(20)
+    lo = 0
+    for shard in group.shards:
+        hi = lo + shard.nb_houses
+        for name in ("Ta", "Tm", "sso", "flags", "actions"):
+            assert torch.equal(shard.t[name], whole.t[name][:, lo:hi]), name
+        assert torch.equal(shard.t["P"], whole.t["P"])
+        lo = hi
+    for name in STATE:
+        assert torch.equal(per.t[name], whole.t[name]), name
