@@ -1,4 +1,4 @@
-// Persistent sharded rollout for MI355X (gfx950, wave64): the bang-bang closed loop of one env whose houses span several
+// Persistent sharded rollout for MI355X (gfx950, wave64): the closed loop (bang-bang or another rule-based controller) of one env whose houses span several
 // workgroups - and several ranks - in ONE launch per time-table window, the houses resident in registers across steps, the
 // per-step exchange (cluster power sum, env 1042-1050; penalty sum / max, env 274-321) through a MAILBOX instead of a
 // kernel boundary and a collective.
@@ -16,7 +16,9 @@
 //                                accumulators (power trace, squared signal error);
 //   house workgroups             pick the totals up DEPTH steps later (the state does not depend on them - only the
 //                                rewards do - so the houses run ahead and the exchange latency is overlapped) and add the
-//                                step's rewards to the running sums in step order.
+//                                step's rewards to the running sums in step order.  Inside a house workgroup the exchange is
+//                                spread over the waves: wave 1 pushes the record (lane = destination rank x granule, one
+//                                store), wave 0 picks the totals up at the END of an iteration for the next one.
 //
 // Tags count steps over the life of the env handle (never reset, never a per-launch memset: a peer may already be pushing
 // into this rank's mailbox when the launch begins); slot = tag mod SLOTS.  Every spin is bounded: on expiry the workgroup
