@@ -305,6 +305,14 @@ int mdr_env_rollout_fused(mdr_env_t *env, uint8_t *actions, int32_t nb_steps, co
  * agents/bangbang_controllers.py classes as main-deploy.py:57-104 drives them.  -1 for anything else. */
 int mdr_env_set_controller(mdr_env_t *env, int action_source);
 
+/* GreedyMyopic (agents/greedy_myopic_controller.py:6-50): for every env, the houses ranked by -(house_temp - target) - hottest
+ * relative to its target first, equal ones in house order - and switched on one after the other while
+ *   p + total < reg_signal   or   (|p + total - reg_signal| < |total - reg_signal| and not hvac_lockout),   p = cooling_capacity / COP,
+ * a taken house adding p to total.  Writes the uint8 actions[E][N] for the CURRENT observation (reg_signal = the signal of the
+ * current time index); follow with mdr_env_step(env, actions, MDR_ACTIONS_EXTERNAL, stream).  One workgroup sorts an env in LDS:
+ * at most 2048 houses per env, unsharded houses (MDR_ERR_UNSUPPORTED otherwise). */
+int mdr_env_greedy_myopic_actions(mdr_env_t *env, uint8_t *actions, void *stream);
+
 /* Sharded houses (one env spans several devices).  Houses interact only through the cluster power sum (env 1042-1050)
  * and the common penalty sum / max (env 274-321): step_begin updates the local houses and leaves the local
  * reductions in tot_sum/tot_max; the caller all-reduces them (SUM / MAX); step_end writes rewards and the

@@ -140,7 +140,7 @@ EXPORTS = (
     "mdr_env_interp_due", "mdr_env_interp_local", "mdr_env_interp_apply", "mdr_obs_vector_length", "mdr_env_obs_vector",
     "mdr_obs_message_fields", "mdr_env_obs_messages", "mdr_env_obs_vector_ext", "mdr_env_comm_draws",
     "mdr_env_graph_room", "mdr_env_graph_replayed", "mdr_env_pack", "mdr_env_cursor", "mdr_env_set_cursor", "mdr_env_active_tables",
-    "mdr_env_set_controller", "mdr_mailbox_bytes", "mdr_persist_records", "mdr_env_rollout_persistent",
+    "mdr_env_set_controller", "mdr_env_greedy_myopic_actions", "mdr_mailbox_bytes", "mdr_persist_records", "mdr_env_rollout_persistent",
     "mdr_mailbox_alloc", "mdr_mailbox_free", "mdr_mailbox_export", "mdr_mailbox_open", "mdr_mailbox_close", "mdr_mailbox_peek",
     # include/mdr_policy.h
     "mdr_actor_steps1", "mdr_actor_steps1_order", "mdr_actor_steps2", "mdr_actor_frag1_floats", "mdr_actor_frag2_floats", "mdr_actor_sample", "mdr_env_actor_sample",
@@ -192,6 +192,7 @@ def load():
         "mdr_env_rollout": (C.c_int, [vp, vp, C.c_int, i32, vp]),
         "mdr_env_rollout_fused": (C.c_int, [vp, vp, i32, C.POINTER(MdrRolloutOut), vp]),
         "mdr_env_set_controller": (C.c_int, [vp, C.c_int]),
+        "mdr_env_greedy_myopic_actions": (C.c_int, [vp, vp, vp]),
         "mdr_env_step_begin": (C.c_int, [vp, vp, C.c_int, vp]),
         "mdr_env_step_end": (C.c_int, [vp, vp]),
         "mdr_env_step_end_gathered": (C.c_int, [vp, vp, i32, vp]),

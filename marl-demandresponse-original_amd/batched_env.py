@@ -467,6 +467,19 @@ class BatchedDemandResponseEnv:
         nat.check(self._lib, self._handle, rc, "mdr_env_set_controller")
         self._controller = nat.CONTROLLERS[kind]
 
+    def greedy_myopic_actions(self) -> torch.Tensor:
+        """GreedyMyopic (agents/greedy_myopic_controller.py): per env, the houses ranked hottest-relative-to-target first and switched
+        on while the power budget ``reg_signal`` lasts (the reference's rule, lockout quirk included).  Returns ``self.t['actions']``
+        (uint8 [E, N]) for the current observation; at most 2048 houses per env, unsharded."""
+        with torch.cuda.device(self.device):
+            rc = self._lib.mdr_env_greedy_myopic_actions(self._handle, C.c_void_p(self.t["actions"].data_ptr()), self._stream())
+            nat.check(self._lib, self._handle, rc, "mdr_env_greedy_myopic_actions")
+        return self.t["actions"]
+
+    def step_greedy_myopic(self):
+        """One step under the GreedyMyopic controller: its actions (one launch), then the step."""
+        return self.step(self.greedy_myopic_actions())
+
     def step_controller(self):
         """One step with the controller of ``set_controller`` evaluated in-kernel; the actions taken land in ``self.t['actions']``."""
         self._step(self.t["actions"].data_ptr(), getattr(self, "_controller", nat.ACTIONS_BANGBANG))

@@ -7,7 +7,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ("mdr_kernels.hip", "mdr_multi.hip", "mdr_persist.hip", "mdr_api.hip", "mdr_policy.hip")
+SOURCES = ("mdr_kernels.hip", "mdr_multi.hip", "mdr_persist.hip", "mdr_control.hip", "mdr_api.hip", "mdr_policy.hip")
 HEADERS = ("mdr_device.h", "mdr_kernels.h", "mdr_step_common.h", os.path.join("..", "..", "include", "mdr.h"), os.path.join("..", "..", "include", "mdr_policy.h"))
 OUTPUT = os.path.join(CSRC, "libmdr_hip.so")
 

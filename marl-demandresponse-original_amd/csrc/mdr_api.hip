@@ -812,6 +812,21 @@ int mdr_env_rollout_fused(mdr_env_t* env, uint8_t* actions, int32_t nb_steps, co
   return MDR_OK;
 }
 
+int mdr_env_greedy_myopic_actions(mdr_env_t* env, uint8_t* actions, void* stream) {
+  if (!env) return MDR_ERR_INVALID;
+  if (!actions) return fail(env, MDR_ERR_INVALID, "actions is NULL");
+  if (!env->bound || !env->has_tables) return fail(env, MDR_ERR_UNBOUND, "no episode: call reset/load_episode and begin_episode first");
+  if (sharded(env)) return fail(env, MDR_ERR_UNSUPPORTED, "GreedyMyopic ranks ALL houses of an env: not over sharded houses");
+  if (env->cfg.nb_houses > 2048) return fail(env, MDR_ERR_UNSUPPORTED, "GreedyMyopic: at most 2048 houses per env (one workgroup sorts an env)");
+  if (env->split_pending) return fail(env, MDR_ERR_INVALID, "step_begin without step_end");
+  mdr::StepArgs a;
+  int rc = step_args(env, actions, MDR_ACTIONS_EXTERNAL, (hipStream_t)stream, &a);   // sig_old = the signal of the current time index
+  if (rc != MDR_OK) return rc;
+  const hipError_t e = mdr::launch_greedy_myopic(a, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(env, e, "greedy_myopic");
+  return MDR_OK;
+}
+
 int mdr_env_set_controller(mdr_env_t* env, int action_source) {
   if (!env) return MDR_ERR_INVALID;
   if (action_source != MDR_ACTIONS_BANGBANG && action_source != MDR_ACTIONS_DEADBAND && action_source != MDR_ACTIONS_ALWAYS_ON)

@@ -231,6 +231,7 @@ hipError_t launch_pack_env(const StepArgs& a, int e, double temp_ref, const doub
                            const double* abs_noise_row, double* out, hipStream_t s);
 hipError_t launch_cursor_set(int32_t* cursor, int32_t row, int32_t k, hipStream_t s);
 hipError_t launch_signal_error(const StepArgs& a, double* sq_signal_error_sum, hipStream_t s);   // += (sig_old - P)^2
+hipError_t launch_greedy_myopic(const StepArgs& a, hipStream_t s);   // GreedyMyopic actions of every env -> a.actions (mdr_control.hip); N <= 2048
 hipError_t launch_reset_obs(const StepArgs& a, bool zero_reward, hipStream_t s);  // planes of the current state; uses sig_old = the row of the current time index
 hipError_t launch_step(const StepArgs& a, const StepPlan& p, hipStream_t s);
 int64_t multi_blocks(int64_t E, const StepPlan& p);

@@ -826,6 +826,23 @@ class OracleEnv:
         half = self.deadband / 2
         return np.where(self.Ta < self.target - half, False, np.where(self.Ta > self.target + half, True, self.on.astype(bool)))
 
+    def greedy_myopic_actions(self):
+        """agents/greedy_myopic_controller.py:29-50: houses sorted by -(house_temp - target) ascending (equal ones in house order:
+        pandas leaves that open), then one greedy pass against the budget reg_signal; a house is taken iff
+        p + total < target  or  (|p + total - target| < |total - target| and not hvac_lockout),  p = cooling_capacity / COP."""
+        E, N = self.Ta.shape
+        out = np.zeros((E, N), dtype=bool)
+        power = self.capacity / self.COP
+        for e in range(E):
+            order = np.argsort(-(self.Ta[e] - self.target[e]), kind="stable")
+            target, total = float(self.S[e]), 0.0
+            for h in order:
+                p = float(power[e, h])
+                if p + total < target or (abs(p + total - target) < abs(total - target) and not self.lock[e, h]):
+                    total += p
+                    out[e, h] = True
+        return out
+
     def always_on_actions(self):
         """agents/bangbang_controllers.py:1-10 (AlwaysOnController)."""
         return np.ones(self.Ta.shape, dtype=bool)

@@ -75,6 +75,18 @@ def _install_standins():
 _loaded = {}
 
 
+def _greedy_myopic():
+    """agents/greedy_myopic_controller.py (needs pandas); its module-level memory is reset so that a fresh set of controller objects
+    starts at time step 0 again."""
+    import agents.greedy_myopic_controller as gm
+
+    def make(agent_properties, config_dict, num_state=None):
+        if agent_properties["id"] == 0:
+            gm.global_myopic_memory[0] = gm.global_myopic_memory[1] = None
+        return gm.GreedyMyopic(agent_properties, config_dict, num_state)
+    return make
+
+
 def load_reference():
     """Returns a namespace dict: MADemandResponseEnv, config_dict, utils and the rule-based controllers of agents/bangbang_controllers.py."""
     if _loaded:
@@ -95,5 +107,5 @@ def load_reference():
     import utils as ref_utils                                     # noqa: E402
     _loaded.update(MADemandResponseEnv=MADemandResponseEnv, HVAC=HVAC, config_dict=config_dict,
                    utils=ref_utils, BangBangController=BangBangController, DeadbandBangBangController=DeadbandBangBangController,
-                   BasicController=BasicController, AlwaysOnController=AlwaysOnController)
+                   BasicController=BasicController, AlwaysOnController=AlwaysOnController, GreedyMyopic=_greedy_myopic())
     return _loaded

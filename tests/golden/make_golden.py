@@ -179,6 +179,10 @@ def run_scenario(name, patches, seed, T, policy, perlin=False, norm_steps=(0, 1,
             others = {i: ref[cls]({"id": i}, cfg) for i in range(N)}
             # (AlwaysOnController.act returns True whatever it is handed; the other two index obs by their id themselves)
             a = {i: others[i].act(obs) for i in range(N)}
+        elif policy == "greedy_myopic":      # the centralised baseline: one object per house sharing a module-level memory
+            if t == 0:
+                greedy = {i: ref["GreedyMyopic"]({"id": i}, cfg) for i in range(N)}
+            a = {i: bool(greedy[i].act(obs)) for i in range(N)}
         elif policy == "on":
             a = {i: True for i in range(N)}
         elif policy == "off":
@@ -421,6 +425,8 @@ def main_controllers():
                                              "noise_house_prop.noise_mode": "big_noise", "default_hvac_prop.lockout_noise": 10}, 71, 600, "deadband")
     run_scenario("s14_controller_basic", {CL + "nb_agents": 6, PG + "signal_mode": "flat", "default_house_prop.deadband": 2.0}, 72, 400, "basic")
     run_scenario("s14_controller_always_on", {CL + "nb_agents": 5, PG + "signal_mode": "flat"}, 73, 150, "always_on")
+    run_scenario("s14_controller_greedy_myopic", {CL + "nb_agents": 14, PG + "signal_mode": "sinusoidals", "noise_house_prop.noise_mode": "big_noise",
+                                                  "noise_hvac_prop.noise_mode": "big_noise", "default_hvac_prop.lockout_noise": 10}, 74, 400, "greedy_myopic")
 
 
 if __name__ == "__main__":

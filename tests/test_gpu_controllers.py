@@ -145,3 +145,52 @@ def test_sharded_steps_and_odd_house_counts_under_the_deadband_controller():
         lo = hi
     for name in STATE:
         assert torch.equal(per.t[name], whole.t[name]), name
+
+
+def test_greedy_myopic_closed_loop_reproduces_the_reference():
+    """agents/greedy_myopic_controller.py on the device (mdr_env_greedy_myopic_actions: per-env ranking in LDS + the budget pass)
+    against the S14 fixture - the reference env under the reference's own GreedyMyopic objects (pandas sort_values + iterrows)."""
+    g = gu.Golden("s14_controller_greedy_myopic")
+    a = g.a
+    env = _env_for(g)
+    for t in range(g.T):
+        acts = env.greedy_myopic_actions()
+        assert np.array_equal(acts[0].cpu().numpy(), a["actions"][t]), t
+        _, reward, _, info = env.step(acts)
+        fl = env.t["flags"][0].cpu().numpy()
+        assert np.array_equal(fl & 1, a["on"][t]) and np.array_equal((fl >> 1) & 1, a["lock"][t]), t
+        assert info["cluster_hvac_power"][0].item() == a["P"][t]
+        np.testing.assert_allclose(env.house_temp()[0].cpu().numpy(), a["Ta"][t], rtol=1e-5, atol=0)
+
+
+@pytest.mark.parametrize("E,N", [(300, 20), (64, 50), (16, 1024), (3, 2048), (5, 777)])
+def test_greedy_myopic_matches_the_oracle_on_batches(E, N):
+    """Every kernel form (64- and 256-thread workgroups, padded sorts) against the oracle's restatement on device-sampled episodes."""
+    import mdr_amd
+    from oracle import mdr_oracle as mo
+    cfg = _cfg(N)
+    env = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=11, table_steps=16)
+    env.reset(episode=0)
+    ora = mo.OracleEnv.mirror(env) if hasattr(mo.OracleEnv, "mirror") else None
+    for t in range(12):
+        acts = env.greedy_myopic_actions().clone()
+        # the rule itself, restated on the device's own state (fp64 pass over the fp32 powers, houses ranked by the fp32 difference)
+        Ta, tg = env.t["Ta"].cpu().numpy(), env.t["target"].cpu().numpy()
+        pw = env.t["P_max"].cpu().numpy().astype(np.float64)
+        lock = ((env.t["flags"].cpu().numpy() >> 1) & 1).astype(bool)
+        sig = env.reg_signal().cpu().numpy()
+        want = np.zeros((E, N), dtype=np.uint8)
+        for e in range(E):
+            order = np.argsort(-(Ta[e] - tg[e]), kind="stable")
+            total = 0.0
+            for h in order:
+                p = pw[e, h]
+                if p + total < sig[e] or (abs(p + total - sig[e]) < abs(total - sig[e]) and not lock[e, h]):
+                    total += p
+                    want[e, h] = 1
+        assert np.array_equal(acts.cpu().numpy(), want), t
+        env.step(acts)
+    big = mdr_amd.BatchedDemandResponseEnv(_cfg(4096), nb_envs=1, device="cuda:0", seed=1)
+    big.reset(episode=0)
+    with pytest.raises(Exception):
+        big.greedy_myopic_actions()

@@ -66,10 +66,12 @@ def test_bangbang_rule_matches_recorded_actions():
 
 
 @pytest.mark.parametrize("name,rule", [("s14_controller_deadband", "deadband_actions"), ("s14_controller_basic", "deadband_actions"),
-                                       ("s14_controller_always_on", "always_on_actions")])
+                                       ("s14_controller_always_on", "always_on_actions"),
+                                       ("s14_controller_greedy_myopic", "greedy_myopic_actions")])
 def test_other_controllers_match_recorded_actions(name, rule):
     """agents/bangbang_controllers.py: DeadbandBangBangController 13-38, BasicController 64-88 (the same rule), AlwaysOnController
-    1-10, restated in OracleEnv and held to the actions the reference's own controller objects took in the S14 fixtures."""
+    1-10, and agents/greedy_myopic_controller.py (the centralised ranking + budget pass), restated in OracleEnv and held to the
+    actions the reference's own controller objects took in the S14 fixtures."""
     g = gu.Golden(name)
     env = replay(g)
     held = 0
