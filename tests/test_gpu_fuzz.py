@@ -154,12 +154,14 @@ def test_fuzz_fused_rollout_equals_stepwise(idx):
     a.reset(episode=episode)
     b.reset(episode=episode)
     pre = int(rng.integers(0, 5))
+    kind = str(np.random.default_rng(19000 + idx).choice(["bangbang", "bangbang", "deadband", "always_on"]))   # (own stream: the cases of the rounds before stay what they were)
     for env in (a, b):
         env.rollout(pre)
+        env.set_controller(kind)
     rsum = torch.zeros((E, N), dtype=torch.float32, device="cuda:0")
     trace = []
     for _ in range(steps):
-        _, r, _, info = a.step_bangbang()
+        _, r, _, info = a.step_controller()
         rsum += r
         trace.append(a.t["P"].clone())
     res = b.rollout_fused(steps, power_trace=True)
@@ -170,6 +172,55 @@ def test_fuzz_fused_rollout_equals_stepwise(idx):
     assert torch.equal(rsum, res["reward_sum"])
     oa, ob = a.obs_vector("rows"), b.obs_vector("rows")       # lockout 0 (duration 1 - noise 1) gives 0/0 columns, as in the reference
     assert torch.equal(torch.nan_to_num(oa, nan=-7.0), torch.nan_to_num(ob, nan=-7.0))
+
+
+@pytest.mark.parametrize("idx", range(40 * SCALE))
+def test_fuzz_persistent_rollout_equals_rollout(idx):
+    """mdr_env_rollout_persistent (mailbox exchange inside ONE launch per table window) ends where `rollout` - one launch per step,
+    split / fused / grouped kernels by shape - ends, bit for bit: any shape that stays resident, penalty mode, controller, table
+    length and step count; the accumulators against their stepwise sums."""
+    import mdr_amd
+    rng = np.random.default_rng(23000 + idx)
+    cfg = mdr_amd.default_config()
+    env_prop = cfg["default_env_prop"]
+    N = int(rng.choice([1, 5, 64, 255, 1024, 1025, 3000, 4097, 9999, 20000, 65536]))
+    E = int(rng.integers(1, max(2, min(12, 600 // (N // 256 + 2)))))
+    env_prop["cluster_prop"]["nb_agents"] = N
+    env_prop["power_grid_prop"]["base_power_mode"] = "constant"
+    env_prop["power_grid_prop"]["signal_mode"] = str(rng.choice(["flat", "sinusoidals", "regular_steps", "perlin"]))
+    env_prop["reward_prop"]["temp_penalty_mode"] = str(rng.choice(["individual_L2", "common_L2", "common_max", "mixture"]))
+    env_prop["start_datetime_mode"] = "random"
+    cfg["default_house_prop"]["deadband"] = float(rng.choice([0.0, 1.0, 2.0]))
+    cfg["noise_house_prop"]["noise_mode"] = str(rng.choice(["no_noise", "small_noise", "big_noise"]))
+    cfg["noise_hvac_prop"]["noise_mode"] = str(rng.choice(["no_noise", "big_noise"]))
+    seed, table_steps, T = int(rng.integers(0, 2 ** 40)), int(rng.choice([4, 16, 64])), int(rng.integers(1, 90))
+    kind = str(rng.choice(["bangbang", "deadband", "always_on"]))
+    a = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=seed, table_steps=table_steps)
+    b = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=seed, table_steps=table_steps)
+    for env in (a, b):
+        env.reset(episode=int(idx % 3))
+        env.set_controller(kind)
+        env.rollout(int(idx % 4))
+    rsum = torch.zeros((E, N), dtype=torch.float32, device="cuda:0")
+    trace = []
+    for _ in range(T):
+        _, r, _, _ = a.step_controller()
+        rsum += r
+        trace.append(a.t["P"].clone())
+    res = b.rollout_persistent(T, power_trace=True)
+    assert b.persist_status() == 0
+    for key in ("Ta", "Tm", "sso", "flags", "actions", "P", "obs"):
+        assert torch.equal(a.t[key], b.t[key]), "%s differs, case %d (E=%d N=%d T=%d %s)" % (key, idx, E, N, T, kind)
+    assert torch.equal(torch.stack(trace), res["power_trace"]), "case %d" % idx
+    # rewards: the persistent kernel re-sums the penalties in the order of the records path (1024-house records); an env of up to
+    # 4096 houses steps through the one-workgroup kernels, whose penalty sum is rounded in another order - equal bits only where the
+    # reward does not involve that sum (individual_L2) or the stepwise path IS the records path (more than 4096 houses)
+    if env_prop["reward_prop"]["temp_penalty_mode"] == "individual_L2" or N > 4096:
+        assert torch.equal(a.t["reward"], b.t["reward"]), "reward differs, case %d (E=%d N=%d T=%d %s)" % (idx, E, N, T, kind)
+        assert torch.equal(rsum, res["reward_sum"]), "case %d" % idx
+    else:
+        torch.testing.assert_close(b.t["reward"], a.t["reward"], rtol=2e-6, atol=1e-6)
+        torch.testing.assert_close(res["reward_sum"], rsum, rtol=2e-5, atol=1e-4)
 
 
 def _interp_case(idx):
