@@ -226,6 +226,33 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
 
 
 @torch.no_grad()
+def deploy_controller(env, kind: str, nb_steps: int) -> Dict[str, torch.Tensor]:
+    """The evaluation loop of main-deploy.py:99-152 under one of the reference's rule-based agents (``agents_dict`` of
+    main-deploy.py:22-34) for all envs at once: "bangbang", "deadband", "basic", "always_on" run inside the step kernels
+    (``env.set_controller``; the houses stay in registers across steps where a fused rollout kernel exists), "greedy_myopic" ranks
+    the houses of every env on the device before each step.  Returns the metrics the script accumulates: ``reward_sum`` [E, N],
+    ``sq_temp_error_sum`` [E], ``sq_signal_error_sum`` [E]."""
+    if kind != "greedy_myopic":
+        env.set_controller(kind)
+        out = None if env.sharded else env.rollout_fused(int(nb_steps))
+        if out is not None:
+            return out
+    E, N = env.nb_envs, env.nb_houses
+    out = {"reward_sum": torch.zeros((E, N), dtype=torch.float32, device=env.device),
+           "sq_temp_error_sum": torch.zeros(E, dtype=torch.float64, device=env.device),
+           "sq_signal_error_sum": torch.zeros(E, dtype=torch.float64, device=env.device)}
+    for _ in range(int(nb_steps)):
+        if kind == "greedy_myopic":
+            _, r, _, info = env.step_greedy_myopic()
+        else:
+            _, r, _, info = env.step_controller()
+        out["reward_sum"] += r
+        d = (env.t["Ta"] - env.t["target"]).double()
+        out["sq_temp_error_sum"] += (d * d).sum(dim=1)
+        out["sq_signal_error_sum"] += (env.reg_signal() - info["cluster_hvac_power"]) ** 2
+    return out
+
+
 def deploy_policy(env, policy, nb_steps: int, seed: int = 0, use_graph: Optional[bool] = None) -> Dict[str, torch.Tensor]:
     """The evaluation loop of main-deploy.py:99-152 with a learned agent (PPOAgent / DQNAgent, agents/rl_controllers.py) for all
     envs at once: every step observation -> ``policy`` (a ``FusedActor``; ``greedy=True`` for a DQN network) -> ``env.step``,

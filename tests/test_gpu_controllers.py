@@ -194,3 +194,28 @@ def test_greedy_myopic_matches_the_oracle_on_batches(E, N):
     big.reset(episode=0)
     with pytest.raises(Exception):
         big.greedy_myopic_actions()
+
+
+def test_deploy_controller_accumulates_what_the_stepwise_loop_does():
+    """rollout.deploy_controller (main-deploy.py's loop under a rule-based agent): the fused rollout's accumulators for the in-kernel
+    rules, a step loop for GreedyMyopic - against plain stepping with the sums kept on the side."""
+    import mdr_amd
+    from mdr_amd.rollout import deploy_controller
+    for kind in ("deadband", "greedy_myopic"):
+        cfg = _cfg(100)
+        a = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=40, device="cuda:0", seed=8, table_steps=16)
+        b = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=40, device="cuda:0", seed=8, table_steps=16)
+        a.reset(episode=0)
+        b.reset(episode=0)
+        got = deploy_controller(a, kind, 30)
+        if kind != "greedy_myopic":
+            b.set_controller(kind)
+        rsum = torch.zeros_like(got["reward_sum"])
+        serr = torch.zeros_like(got["sq_signal_error_sum"])
+        for _ in range(30):
+            _, r, _, info = b.step_greedy_myopic() if kind == "greedy_myopic" else b.step_controller()
+            rsum += r
+            serr += (b.reg_signal() - info["cluster_hvac_power"]) ** 2
+        assert torch.equal(a.t["Ta"], b.t["Ta"]) and torch.equal(a.t["flags"], b.t["flags"]), kind
+        assert torch.equal(got["reward_sum"], rsum), kind
+        torch.testing.assert_close(got["sq_signal_error_sum"], serr, rtol=1e-12, atol=0)
