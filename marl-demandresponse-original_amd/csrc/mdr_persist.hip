@@ -159,7 +159,10 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
           x[k][g] = (have[k] && g < g_now) ? granule_load<SYS>(base + off[k] + g) : ((unsigned long long)tag << 32);
     };
     if (j <= last) fetch(j);
-    for (int s = j; s <= last; s += R) {
+    // (`par`: the reductions of THIS reducer alternate between the two LDS scratch sets - with an even number of reducers the
+    // parity of its steps never changes, and one barrier per reduction only separates a set's readers from the writers after next)
+    int par = 0;
+    for (int s = j; s <= last; s += R, par ^= 1) {
       const uint32_t tag = m.tag_base + (uint32_t)s;
       const int slot = (int)(tag % PERSIST_SLOTS);
       const int g_now = (s == T) ? 2 : ng;
@@ -205,9 +208,9 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
       MDR_STAMP(ro.power_trace, s, 8, tid == 0 && e == 0);
       MDR_NOTE(ro.power_trace, s, 11, tid == 0 && e == 0, spins);
       if (s + R <= last) fetch(s + R);   // in flight across the reduction and the publication below
-      if (failed) lds_fail[s & 1] = 1;
-      tot = block_reduce<256>(acc, lds_part[s & 1]);   // one barrier: the failure flag rides on it
-      if (lds_fail[s & 1]) return;
+      if (failed) lds_fail[par] = 1;
+      tot = block_reduce<256>(acc, lds_part[par]);   // one barrier: the failure flag rides on it
+      if (lds_fail[par]) return;
       MDR_STAMP(ro.power_trace, s, 9, tid == 0 && e == 0);
       if (s == T) {
         if (tid == 0) ro.sq_temp_error_sum[e] += tot.sum_p;
