@@ -2236,11 +2236,10 @@ hipError_t launch_tables(const TableArgs& a, hipStream_t s) {
       tl.minutes = (int)minutes;
       const int slots = perlin ? tl.base[a.perlin_octaves] : 0;
       const size_t lds = (size_t)slots * TABLE_TILE_ENVS * sizeof(uint32_t);
-      static const bool raised = [] {
-        return hipFuncSetAttribute((const void*)k_fill_tables_tile, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   TABLE_TILE_MAX_SLOTS * TABLE_TILE_ENVS * (int)sizeof(uint32_t)) == hipSuccess;
-      }();
-      if (raised || lds <= 32768) {
+      // (beyond 64 KB of dynamic LDS the limit is raised per launch: the attribute belongs to the current device)
+      const bool raised = lds <= 65536 || hipFuncSetAttribute((const void*)k_fill_tables_tile, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                TABLE_TILE_MAX_SLOTS * TABLE_TILE_ENVS * (int)sizeof(uint32_t)) == hipSuccess;
+      if (raised) {
         hipLaunchKernelGGL(k_fill_tables_tile, dim3((unsigned)((a.E + TABLE_TILE_ENVS - 1) / TABLE_TILE_ENVS)), dim3(256), lds, s, a, tl);
         return hipGetLastError();
       }
