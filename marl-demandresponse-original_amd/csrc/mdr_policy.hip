@@ -605,9 +605,10 @@ __device__ __forceinline__ T ld32(const T* base, uint32_t byte_offset) {
 }
 
 // the per-house / per-env columns of the extended form (thermal, hvac: per house, divided by their defaults; the rest: k_observe_env_extras)
+template <bool ENV = true>   // ENV = false: the per-env columns come later (observe_env_extras_now: whole-tile staging, one env per tile)
 __device__ __forceinline__ void observe_load_extras(const mdr::ObserveArgs& o, HouseRegs& r, uint32_t i4, int e) {
   if (o.f_thermal) {
-    r.x_od = o.env_extra_a[e];
+    if (ENV) r.x_od = o.env_extra_a[e];
     r.Ua = ld32(o.Ua, i4) * o.inv_Ua;
     r.Cm = ld32(o.Cm, i4) * o.inv_Cm;
     r.Ca = ld32(o.Ca, i4) * o.inv_Ca;
@@ -617,6 +618,23 @@ __device__ __forceinline__ void observe_load_extras(const mdr::ObserveArgs& o, H
     r.COP = ld32(o.COP, i4) * o.inv_COP;
     r.latent = ld32(o.latent, i4) * o.inv_latent;
   }
+  if (!ENV) return;
+  if (o.f_day) {
+    r.x_sd = o.env_extra_a[(int64_t)o.E + e];
+    r.x_cd = o.env_extra_a[2 * (int64_t)o.E + e];
+  }
+  if (o.f_hour) {
+    r.x_sh = o.env_extra_a[3 * (int64_t)o.E + e];
+    r.x_ch = o.env_extra_b[e];
+  }
+  if (o.f_solar) r.x_sol = o.env_extra_b[(int64_t)o.E + e];
+}
+
+// The per-env columns of ONE env, fetched when its tile's rows are staged (whole-tile staging: up to six registers less to carry
+// from the loads before layer 1 to the staging behind it; the index is wave-uniform)
+__device__ __forceinline__ void observe_env_extras_now(const mdr::ObserveArgs& o, HouseRegs& r, int e_uniform) {
+  const int e = __builtin_amdgcn_readfirstlane(e_uniform);
+  if (o.f_thermal) r.x_od = o.env_extra_a[e];
   if (o.f_day) {
     r.x_sd = o.env_extra_a[(int64_t)o.E + e];
     r.x_cd = o.env_extra_a[2 * (int64_t)o.E + e];
@@ -691,7 +709,7 @@ __device__ __forceinline__ HouseRegs observe_load(const mdr::ObserveArgs& o, con
       r.sso = ld32(o.sso, i4);
       r.lk = ld32(o.lockout, i4);
       r.fl = ld32(o.flags, i1);
-      observe_load_extras(o, r, i4, e);
+      observe_load_extras<false>(o, r, i4, e);
     } else {
       r.Ta = o.Ta[i];
       r.Tm = o.Tm[i];
@@ -710,7 +728,7 @@ __device__ __forceinline__ HouseRegs observe_load(const mdr::ObserveArgs& o, con
 }
 
 template <int TILE, bool EXT = false, int ROWC = 0>
-__device__ __forceinline__ void observe_stage(const mdr::ObserveArgs& o, const HouseRegs& r, float* rows, int lane) {
+__device__ __forceinline__ void observe_stage(const mdr::ObserveArgs& o, const HouseRegs& r, float* rows, int lane, int e = 0) {
   const float4 rec = make_float4((r.Ta - r.tg) * 0.2f, (float)r.sso, ((r.fl & 1u) ? r.pm : 0.0f) * o.inv_norm_reg, r.pm * o.inv_norm_reg);
   if (EXT) {
     const int before = o.before, c = o.c;
@@ -724,7 +742,9 @@ __device__ __forceinline__ void observe_stage(const mdr::ObserveArgs& o, const H
       if (rr >= 0 && rr < TILE) *reinterpret_cast<float4*>(rows + rr * ROW + 4 * m) = rec;
     }
     const int rr = lane - before;
-    if (rr >= 0 && rr < TILE) observe_write_own_ext(o, r, rows + rr * ROW, c, ROW);
+    HouseRegs own = r;
+    observe_env_extras_now(o, own, e);
+    if (rr >= 0 && rr < TILE) observe_write_own_ext(o, own, rows + rr * ROW, c, ROW);
     return;
   }
   if (lane >= TILE + 2 * OBS_HALO) return;
@@ -1049,7 +1069,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
       observe_stage_gen<EXT>(o, first, slot, rows);
     } else {
       const HouseRegs first = observe_load<TILE, EXT>(o, sig_row, tc.e, tc.h0, lane);
-      observe_stage<TILE, EXT>(o, first, rows, lane);
+      observe_stage<TILE, EXT>(o, first, rows, lane, tc.e);
     }
     observe_window_fence();
     gather((int64_t)wave * TILE);
@@ -1109,7 +1129,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
     for (int s = 0; s < S2B; ++s) {
       if (s == 1 && more) {
         if (GEN) observe_stage_gen<EXT>(o, nxt, slot, rows);
-        else observe_stage<TILE, EXT>(o, nxt, rows, lane);
+        else observe_stage<TILE, EXT>(o, nxt, rows, lane, tc.e);
       }
       bf16x8 Bh[NCB], Bl[NCB];
 #pragma unroll
@@ -1245,7 +1265,7 @@ __global__ __launch_bounds__(64 * (EXTK ? WAVES16_EXT : WAVES16)) void k_actor_o
       observe_stage_gen<EXT, EXT ? ROW : 0>(o, first, slot, rows);
     } else {
       const HouseRegs first = observe_load<TILE, EXT>(o, sig_row, tc.e, tc.h0, lane);
-      observe_stage<TILE, EXT, EXT ? ROW : 0>(o, first, rows, lane);
+      observe_stage<TILE, EXT, EXT ? ROW : 0>(o, first, rows, lane, tc.e);
     }
     observe_window_fence();
     gather(wave * TILE);
@@ -1280,7 +1300,7 @@ __global__ __launch_bounds__(64 * (EXTK ? WAVES16_EXT : WAVES16)) void k_actor_o
     // while the accumulators of layer 2 do not exist yet)
     if (STAGE_Q < 0 && more) {
       if (GEN) observe_stage_gen<EXT, EXT ? ROW : 0>(o, nxt, slot, rows);
-      else observe_stage<TILE, EXT, EXT ? ROW : 0>(o, nxt, rows, lane);
+      else observe_stage<TILE, EXT, EXT ? ROW : 0>(o, nxt, rows, lane, tc.e);
     }
     f32x4 out[MB];
 #pragma unroll
@@ -1289,7 +1309,7 @@ __global__ __launch_bounds__(64 * (EXTK ? WAVES16_EXT : WAVES16)) void k_actor_o
     for (int q = 0; q < 4 * MB; ++q) {
       if (q == STAGE_Q && more) {
         if (GEN) observe_stage_gen<EXT, EXT ? ROW : 0>(o, nxt, slot, rows);
-        else observe_stage<TILE, EXT, EXT ? ROW : 0>(o, nxt, rows, lane);
+        else observe_stage<TILE, EXT, EXT ? ROW : 0>(o, nxt, rows, lane, tc.e);
       }
       if (q < a.S2) {
         const float b = relu(TAIL && q >= 4 * (MB - 1) ? pick_register(acc[MB - 1], g) : acc[q >> 2][q & 3]);   // tail: k-index g is unit 96 + g
