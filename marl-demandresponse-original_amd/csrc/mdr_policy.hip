@@ -772,6 +772,7 @@ __device__ __forceinline__ void observe_stage(const mdr::ObserveArgs& o, const H
 struct SegSlot {
   int j, hs, len, rb;   // this lane's house in its segment's env; the segment's receivers [hs, hs + len) = tile rows [rb, rb + len)
   bool live;
+  int e;                // ... and that env (the extended form fetches its per-env columns when the rows are staged)
 };
 
 template <int TILE, bool EXT = false>
@@ -779,7 +780,7 @@ __device__ __forceinline__ HouseRegs observe_load_gen(const mdr::ObserveArgs& o,
                                                       int lane, SegSlot& slot) {
   const int before = EXT ? o.before : OBS_HALO, c = EXT ? o.c : 2 * OBS_HALO;   // senders before the house / in all (env 816-828)
   HouseRegs r{};
-  slot = SegSlot{0, 0, 0, 0, false};
+  slot = SegSlot{0, 0, 0, 0, false, 0};
   // the segment walk is wave-uniform: keep it on the scalar unit (the tile index comes out of threadIdx, which the compiler
   // cannot see is uniform across the wave)
   int rem = __builtin_amdgcn_readfirstlane((int)((A - a0) < (int64_t)TILE ? (A - a0) : (int64_t)TILE));
@@ -793,7 +794,7 @@ __device__ __forceinline__ HouseRegs observe_load_gen(const mdr::ObserveArgs& o,
     if (lane >= wb && lane < wb + wlen) {
       int j = start + (lane - wb);
       j -= j >= o.N ? o.N : 0;
-      slot = SegSlot{j, hs, len, rb, true};
+      slot = SegSlot{j, hs, len, rb, true, e};
       my_e = e;
     }
     wb += wlen;
@@ -815,7 +816,7 @@ __device__ __forceinline__ HouseRegs observe_load_gen(const mdr::ObserveArgs& o,
       r.sso = ld32(o.sso, i4);
       r.lk = ld32(o.lockout, i4);
       r.fl = ld32(o.flags, i1);
-      observe_load_extras(o, r, i4, my_e);
+      observe_load_extras<false>(o, r, i4, my_e);
     } else {
       r.Ta = o.Ta[i];
       r.Tm = o.Tm[i];
@@ -851,7 +852,21 @@ __device__ __forceinline__ void observe_stage_gen(const mdr::ObserveArgs& o, con
   }
   const int k = slot.j - slot.hs;
   if (EXT) {
-    if (k >= 0 && k < slot.len) observe_write_own_ext(o, r, rows + (slot.rb + k) * ROW, c, ROW);
+    if (k >= 0 && k < slot.len) {
+      HouseRegs own = r;
+      const int e = slot.e;      // per lane here: a tile may span envs
+      if (o.f_thermal) own.x_od = o.env_extra_a[e];
+      if (o.f_day) {
+        own.x_sd = o.env_extra_a[(int64_t)o.E + e];
+        own.x_cd = o.env_extra_a[2 * (int64_t)o.E + e];
+      }
+      if (o.f_hour) {
+        own.x_sh = o.env_extra_a[3 * (int64_t)o.E + e];
+        own.x_ch = o.env_extra_b[e];
+      }
+      if (o.f_solar) own.x_sol = o.env_extra_b[(int64_t)o.E + e];
+      observe_write_own_ext(o, own, rows + (slot.rb + k) * ROW, c, ROW);
+    }
     return;
   }
   if (k >= 0 && k < slot.len) {
