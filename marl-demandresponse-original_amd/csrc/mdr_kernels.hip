@@ -1805,30 +1805,27 @@ __global__ __launch_bounds__(TILE) void k_obs_tiled(ObsArgs a) {
   }
 }
 
-// ---- rows layout, circular neighbours: one workgroup per TILE consecutive houses of one env.  Only the COMPACT data
-// is staged in LDS - each house's own features [TILE][own], the senders' message fields [(TILE + c)][mf] and the
-// receivers' lockout - and the output rows are then generated directly in output order (element o = r * F + f) and
-// streamed with 16-byte stores.  ~17 KB of LDS per 256 houses, so occupancy is not LDS-bound and HBM sees each state
-// array once while the 10x message fan-out is served from LDS.
+// ---- rows layout, circular neighbours: one workgroup per TILE consecutive houses of one env - or, for envs of fewer than TILE
+// houses, per TILE / N whole envs (the reference trains with 20 houses and deploys with 50: one env per 256-thread workgroup left
+// four threads in five idle and took 3x the time of the default-shape kernel).  Only the COMPACT data is staged in LDS - each
+// house's own features [TILE][own], the senders' message fields of every env segment [(houses + c)][mf] and the receivers'
+// lockout - and the output rows are then generated directly in output order (element o = r * F + f) and streamed with 16-byte
+// stores.  HBM sees each state array once while the 10x message fan-out is served from LDS.
 template <int TILE>
 __global__ __launch_bounds__(TILE) void k_obs_rows(ObsArgs a) {
   rebase(a);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
-  const int tpe = (a.N + TILE - 1) / TILE;              // 1-D grid: tile id -> (env, first house)
-  const int e = (int)(blockIdx.x / (unsigned)tpe);
-  const int h0 = (int)(blockIdx.x - (unsigned)e * (unsigned)tpe) * TILE;
-  const int h = h0 + tid;
-  const int nh = min(TILE, a.N - h0);
-  const int64_t base = (int64_t)e * a.N;
+  const ObsTile t = obs_tile<TILE>(a, blockIdx.x);
   const int mf = 4 + (a.m_thermal ? 4 : 0) + (a.m_hvac ? 3 : 0);
   const int own = a.F - a.c * mf;
   const int ownp = own | 1;
-  const int span = TILE + a.c;
+  const int entries = t.nenv * (t.nh + a.c);             // staged senders: per env segment its houses and the c around them
   const int before = a.c / 2;
+  const bool multi = t.nenv > 1;
   float* ownbuf = lds;                                   // [TILE][ownp]
-  float* msg = ownbuf + TILE * ownp;                     // [span][mf]
-  float* lock_f = msg + span * mf;                       // [TILE] the receiver's lockout L ...
+  float* msg = ownbuf + TILE * ownp;                     // [a.lds_entries][mf]
+  float* lock_f = msg + a.lds_entries * mf;              // [TILE] the receiver's lockout L ...
   float* lock_r = lock_f + TILE;                         // [TILE] ... and RN(1 / L)
   uint32_t* dead = reinterpret_cast<uint32_t*>(lock_r + TILE);   // [TILE] bit m: message slot m is defective
   uint32_t* desc = dead + TILE;                          // [F] where element f of a row comes from
@@ -1846,29 +1843,15 @@ __global__ __launch_bounds__(TILE) void k_obs_rows(ObsArgs a) {
     }
     desc[f] = d;
   }
-  for (int idx = tid; idx < span; idx += TILE) {
-    int j = (h0 - before + idx) % a.N;
-    if (j < 0) j += a.N;
-    const MsgFields m = sender_from_global(a, base + j);
-    float* d = msg + idx * mf;
-    d[0] = m.diff;
-    d[1] = m.sso;
-    d[2] = m.curr;
-    d[3] = m.pmax;
-    int q = 4;
-    if (a.m_thermal) {
-      d[q] = m.Ua; d[q + 1] = m.Cm; d[q + 2] = m.Ca; d[q + 3] = m.Hm;
-      q += 4;
-    }
-    if (a.m_hvac) {
-      d[q] = m.COP; d[q + 1] = m.latent; d[q + 2] = m.cap;
-    }
-  }
-  if (h < a.N) {
+  stage_tile_senders<false>(a, t, msg, entries, mf, tid, TILE);
+  if (tid < t.rows) {
+    const int el = multi ? (int)(((uint32_t)tid * a.magic_n) >> 20) : 0;
+    const int e = t.e0 + el, h = t.h0 + tid - el * a.N;
+    const int64_t i = (int64_t)e * a.N + h;
     int f = 0;
-    obs_features<1, false>(a, e, h, base + h, [&](const float* v) { ownbuf[tid * ownp + f] = v[0]; ++f; },
+    obs_features<1, false>(a, e, h, i, [&](const float* v) { ownbuf[tid * ownp + f] = v[0]; ++f; },
                            [&](int, int) { return MsgFields{}; });
-    lock_f[tid] = (float)a.lockout[base + h];
+    lock_f[tid] = (float)a.lockout[i];
     lock_r[tid] = 1.0f / lock_f[tid];
     uint32_t mask = 0;
     if (a.defect_prob > 0.0f) {
@@ -1884,7 +1867,8 @@ __global__ __launch_bounds__(TILE) void k_obs_rows(ObsArgs a) {
     dead[tid] = mask;
   }
   __syncthreads();
-  float* dst = a.out + (base + h0) * a.F;          // nh * F contiguous floats
+  float* dst = a.out + ((int64_t)t.e0 * a.N + t.h0) * a.F;          // rows * F contiguous floats
+  const int nh = t.rows;
   const int total = nh * a.F;
   const bool vec = (((uintptr_t)dst) & 15u) == 0;
   const bool defects = a.defect_prob > 0.0f;
@@ -1898,7 +1882,8 @@ __global__ __launch_bounds__(TILE) void k_obs_rows(ObsArgs a) {
       const int rc = min(rr, nh - 1);
       const uint32_t d = desc[ff];
       const bool is_msg = (d & D_MSG) != 0u;
-      float val = lds[(is_msg ? msg_base + rc * mf : rc * ownp) + (int)(d & 0xFFFFu)];
+      const int el = multi ? (int)(((uint32_t)rc * a.magic_n) >> 20) : 0;   // the row's env segment: its senders start c * el entries further
+      float val = lds[(is_msg ? msg_base + (rc + a.c * el) * mf : rc * ownp) + (int)(d & 0xFFFFu)];
       if (d & D_SSO) val = div_by_lockout(val, lock_f[rc], lock_r[rc]);   // sender's seconds_since_off over the RECEIVER's lockout (utils.py:849-851)
       if (defects && is_msg && ((dead[rc] >> ((d >> 16) & 63u)) & 1u)) val = 0.0f;
       v[q] = val;
@@ -2103,8 +2088,9 @@ hipError_t launch_obs_vector(const ObsArgs& a_in, int layout, hipStream_t s) {
   if (layout == MDR_OBS_ROWS && circular && a.c <= 32 && (a.c + 1) * (int)nf < 65536) {
     constexpr int RT = 256;
     const size_t own = (size_t)(a.F - a.c * (int)nf) | 1;
-    const size_t lds_bytes = (RT * own + (RT + a.c) * nf + 3 * RT + a.F) * sizeof(float);
-    const int64_t tiles = a.E * (int64_t)((a.N + RT - 1) / RT);
+    a.lds_entries = a.N < RT ? (RT / a.N) * (a.N + a.c) : RT + a.c;   // senders staged per tile: whole small envs, or a chunk of a big one
+    const size_t lds_bytes = (RT * own + (size_t)a.lds_entries * nf + 3 * RT + a.F) * sizeof(float);
+    const int64_t tiles = obs_tile_count<RT>(a.E, a.N);
     if (lds_bytes <= lds_cap && tiles < (int64_t)1 << 31)
       return launch_with_lds(k_obs_rows<RT>, dim3((unsigned)tiles), dim3(RT), lds_bytes, s, a);
   }
