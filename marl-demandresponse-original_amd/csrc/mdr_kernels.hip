@@ -1870,23 +1870,32 @@ __global__ __launch_bounds__(TILE) void k_obs_rows(ObsArgs a) {
   float* dst = a.out + ((int64_t)t.e0 * a.N + t.h0) * a.F;          // rows * F contiguous floats
   const int nh = t.rows;
   const int total = nh * a.F;
-  const bool vec = (((uintptr_t)dst) & 15u) == 0;
+  // the tile's first byte is only 4-byte aligned in general (odd F): the 16-byte store grid starts at the next boundary, the
+  // up-to-3 leading floats go out singly (thread 0)
+  const int lead = (int)(((16u - ((uint32_t)(uintptr_t)dst & 15u)) & 15u) >> 2);
   const bool defects = a.defect_prob > 0.0f;
-  int r = (tid * 4) / a.F, f = tid * 4 - r * a.F;
+  auto element = [&](int rc, int ff) {
+    const uint32_t d = desc[ff];
+    const bool is_msg = (d & D_MSG) != 0u;
+    const int el = multi ? (int)(((uint32_t)rc * a.magic_n) >> 20) : 0;   // the row's env segment: its senders start c * el entries further
+    float val = lds[(is_msg ? msg_base + (rc + a.c * el) * mf : rc * ownp) + (int)(d & 0xFFFFu)];
+    if (d & D_SSO) val = div_by_lockout(val, lock_f[rc], lock_r[rc]);   // sender's seconds_since_off over the RECEIVER's lockout (utils.py:849-851)
+    if (defects && is_msg && ((dead[rc] >> ((d >> 16) & 63u)) & 1u)) val = 0.0f;
+    return val;
+  };
+  if (tid == 0)
+    for (int q = 0; q < lead && q < total; ++q) dst[q] = element(q / a.F, q % a.F);
+  const int o0 = lead + tid * 4;
+  int r = o0 / a.F, f = o0 - r * a.F;
   const int dr = (TILE * 4) / a.F, df = TILE * 4 - dr * a.F;
-  for (int o = tid * 4; o < total; o += TILE * 4) {
+  const bool vec = true;
+  for (int o = o0; o < total; o += TILE * 4) {
     float v[4];
     int rr = r, ff = f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int rc = min(rr, nh - 1);
-      const uint32_t d = desc[ff];
-      const bool is_msg = (d & D_MSG) != 0u;
-      const int el = multi ? (int)(((uint32_t)rc * a.magic_n) >> 20) : 0;   // the row's env segment: its senders start c * el entries further
-      float val = lds[(is_msg ? msg_base + (rc + a.c * el) * mf : rc * ownp) + (int)(d & 0xFFFFu)];
-      if (d & D_SSO) val = div_by_lockout(val, lock_f[rc], lock_r[rc]);   // sender's seconds_since_off over the RECEIVER's lockout (utils.py:849-851)
-      if (defects && is_msg && ((dead[rc] >> ((d >> 16) & 63u)) & 1u)) val = 0.0f;
-      v[q] = val;
+      v[q] = element(rc, ff);
       if (++ff == a.F) {
         ff = 0;
         ++rr;
