@@ -226,6 +226,49 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
 
 
 @torch.no_grad()
+def collect_dqn_transitions(env, q_net: nn.Module, nb_steps: int, epsilon: float = 1.0, epsilon_decay: float = 1.0,
+                            min_epsilon: float = 0.0, seed: int = 0, policy_precision: str = "fp32") -> Dict[str, torch.Tensor]:
+    """The interaction loop of train_dqn.py:55-91 for all envs at once, transitions kept on the GPU: every step the epsilon-greedy
+    action of ``q_net`` (agents/network.py DQN_network: the same MLP stack as the PPO actor; ``DQNAgent.select_action`` is an argmax -
+    agents/dqn.py:52-56 - evaluated by the fused policy kernel in its greedy form), ``env.step``, and the transition
+    (state, action, reward, next_state) of ``store_transition`` (agents/dqn.py:58-63).  Exploration as the reference's loop ends up doing it:
+    its per-agent draw (train_dqn.py:61-65) is overwritten by ONE draw per step (67-70) - with probability epsilon every agent of the env
+    acts at random, otherwise every agent acts greedily; here one such draw per env and step.  epsilon <- max(epsilon * decay, min)
+    after every step (19-22, 91).  Returns ``state`` [T + 1, E*N, F] (``state[t + 1]`` is ``next_state[t]``), ``action`` int64,
+    ``reward`` [T, E*N], ``explored`` bool [T, E] and the final ``epsilon``."""
+    from .policy import FusedActor
+    E, N = env.nb_envs, env.nb_houses
+    dev = env.device
+    F_len = env.obs_vector_length()
+    T = int(nb_steps)
+    layout = None
+    if policy_precision == "bf16x3" and q_net.fc[0].in_features <= 64:
+        from .policy import BF16X3
+        layout = BF16X3
+    greedy = FusedActor.from_module(q_net, device=dev, layout=layout, greedy=True)
+    state = torch.empty((T + 1, E * N, F_len), dtype=torch.float32, device=dev)
+    action = torch.empty((T, E * N), dtype=torch.int64, device=dev)
+    reward = torch.empty((T, E * N), dtype=torch.float32, device=dev)
+    explored = torch.empty((T, E), dtype=torch.bool, device=dev)
+    act = torch.empty(E * N, dtype=torch.uint8, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(int(seed))
+    eps = float(epsilon)
+    env.obs_vector("rows", out=state[0].view(E, N, F_len))
+    for t in range(T):
+        greedy.sample(state[t], seed, env.steps_taken, action=act)
+        coin = torch.rand(E, device=dev, generator=gen) < eps
+        random_act = torch.randint(0, 2, (E, N), device=dev, generator=gen, dtype=torch.uint8)
+        chosen = torch.where(coin[:, None], random_act, act.view(E, N))
+        _, r, _, _ = env.step(chosen)
+        action[t] = chosen.view(-1).to(torch.int64)
+        reward[t] = r.view(-1)
+        explored[t] = coin
+        env.obs_vector("rows", out=state[t + 1].view(E, N, F_len))
+        eps = max(eps * float(epsilon_decay), float(min_epsilon))
+    return {"state": state, "action": action, "reward": reward, "explored": explored, "epsilon": eps}
+
+
 def deploy_controller(env, kind: str, nb_steps: int) -> Dict[str, torch.Tensor]:
     """The evaluation loop of main-deploy.py:99-152 under one of the reference's rule-based agents (``agents_dict`` of
     main-deploy.py:22-34) for all envs at once: "bangbang", "deadband", "basic", "always_on" run inside the step kernels

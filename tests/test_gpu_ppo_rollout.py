@@ -145,3 +145,36 @@ def test_discounted_returns_kernel_equals_the_torch_scan(with_bootstrap):
         R = r64[t] + 0.97 * R
         exp.insert(0, R)
     np.testing.assert_allclose(got[:, 5].cpu().numpy(), exp, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_dqn_transitions_follow_the_greedy_network_and_the_global_coin():
+    """rollout.collect_dqn_transitions (train_dqn.py:55-91): with epsilon 0 every action is the argmax of the Q-network on the stored
+    state (the plain fp32 torch forward; agents whose two Q-values lie within 1e-5 of each other aside), with epsilon 1 every env explores,
+    in between whole envs explore or exploit; next_state[t] is state[t + 1] and what the env observes after the step."""
+    import mdr_amd
+    from mdr_amd.rollout import ActorMLP, collect_dqn_transitions
+    cfg = mdr_amd.default_config()
+    cfg["default_env_prop"]["cluster_prop"]["nb_agents"] = 50
+    cfg["default_env_prop"]["power_grid_prop"]["base_power_mode"] = "constant"
+    torch.manual_seed(3)
+    env = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=64, device="cuda:0", seed=4)
+    env.reset(episode=0)
+    q = ActorMLP(env.obs_vector_length()).to("cuda:0")      # DQN_network has the Actor's stack of Linear layers (agents/network.py:58-77)
+    out = collect_dqn_transitions(env, q, 6, epsilon=0.0, seed=1)
+    assert not bool(out["explored"].any())
+    with torch.no_grad():
+        x = out["state"][:-1]
+        for i, layer in enumerate(q.fc):
+            x = layer(x)
+            if i < 2:
+                x = torch.relu(x)
+    clear = (x[..., 0] - x[..., 1]).abs() > 1e-5
+    assert torch.equal(out["action"][clear], x.argmax(dim=-1)[clear]) and float(clear.float().mean()) > 0.99
+    assert torch.equal(out["state"][-1].view(64, 50, -1), env.obs_vector("rows"))
+    assert torch.equal(out["reward"][-1].view(64, 50), env.t["reward"])
+    every = collect_dqn_transitions(env, q, 4, epsilon=1.0, seed=2)
+    assert bool(every["explored"].all()) and 0.4 < float(every["action"].float().mean()) < 0.6
+    mixed = collect_dqn_transitions(env, q, 8, epsilon=0.5, epsilon_decay=0.9, min_epsilon=0.1, seed=3)
+    frac = float(mixed["explored"].float().mean())
+    assert 0.2 < frac < 0.6 and abs(mixed["epsilon"] - 0.5 * 0.9 ** 8) < 1e-12
