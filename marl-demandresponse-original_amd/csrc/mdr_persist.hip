@@ -310,12 +310,11 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
   bool have_pre = false;
   for (int it = 0, ring = 0; it < T + D; ++it, ring = (ring == D ? 0 : ring + 1)) {   // ring = it mod (D + 1)
     const int par = it & 1;
-    const bool tr = tid == 0 && blk == 0 && e == 0 && it < T;
+    [[maybe_unused]] const bool tr = tid == 0 && blk == 0 && e == 0 && it < T;   // (trace build only)
     MDR_STAMP(ro.power_trace, it, 0, tr);
     // the step `it` itself: needs nothing from the other workgroups
     Red3 acc{0.0, 0.0, 0.0f};
     if (it < T) {
-      const int64_t row = (int64_t)it * a.E + e;
       const float od_old = row_od[it], solar = row_solar[it];
       if (live) {
         float p = 0.0f, ps = 0.0f, te = 0.0f;
@@ -439,7 +438,6 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
   }
   if (!live) return;
   // final state, and the last step's outputs exactly as the single-step kernels leave them
-  const int64_t row = (int64_t)(T - 1) * a.E + e;
   const float o_sig = (float)(row_sig_new[T - 1] * a.inv_obs_norm);
   const float o_pow = (float)(tot.sum_p * a.inv_obs_norm);
   float nTa[VEC], nTm[VEC], pen[VEC];

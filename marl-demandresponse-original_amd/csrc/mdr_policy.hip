@@ -382,7 +382,6 @@ __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
 }
 
 constexpr int WAVESB = 8;    // 2 per SIMD: two column blocks of accumulators (~200 registers per lane)
-constexpr int WAVESB_EXT = 6; // the extended observe -> act form: its 68-float rows make a window 8.8 KB, six of them fit beside the 96 KB of weight fragments
 constexpr int NCB = 2;       // 16-agent column blocks per wavefront: every weight fragment read from LDS feeds NCB MFMAs (with one block
                              // the fragment reads, 84 KB per 16 agents, kept the LDS busier than the matrix pipe)
 
@@ -574,7 +573,7 @@ constexpr int OBS_HALO = 5, OBS_C = 10, OBS_ROW = 56, OBS_PAD = 16;   // floats;
 // normStateDict index (k < 4 c ? own + k : k - 4 c), the packed weights follow (mdr_actor_t.feature_order = 1), F = 4 c + own <= 64.
 // The row stride of the extended form is a run-time value (ObserveArgs.row; L and 1 / L sit in its floats row - 2, row - 1): the
 // features rounded up to 16 bytes, so that as many windows fit the LDS as for the default shape where the shape allows it.
-constexpr int OBS_ROW_MAX = 68, OBS_MAX_C = 13;   // (run-time strides: 4 c + own + 2 rounded up to 4 * odd, at most 68)
+constexpr int OBS_MAX_C = 13;                         // (run-time strides: 4 c + own + 2 rounded up to 4 * odd, at most 68)
 typedef float v4f_nt __attribute__((ext_vector_type(4)));
 
 // between a wave's window stores and its loads of what OTHER lanes stored
