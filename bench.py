@@ -394,6 +394,15 @@ PERSIST_NOTE = ("mdr_env_rollout_persistent: ONE launch per 64-step table window
                 "c5 leg's")
 
 
+def _persist_floor(leg):
+    """What a step that STREAMS its state would cost at the HBM figure (the records path: 107 B per house-step - SURVEY 8e / VERDICT r2:
+    13.4 us at 1,000,000 houses, 1.7 us at 125,000) beside the measured step: the persistent kernel keeps the state in registers."""
+    if "us_per_step" in leg and "houses_per_rank" in leg:
+        floor = leg["houses_per_rank"] * 107 / 8.0e12 * 1e6
+        leg["streaming_step_floor_us"] = floor
+        leg["vs_streaming_step_floor"] = floor / leg["us_per_step"]
+
+
 def c5_persistent_leg(rk: Ranks, mdr, args):
     """BASELINE.json configs[4] without a kernel boundary or a collective per step ('compare RCCL vs a P2P mailbox')."""
     K = args.c5_steps
@@ -407,6 +416,7 @@ def c5_persistent_leg(rk: Ranks, mdr, args):
         m = persist_measure(env, K, rk.fence, rk.max_over_ranks)
         base.update(m)
         base.update({"value": C5_HOUSES * K / (m["us_per_step"] * 1e-6 * K), "houses_per_rank": C5_HOUSES, "exchange": "mailbox on this device (a world of one)"})
+        _persist_floor(base)
         return base
     # N > 1: peer mailboxes over hipIpc / xGMI have never run on hardware before the driver's own scaling run - every rank measures
     # in a child process of its own (own process group over gloo, no RCCL: the data path has no collective), so that whatever
@@ -425,6 +435,7 @@ def c5_persistent_leg(rk: Ranks, mdr, args):
         raise RuntimeError("child rc %d: %s" % (res.returncode, (res.stderr or res.stdout)[-400:]))
     if rk.rank == 0:
         base.update(json.loads(lines[-1]))
+        _persist_floor(base)
     return base
 
 
