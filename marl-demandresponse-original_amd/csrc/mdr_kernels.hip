@@ -2286,13 +2286,16 @@ StepPlan plan_step(int N, int64_t E) {
     return p;
   }
   // Device-filling batches with N % 4 == 0 whose N / 4 lanes are not a power of two: whole envs packed into the wavefront
-  // (k_step_packed) where rounding each env up to a power of two would leave more than 40 % of the lanes idle - 36 houses: 9 lanes
-  // of 16 -> 63 of 64, 67.9 -> 64.4 us at 4.19 M houses.  (Measured and left alone: 20 houses, 5 lanes of 8 -> 60 of 64: 64.0 -> 64.1 us;
-  // 12 and 40 houses lose 1-2 % - at these sizes the step is bound by its memory INSTRUCTIONS per wave, not by idle lanes.)
+  // (k_step_packed) where rounding each env up to a power of two would leave more than 35 % of the lanes idle - 36 houses: 9 lanes
+  // of 16 -> 63 of 64, 67.9 -> 64.4 us at 4.19 M houses.  20 and 40 houses (5 of 8, 10 of 16 lanes) gain nothing as a STEP - it is
+  // bound by its memory instructions per wave, not by idle lanes - but their multi-step rollouts, which share the step's lane mapping
+  // bit for bit and are vector-bound, run 11-12 % faster packed (20 houses: 14.2 -> 12.7 us per step of 4.19 M houses); 12 and 24
+  // houses (3 of 4, 6 of 8 lanes) lose 2-3 % as steps and stay unpacked.
   static const bool packed_ok = [] { const char* t = getenv("MDR_PLAN_PACKED"); return !(t && t[0] == '0'); }();
   if (packed_ok && N % 4 == 0 && N >= 12 && N <= 128 && E * N >= 262144) {
     const int L = N / 4, per_wave = 64 / L;
-    if ((L & (L - 1)) != 0 && 10 * L < 6 * pow2_at_least(L) && per_wave * pow2_at_least(L) > 64) {
+    static const int fill_pm = [] { const char* t = getenv("MDR_PLAN_PACKED_FILL"); return t ? atoi(t) : 650; }();   // experiment knob: pack below this lane fill (per mille)
+    if ((L & (L - 1)) != 0 && 1000 * L < fill_pm * pow2_at_least(L) && per_wave * pow2_at_least(L) > 64) {
       p.kind = STEP_PACKED;
       p.vec = 4;
       p.threads = L;

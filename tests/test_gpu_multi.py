@@ -35,7 +35,7 @@ def _envs(N, odd=False):
                                         (30, "common_max", False), (126, "mixture", True), (14, "individual_L2", False), (66, "common_L2", True),
                                         # N % 4 == 0 with N / 4 lanes not a power of two: whole envs packed into the wavefront (k_step_packed)
                                         (36, "individual_L2", False), (36, "mixture", True), (68, "common_L2", False), (72, "common_max", True),
-                                        (76, "mixture", False)])
+                                        (76, "mixture", False), (20, "mixture", False), (20, "individual_L2", True), (40, "common_L2", True)])
 def test_multi_env_groups_match_oracle_and_single_env_groups(N, mode, odd):
     import mdr_amd
     from oracle import mdr_oracle as mo
@@ -76,7 +76,8 @@ def test_multi_env_groups_match_oracle_and_single_env_groups(N, mode, odd):
 
 
 @pytest.mark.parametrize("N,mode,odd", [(50, "mixture", False), (50, "individual_L2", True), (10, "common_max", False), (126, "common_L2", True),
-                                        (36, "mixture", False), (36, "individual_L2", True), (72, "common_L2", True), (76, "common_max", False)])
+                                        (36, "mixture", False), (36, "individual_L2", True), (72, "common_L2", True), (76, "common_max", False),
+                                        (20, "common_max", True), (40, "mixture", False)])
 def test_multi_env_fused_rollout_equals_single_steps(N, mode, odd):
     import mdr_amd
     E = _envs(N, odd)
