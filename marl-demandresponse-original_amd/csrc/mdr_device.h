@@ -245,53 +245,80 @@ struct Red3 {
 constexpr int DPP_QUAD_SWAP1 = 0xB1, DPP_QUAD_SWAP2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140,
               DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
 
+// With every row enabled each lane is written from a valid lane, so bound_ctrl (zero for invalid sources) changes nothing but
+// spares the compiler the v_mov 0 that otherwise seeds the destination before each DPP move.
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp_f32(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF));
 }
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ double dpp_f64(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
   return __hiloint2double(hi, lo);
 }
 
-// `pen` (wave-uniform): the penalty sum / max are wanted too.  The multi-step kernels pass false in the individual_L2 mode,
-// where only the cluster power is reduced - a third of their per-step vector instructions were these exchanges.
-template <int CTRL, int ROW_MASK = 0xF>
-__device__ __forceinline__ void red3_dpp(Red3& v, bool pen = true) {
-  v.sum_p += dpp_f64<CTRL, ROW_MASK>(v.sum_p);
-  if (pen) {
-    v.sum_pen += dpp_f64<CTRL, ROW_MASK>(v.sum_pen);
-    v.max_pen = fmaxf(v.max_pen, dpp_f32<CTRL, ROW_MASK>(v.max_pen));   // penalties are >= 0: 0 is the identity
+// One exchange step on M independent triples at once (the envs that share a lane group, mdr_multi.hip): their dependent chains
+// interleave inside one basic block.  PEN: the penalty sum / max are wanted too.  The multi-step kernels pass pen = false in the
+// individual_L2 mode, where only the cluster power is reduced - a third of their per-step vector instructions were these exchanges.
+template <int CTRL, int ROW_MASK, bool PEN, int M>
+__device__ __forceinline__ void red3_dpp(Red3* v) {
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    v[m].sum_p += dpp_f64<CTRL, ROW_MASK>(v[m].sum_p);
+    if constexpr (PEN) {
+      v[m].sum_pen += dpp_f64<CTRL, ROW_MASK>(v[m].sum_pen);
+      v[m].max_pen = fmaxf(v[m].max_pen, dpp_f32<CTRL, ROW_MASK>(v[m].max_pen));   // penalties are >= 0: 0 is the identity
+    }
+  }
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+template <int WIDTH, bool SKIP1, bool PEN, int M>
+__device__ __forceinline__ void lanes_reduce_steps(Red3* v) {
+  if constexpr (WIDTH >= 2 && !SKIP1) red3_dpp<DPP_QUAD_SWAP1, 0xF, PEN, M>(v);
+  if constexpr (WIDTH >= 4) red3_dpp<DPP_QUAD_SWAP2, 0xF, PEN, M>(v);
+  if constexpr (WIDTH >= 8) red3_dpp<DPP_ROW_HALF_MIRROR, 0xF, PEN, M>(v);
+  if constexpr (WIDTH >= 16) red3_dpp<DPP_ROW_MIRROR, 0xF, PEN, M>(v);
+  if constexpr (WIDTH == 32) {
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      v[m].sum_p += __shfl_xor(v[m].sum_p, 16, 64);
+      if constexpr (PEN) {
+        v[m].sum_pen += __shfl_xor(v[m].sum_pen, 16, 64);
+        v[m].max_pen = fmaxf(v[m].max_pen, __shfl_xor(v[m].max_pen, 16, 64));
+      }
+    }
+  }
+  if constexpr (WIDTH == 64) {
+    red3_dpp<DPP_ROW_BCAST15, 0xA, PEN, M>(v);   // rows 1 and 3 += row 0 / row 2 totals
+    red3_dpp<DPP_ROW_BCAST31, 0xC, PEN, M>(v);   // rows 2 and 3 += the total of rows 0-1: lane 63 holds everything
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      v[m].sum_p = readlane_f64(v[m].sum_p, 63);
+      if constexpr (PEN) {
+        v[m].sum_pen = readlane_f64(v[m].sum_pen, 63);
+        v[m].max_pen = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[m].max_pen), 63));
+      }
+    }
   }
 }
 
 // Reduction over groups of WIDTH consecutive lanes (WIDTH a power of two <= 64); every lane of a group ends with the
 // group's totals.  Distances 1..8 by DPP; 16 by one bpermute butterfly (WIDTH == 32) or, for the full wavefront, the
-// row broadcasts + a scalar read of lane 63.
-template <int WIDTH>
+// row broadcasts + a scalar read of lane 63.  `pen` is wave-uniform: ONE branch picks the form with or without the penalties.
+// SKIP1: neighbouring lanes 2 j, 2 j + 1 already hold the same pair total - the tree starts at distance 2 (mdr_multi.hip k_rollout_pairs).
+template <int WIDTH, bool SKIP1 = false, int M = 1>
+__device__ __forceinline__ void lanes_reduce_n(Red3* v, bool pen) {
+  if (pen) lanes_reduce_steps<WIDTH, SKIP1, true, M>(v);
+  else lanes_reduce_steps<WIDTH, SKIP1, false, M>(v);
+}
+template <int WIDTH, bool SKIP1 = false>
 __device__ __forceinline__ Red3 lanes_reduce(Red3 v, bool pen = true) {
-  if constexpr (WIDTH >= 2) red3_dpp<DPP_QUAD_SWAP1>(v, pen);
-  if constexpr (WIDTH >= 4) red3_dpp<DPP_QUAD_SWAP2>(v, pen);
-  if constexpr (WIDTH >= 8) red3_dpp<DPP_ROW_HALF_MIRROR>(v, pen);
-  if constexpr (WIDTH >= 16) red3_dpp<DPP_ROW_MIRROR>(v, pen);
-  if constexpr (WIDTH == 32) {
-    v.sum_p += __shfl_xor(v.sum_p, 16, 64);
-    if (pen) {
-      v.sum_pen += __shfl_xor(v.sum_pen, 16, 64);
-      v.max_pen = fmaxf(v.max_pen, __shfl_xor(v.max_pen, 16, 64));
-    }
-  }
-  if constexpr (WIDTH == 64) {
-    red3_dpp<DPP_ROW_BCAST15, 0xA>(v, pen);   // rows 1 and 3 += row 0 / row 2 totals
-    red3_dpp<DPP_ROW_BCAST31, 0xC>(v, pen);   // rows 2 and 3 += the total of rows 0-1: lane 63 holds everything
-    v.sum_p = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v.sum_p), 63), __builtin_amdgcn_readlane(__double2loint(v.sum_p), 63));
-    if (pen) {
-      v.sum_pen = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v.sum_pen), 63), __builtin_amdgcn_readlane(__double2loint(v.sum_pen), 63));
-      v.max_pen = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.max_pen), 63));
-    }
-  }
+  lanes_reduce_n<WIDTH, SKIP1, 1>(&v, pen);
   return v;
 }
 

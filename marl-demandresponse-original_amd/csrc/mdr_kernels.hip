@@ -2339,7 +2339,13 @@ StepPlan plan_step(int N, int64_t E) {
 // The multi-step kernels keep one house per lane (sub-wave groups) or VEC x TILES houses per thread (workgroup per env)
 StepPlan plan_rollout(int N, int64_t E) {
   StepPlan p = plan_step(N, E);
-  if (p.kind == STEP_GROUP || p.kind == STEP_MULTI || p.kind == STEP_PACKED) return p;   // same lane mapping as the single-step kernel
+  if (p.kind == STEP_GROUP || p.kind == STEP_PACKED) return p;   // same lane mapping as the single-step kernel
+  if (p.kind == STEP_MULTI) {           // k_step_multi forms the totals of one env per group, a pair of houses per lane (mdr_multi.hip)
+    p.kind = STEP_GROUP;
+    p.vec = 2;
+    p.tiles = 1;                        // p.threads = pow2_at_least(N / 2) already
+    return p;
+  }
   if (p.kind == STEP_SINGLE) {          // one lane per env; nothing to reduce, so any mapping gives the same bits
     p.kind = STEP_GROUP;
     p.vec = 1;
@@ -2418,11 +2424,11 @@ hipError_t launch_step_end_begin_split(const StepArgs& f, const StepArgs& p, hip
   return hipGetLastError();
 }
 
-bool rollout_fused_supported(const StepPlan& p) { return p.kind == STEP_GROUP || p.kind == STEP_FUSED || p.kind == STEP_MULTI || p.kind == STEP_PACKED; }
+bool rollout_fused_supported(const StepPlan& p) { return p.kind == STEP_GROUP || p.kind == STEP_FUSED || p.kind == STEP_PACKED; }
 
 hipError_t launch_rollout_fused(const StepArgs& a, const RolloutArgs& r, const StepPlan& p, hipStream_t s) {
   if (!rollout_fused_supported(p)) return hipErrorInvalidValue;
-  if (p.kind == STEP_MULTI || p.kind == STEP_PACKED) return launch_rollout_multi(a, r, p, s);
+  if (p.kind == STEP_PACKED) return launch_rollout_multi(a, r, p, s);
   const bool bb = a.action_source == MDR_ACTIONS_BANGBANG;
   if (p.kind == STEP_GROUP) {
     const int64_t lanes = (int64_t)a.E * p.threads;

@@ -7,59 +7,54 @@
 #include "mdr_step_common.h"
 
 namespace mdr {
-
-// ---- (2c) several small envs per lane group, four FLAT houses per lane.  The reference trains with 20 houses and deploys with
-// 50 (cli.py:53, 629).  One env per lane group leaves lanes idle (20 houses = 5 lanes of 8) or - N % 4 != 0 - forces narrow
-// accesses (50 houses: rows start every 200 bytes, so 8-byte accesses at most).  Here ENVS consecutive envs share a group of GROUP
-// lanes, ENVS * N a multiple of 4: lane l holds the four houses 4 l .. 4 l + 3 of the group's ENVS * N, always on a 16-byte
-// boundary of the [E][N] arrays and in at most two envs (N >= 4).  20 houses: 3 envs = 15 lanes of 16; 50 houses: 2 envs = 25
-// lanes of 32 with 16-byte accesses.  (Only ENVS = 2 is instantiated: three and four envs per group measured slower than one, see plan_step.)  Every env's totals come out of the same sub-wave DPP tree, once per env of the group (a
-// lane contributes zeros to the envs it holds nothing of), so k_step_multi and k_rollout_multi end bit for bit alike.
-template <int ENVS>
+// ---- (2c) two small envs per lane group, four FLAT houses per lane.  The reference deploys with 50 houses (cli.py:629).  N % 4 == 2:
+// one env per lane group forces narrow accesses (rows start every 200 bytes, so 8-byte accesses at most).  Here two consecutive
+// envs share a group of GROUP lanes, 2 N a multiple of 4: lane l holds the four houses 4 l .. 4 l + 3 of the group's 2 N, always on
+// a 16-byte boundary of the [E][N] arrays and in at most two envs: 50 houses = 25 lanes of 32 with 16-byte accesses.  (Three and
+// four envs per group - 20 houses at 15 of 16 lanes, odd N - measured slower than one env per group, see plan_step.)
+//
+// The totals are those of the one-env-per-group mapping (k_step_group<GROUP, 2>: GROUP lanes per env, one PAIR of houses per lane)
+// bit for bit, so the multi-step kernel of that mapping (k_rollout_group<GROUP, 2>) is this step's closed loop: a rollout is bound
+// by vector instructions and by the waves a SIMD holds, not by access width, and four houses of two envs per lane cost it twice the
+// registers and a reduction per env (measured at 4.19 M houses of 50: 20.5 us per step on this mapping, 10.8 us on that one).
+// An env begins and ends on a pair (N even): with h = N / 2 pairs per env the lane's pair A (houses 0, 1) and pair B (2, 3) are
+// leaves 2 l and 2 l + 1 of env 0's tree for l <= (h - 1) / 2 = L0, and env 1's leaves 2 n, 2 n + 1 are pair B of lane L0 + n and
+// pair A of lane L0 + n + 1.  So after the first level - fp32 pair sums widened to fp64 and added, own pair + neighbour's as over
+// there - env 0's nodes sit in lanes 0 .. and env 1's in lanes L0 ..; those move up to lanes GROUP / 2 .., and ONE tree over the two
+// half groups (lanes_reduce<GROUP / 2>) finishes both envs at once.
 struct MultiLane {
-  int nv;           // houses of this lane that exist (4, or fewer at the very end of the batch; 0: idle lane)
+  int nv;           // houses of this lane that exist: 4, or 2 / 0 at the end of the batch or of the group (N even: whole pairs)
   int q[4];         // env of each house within the group
   int64_t i;        // flat index of the first house
   int64_t ea, eb;   // the (at most two) envs the lane's houses belong to: first and last house's
   __device__ __forceinline__ void init(const StepArgs& a, int64_t group, int lane) {
     const int k0 = lane * 4;
-    const int64_t e0 = group * ENVS;
+    const int64_t e0 = group * 2;
     i = e0 * a.N + k0;
     const int64_t total = (int64_t)a.E * a.N;
-    nv = (k0 < ENVS * a.N && i < total) ? (int)(total - i < 4 ? total - i : 4) : 0;
+    nv = (k0 < 2 * a.N && i < total) ? (int)(total - i < 4 ? total - i : 4) : 0;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int k = k0 + v;
-      q[v] = (k >= a.N ? 1 : 0) + (ENVS > 2 && k >= 2 * a.N ? 1 : 0) + (ENVS > 3 && k >= 3 * a.N ? 1 : 0);
-    }
+    for (int v = 0; v < 4; ++v) q[v] = k0 + v >= a.N ? 1 : 0;
     const int64_t last = (int64_t)a.E - 1;
     ea = e0 + q[0] < last ? e0 + q[0] : last;
     eb = e0 + q[3] < last ? e0 + q[3] : last;
   }
 };
 
-template <int ENVS>
-__device__ __forceinline__ Red3 pick_env(const Red3* t, int q) {
-  Red3 r = t[0];
-#pragma unroll
-  for (int k = 1; k < ENVS; ++k)
-    if (q == k) r = t[k];
-  return r;
-}
-
-template <int GROUP, int ENVS>
+template <int GROUP>
 __global__ __launch_bounds__(256) void k_step_multi(StepArgs a) {
+  constexpr int HALF = GROUP / 2;
   rebase(a);
   const bool need_pen = a.penalty_mode != MDR_PENALTY_INDIVIDUAL_L2;
   const int64_t group = ((int64_t)blockIdx.x * 256 + threadIdx.x) / GROUP;
   const int lane = threadIdx.x % GROUP;
-  MultiLane<ENVS> m;
+  const int wbase = (threadIdx.x & 63) & ~(GROUP - 1);   // first lane of this group inside the wavefront
+  MultiLane m;
   m.init(a, group, lane);
   HouseOut o[4];
   int lockout[4];
-  Red3 acc[ENVS];
 #pragma unroll
-  for (int k = 0; k < ENVS; ++k) acc[k] = Red3{0.0, 0.0, 0.0f};
+  for (int v = 0; v < 4; ++v) o[v] = HouseOut{};
   if (m.nv > 0) {
     const float od_a = a.od_old[m.ea], od_b = a.od_old[m.eb], so_a = a.solar_new[m.ea], so_b = a.solar_new[m.eb];
     float od[4], so[4];
@@ -71,33 +66,46 @@ __global__ __launch_bounds__(256) void k_step_multi(StepArgs a) {
     if (m.nv == 4) {
       step_vec_rows<4>(a, m.i, od, so, o, lockout);
       store_obs_local<4>(a, m.i, o, lockout);
-    } else {   // the last lane of the whole batch when E * N is not a multiple of 4
-#pragma unroll
-      for (int v = 0; v < 3; ++v)
-        if (v < m.nv) {
-          step_vec<1>(a, m.i + v, od[v], so[v], o + v, lockout + v);
-          store_obs_local<1>(a, m.i + v, o + v, lockout + v);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < ENVS; ++k) {
-      float p = 0.0f, ps = 0.0f;
-#pragma unroll
-      for (int v = 0; v < 4; ++v)
-        if (v < m.nv && m.q[v] == k) {
-          p += o[v].power;
-          ps += o[v].pen;
-          acc[k].max_pen = fmaxf(acc[k].max_pen, o[v].pen);
-        }
-      acc[k].sum_p = (double)p;
-      acc[k].sum_pen = (double)ps;
+    } else {   // the batch's last lane when E is odd: one pair
+      step_vec_rows<2>(a, m.i, od, so, o, lockout);
+      store_obs_local<2>(a, m.i, o, lockout);
     }
   }
-  Red3 tot[ENVS];
-#pragma unroll
-  for (int k = 0; k < ENVS; ++k) tot[k] = lanes_reduce<GROUP>(acc[k], need_pen);
+  // level 1: the lane's pairs as k_step_group<GROUP, 2>'s lanes hold them (fp32 sum of two houses, widened), own + neighbour
+  const bool a_in = m.nv >= 2, b_in = m.nv == 4;
+  const bool a0 = a_in && m.q[0] == 0, a1 = a_in && m.q[0] == 1, b0 = b_in && m.q[2] == 0, b1 = b_in && m.q[2] == 1;
+  const double pa = (double)(o[0].power + o[1].power), pb = (double)(o[2].power + o[3].power);
+  const bool has_next = lane < GROUP - 1;   // the next lane's pair A follows this lane's pair B
+  const double pa_next = __shfl_down(a1 ? pa : 0.0, 1, 64);
+  Red3 n0{(a0 ? pa : 0.0) + (b0 ? pb : 0.0), 0.0, 0.0f};
+  Red3 n1{(b1 ? pb : 0.0) + (has_next ? pa_next : 0.0), 0.0, 0.0f};
+  if (need_pen) {
+    const float sa = o[0].pen + o[1].pen, sb = o[2].pen + o[3].pen, xa = fmaxf(o[0].pen, o[1].pen), xb = fmaxf(o[2].pen, o[3].pen);
+    const double sa_next = __shfl_down(a1 ? (double)sa : 0.0, 1, 64);
+    const float xa_next = __shfl_down(a1 ? xa : 0.0f, 1, 64);
+    n0.sum_pen = (a0 ? (double)sa : 0.0) + (b0 ? (double)sb : 0.0);
+    n0.max_pen = fmaxf(a0 ? xa : 0.0f, b0 ? xb : 0.0f);
+    n1.sum_pen = (b1 ? (double)sb : 0.0) + (has_next ? sa_next : 0.0);
+    n1.max_pen = fmaxf(b1 ? xb : 0.0f, has_next ? xa_next : 0.0f);
+  }
+  // env 1's nodes from lanes L0 .. up to lanes HALF ..; then one tree over each half group
+  const int L0 = (a.N - 2) >> 2;
+  const int src = wbase + (lane >= HALF ? lane - HALF + L0 : lane);
+  Red3 node;
+  node.sum_p = __shfl(n1.sum_p, src, 64);
+  node.sum_pen = need_pen ? __shfl(n1.sum_pen, src, 64) : 0.0;
+  node.max_pen = need_pen ? __shfl(n1.max_pen, src, 64) : 0.0f;
+  if (lane < HALF) node = n0;
+  node = lanes_reduce<HALF>(node, need_pen);
+  Red3 t0, t1;   // both envs' totals in every lane
+  t0.sum_p = __shfl(node.sum_p, wbase, 64);
+  t1.sum_p = __shfl(node.sum_p, wbase + HALF, 64);
+  t0.sum_pen = need_pen ? __shfl(node.sum_pen, wbase, 64) : 0.0;
+  t1.sum_pen = need_pen ? __shfl(node.sum_pen, wbase + HALF, 64) : 0.0;
+  t0.max_pen = need_pen ? __shfl(node.max_pen, wbase, 64) : 0.0f;
+  t1.max_pen = need_pen ? __shfl(node.max_pen, wbase + HALF, 64) : 0.0f;
   if (m.nv > 0) {
-    const Red3 ta = pick_env<ENVS>(tot, m.q[0]), tb = pick_env<ENVS>(tot, m.q[3]);
+    const Red3 ta = m.q[0] ? t1 : t0, tb = m.q[3] ? t1 : t0;
     const float st_a = signal_term(a, ta.sum_p, a.sig_old[m.ea]), st_b = signal_term(a, tb.sum_p, a.sig_old[m.eb]);
     const float os_a = (float)(a.sig_new[m.ea] * a.inv_obs_norm), os_b = (float)(a.sig_new[m.eb] * a.inv_obs_norm);
     const float op_a = (float)(ta.sum_p * a.inv_obs_norm), op_b = (float)(tb.sum_p * a.inv_obs_norm);
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(256) void k_step_multi(StepArgs a) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const bool first = m.q[v] == m.q[0];
-      r[v] = first ? reward_value(a, o[v].pen, ta.sum_pen, ta.max_pen, st_a) : reward_value(a, o[v].pen, tb.sum_pen, tb.max_pen, st_b);
+      r[v] = reward_value(a, o[v].pen, first ? ta.sum_pen : tb.sum_pen, first ? ta.max_pen : tb.max_pen, first ? st_a : st_b);
       c5[v] = first ? os_a : os_b;
       c6[v] = first ? op_a : op_b;
     }
@@ -116,214 +124,17 @@ __global__ __launch_bounds__(256) void k_step_multi(StepArgs a) {
         store_out<4>(a.obs + 6 * a.plane, m.i, c6);
       }
     } else {
-#pragma unroll
-      for (int v = 0; v < 3; ++v)
-        if (v < m.nv) {
-          store_out<1>(a.reward, m.i + v, r + v);
-          if (a.obs != nullptr) {
-            store_out<1>(a.obs + 5 * a.plane, m.i + v, c5 + v);
-            store_out<1>(a.obs + 6 * a.plane, m.i + v, c6 + v);
-          }
-        }
+      store_out<2>(a.reward, m.i, r);
+      if (a.obs != nullptr) {
+        store_out<2>(a.obs + 5 * a.plane, m.i, c5);
+        store_out<2>(a.obs + 6 * a.plane, m.i, c6);
+      }
     }
   }
-  if (lane < ENVS && group * ENVS + lane < a.E) a.P[group * ENVS + lane] = pick_env<ENVS>(tot, lane).sum_p;
+  if (lane < 2 && group * 2 + lane < a.E) a.P[group * 2 + lane] = lane ? t1.sum_p : t0.sum_p;
   cursor_done(a);
 }
 
-// The closed loop on the same mapping: houses in registers for nsteps steps (k_rollout_group's counterpart).
-template <int GROUP, int ENVS, bool BB>   // BB: the bang-bang rule compiled in (mdr_kernels.hip k_rollout_fused)
-__global__ __launch_bounds__(256) void k_rollout_multi(StepArgs a, RolloutArgs ro) {
-  const bool need_pen = a.penalty_mode != MDR_PENALTY_INDIVIDUAL_L2;
-  const bool want_rsum = ro.reward_sum != nullptr;
-  const int64_t group = ((int64_t)blockIdx.x * 256 + threadIdx.x) / GROUP;
-  const int lane = threadIdx.x % GROUP;
-  MultiLane<ENVS> m;
-  m.init(a, group, lane);
-  HouseIn hs[4];
-  HouseOut o[4];
-  float rsum[4];
-  unsigned act[4];
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    hs[v] = HouseIn{};
-    hs[v].lockout = 1;
-    o[v] = HouseOut{};
-    rsum[v] = 0.0f;
-    act[v] = 0u;
-  }
-  if (m.nv == 4) {
-    float Ta[4], Tm[4], k01[4], s0[4], k10[4], s1[4], iu[4], q[4], pm[4], tg[4], db[4];
-    int sso[4], lk[4];
-    unsigned fl[4];
-    load_vec<4>(a.Ta, m.i, Ta);
-    load_vec<4>(a.Tm, m.i, Tm);
-    load_vec<4>(a.sso, m.i, sso);
-    load_bytes<4>(a.flags, m.i, fl);
-    load_vec<4>(a.k01, m.i, k01);
-    load_vec<4>(a.s0, m.i, s0);
-    load_vec<4>(a.k10, m.i, k10);
-    load_vec<4>(a.s1, m.i, s1);
-    load_vec<4>(a.inv_Ua, m.i, iu);
-    load_vec<4>(a.Q_hvac, m.i, q);
-    load_vec<4>(a.P_max, m.i, pm);
-    load_vec<4>(a.target, m.i, tg);
-    load_vec<4>(a.deadband, m.i, db);
-    load_vec<4>(a.lockout, m.i, lk);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) hs[v] = HouseIn{Ta[v], Tm[v], sso[v], fl[v], k01[v], s0[v], k10[v], s1[v], iu[v], q[v], pm[v], tg[v], db[v], lk[v]};
-    if (ro.reward_sum) load_vec<4>(ro.reward_sum, m.i, rsum);
-  } else {
-#pragma unroll
-    for (int v = 0; v < 3; ++v)
-      if (v < m.nv) {
-        const int64_t iv = m.i + v;
-        hs[v] = HouseIn{a.Ta[iv], a.Tm[iv], a.sso[iv], a.flags[iv], a.k01[iv], a.s0[iv], a.k10[iv], a.s1[iv], a.inv_Ua[iv], a.Q_hvac[iv],
-                        a.P_max[iv], a.target[iv], a.deadband[iv], a.lockout[iv]};
-        if (ro.reward_sum) rsum[v] = ro.reward_sum[iv];
-      }
-  }
-  double terr[ENVS], serr = 0.0;   // serr: lane k < ENVS keeps env k's
-#pragma unroll
-  for (int k = 0; k < ENVS; ++k) terr[k] = 0.0;
-  Red3 tot[ENVS];
-#pragma unroll
-  for (int k = 0; k < ENVS; ++k) tot[k] = Red3{0.0, 0.0, 0.0f};
-  Red3 ta{0.0, 0.0, 0.0f}, tb{0.0, 0.0, 0.0f};
-  float st_a = 0.0f, st_b = 0.0f;
-  double sn_a = 0.0, sn_b = 0.0;
-  const int64_t my_env = group * ENVS + lane;   // lane k < ENVS also keeps env k's per-step scalars
-  const bool env_lane = lane < ENVS && my_env < a.E;
-  for (int s = 0; s < ro.nsteps; ++s) {
-    const int64_t base = (int64_t)s * a.E;
-    Red3 acc[ENVS];
-#pragma unroll
-    for (int k = 0; k < ENVS; ++k) acc[k] = Red3{0.0, 0.0, 0.0f};
-    if (m.nv > 0) {
-      const float od_a = a.od_old[base + m.ea], od_b = a.od_old[base + m.eb], so_a = a.solar_new[base + m.ea], so_b = a.solar_new[base + m.eb];
-      float te[ENVS];
-#pragma unroll
-      for (int k = 0; k < ENVS; ++k) te[k] = 0.0f;
-      bool cmds[4];
-      controller_cmds<4>(BB ? MDR_ACTIONS_BANGBANG : a.action_source, hs, cmds);
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        if (v >= m.nv) continue;
-        const bool first = m.q[v] == m.q[0];
-        const bool cmd = cmds[v];
-        act[v] = cmd ? 1u : 0u;
-        o[v] = house_step(hs[v], cmd, first ? od_a : od_b, first ? so_a : so_b, a.dt);
-        hs[v].Ta = o[v].Ta;
-        hs[v].Tm = o[v].Tm;
-        hs[v].sso = o[v].sso;
-        hs[v].flags = o[v].flags;
-      }
-#pragma unroll
-      for (int k = 0; k < ENVS; ++k) {
-        float p = 0.0f, ps = 0.0f;
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-          if (v < m.nv && m.q[v] == k) {
-            p += o[v].power;
-            ps += o[v].pen;
-            acc[k].max_pen = fmaxf(acc[k].max_pen, o[v].pen);
-            const float d = o[v].Ta - hs[v].target;
-            te[k] = fmaf(d, d, te[k]);
-          }
-        acc[k].sum_p = (double)p;
-        acc[k].sum_pen = (double)ps;
-        terr[k] += (double)te[k];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < ENVS; ++k) tot[k] = lanes_reduce<GROUP>(acc[k], need_pen);
-    if (m.nv > 0) {
-      ta = pick_env<ENVS>(tot, m.q[0]);
-      tb = pick_env<ENVS>(tot, m.q[3]);
-      st_a = signal_term(a, ta.sum_p, a.sig_old[base + m.ea]);
-      st_b = signal_term(a, tb.sum_p, a.sig_old[base + m.eb]);
-      if (want_rsum) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          if (v >= m.nv) continue;
-          const bool first = m.q[v] == m.q[0];
-          rsum[v] = __fadd_rn(rsum[v], first ? reward_value(a, o[v].pen, ta.sum_pen, ta.max_pen, st_a) : reward_value(a, o[v].pen, tb.sum_pen, tb.max_pen, st_b));
-        }
-      }
-    }
-    if (env_lane) {
-      const double P = pick_env<ENVS>(tot, lane).sum_p;
-      if (ro.power_trace) ro.power_trace[base + my_env] = P;
-      const double d = a.sig_new[base + my_env] - P;
-      if (!(ro.defer_last_signal_error && s == ro.nsteps - 1)) serr += d * d;
-    }
-  }
-  if (ro.nsteps <= 0) return;
-  Red3 tr[ENVS];
-#pragma unroll
-  for (int k = 0; k < ENVS; ++k) {
-    tr[k] = Red3{terr[k], 0.0, 0.0f};
-    tr[k] = lanes_reduce<GROUP>(tr[k], false);
-  }
-  if (env_lane) {
-    a.P[my_env] = pick_env<ENVS>(tot, lane).sum_p;
-    if (ro.sq_temp_error_sum) ro.sq_temp_error_sum[my_env] += pick_env<ENVS>(tr, lane).sum_p;
-    if (ro.sq_signal_error_sum) ro.sq_signal_error_sum[my_env] += serr;
-  }
-  if (m.nv == 0) return;
-  const int64_t last = (int64_t)(ro.nsteps - 1) * a.E;
-  sn_a = a.sig_new[last + m.ea];
-  sn_b = a.sig_new[last + m.eb];
-  const float os_a = (float)(sn_a * a.inv_obs_norm), os_b = (float)(sn_b * a.inv_obs_norm);
-  const float op_a = (float)(ta.sum_p * a.inv_obs_norm), op_b = (float)(tb.sum_p * a.inv_obs_norm);
-  float nTa[4], nTm[4], r[4], c5[4], c6[4];
-  int nsso[4], lk[4];
-  unsigned nfl[4];
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const bool first = m.q[v] == m.q[0];
-    nTa[v] = hs[v].Ta;
-    nTm[v] = hs[v].Tm;
-    nsso[v] = hs[v].sso;
-    nfl[v] = hs[v].flags;
-    lk[v] = hs[v].lockout;
-    r[v] = first ? reward_value(a, o[v].pen, ta.sum_pen, ta.max_pen, st_a) : reward_value(a, o[v].pen, tb.sum_pen, tb.max_pen, st_b);
-    c5[v] = first ? os_a : os_b;
-    c6[v] = first ? op_a : op_b;
-  }
-  if (m.nv == 4) {
-    store_vec<4>(a.Ta, m.i, nTa);
-    store_vec<4>(a.Tm, m.i, nTm);
-    store_vec<4>(a.sso, m.i, nsso);
-    store_bytes<4>(a.flags, m.i, nfl);
-    if (a.actions != nullptr) store_bytes<4>(a.actions, m.i, act);
-    store_obs_local<4>(a, m.i, o, lk);
-    store_out<4>(a.reward, m.i, r);
-    if (a.obs != nullptr) {
-      store_out<4>(a.obs + 5 * a.plane, m.i, c5);
-      store_out<4>(a.obs + 6 * a.plane, m.i, c6);
-    }
-    if (ro.reward_sum) store_vec<4>(ro.reward_sum, m.i, rsum);
-  } else {
-#pragma unroll
-    for (int v = 0; v < 3; ++v)
-      if (v < m.nv) {
-        const int64_t iv = m.i + v;
-        a.Ta[iv] = nTa[v];
-        a.Tm[iv] = nTm[v];
-        a.sso[iv] = nsso[v];
-        a.flags[iv] = (uint8_t)nfl[v];
-        if (a.actions != nullptr) a.actions[iv] = (uint8_t)act[v];
-        store_obs_local<1>(a, iv, o + v, lk + v);
-        store_out<1>(a.reward, iv, r + v);
-        if (a.obs != nullptr) {
-          store_out<1>(a.obs + 5 * a.plane, iv, c5 + v);
-          store_out<1>(a.obs + 6 * a.plane, iv, c6 + v);
-        }
-        if (ro.reward_sum) ro.reward_sum[iv] = rsum[v];
-      }
-  }
-}
 
 // ---- (2d) whole envs packed into a wavefront without rounding their lane count up to a power of two.  N % 4 == 0, L = N / 4
 // lanes per env, floor(64 / L) envs per wavefront: 20 houses (the reference's training size, cli.py:53) fill 60 of 64 lanes
@@ -529,50 +340,31 @@ int64_t multi_blocks(int64_t E, const StepPlan& p) {
   return (groups * p.threads + 255) / 256;
 }
 
-#define MDR_MULTI_DISPATCH(KERNEL, ...)                                              \
-  switch (p.tiles * 100 + p.threads) {                                               \
-    case 204: hipLaunchKernelGGL((KERNEL<4, 2>), g, b, 0, s, __VA_ARGS__); break;    \
-    case 208: hipLaunchKernelGGL((KERNEL<8, 2>), g, b, 0, s, __VA_ARGS__); break;    \
-    case 216: hipLaunchKernelGGL((KERNEL<16, 2>), g, b, 0, s, __VA_ARGS__); break;   \
-    case 232: hipLaunchKernelGGL((KERNEL<32, 2>), g, b, 0, s, __VA_ARGS__); break;   \
-    case 264: hipLaunchKernelGGL((KERNEL<64, 2>), g, b, 0, s, __VA_ARGS__); break;   \
-    default: return hipErrorInvalidValue;                                            \
-  }
-
 hipError_t launch_step_multi(const StepArgs& a, const StepPlan& p, hipStream_t s) {
   const dim3 g((unsigned)multi_blocks(a.E, p)), b(256);
   if (p.kind == STEP_PACKED) {
     hipLaunchKernelGGL(k_step_packed, g, b, 0, s, a);
     return hipGetLastError();
   }
-  MDR_MULTI_DISPATCH(k_step_multi, a)
+  if (p.tiles != 2 || a.N % 4 != 2) return hipErrorInvalidValue;   // k_step_multi: two envs per group, envs made of whole pairs
+  switch (p.threads) {
+    case 4: hipLaunchKernelGGL(k_step_multi<4>, g, b, 0, s, a); break;
+    case 8: hipLaunchKernelGGL(k_step_multi<8>, g, b, 0, s, a); break;
+    case 16: hipLaunchKernelGGL(k_step_multi<16>, g, b, 0, s, a); break;
+    case 32: hipLaunchKernelGGL(k_step_multi<32>, g, b, 0, s, a); break;
+    case 64: hipLaunchKernelGGL(k_step_multi<64>, g, b, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 
-#undef MDR_MULTI_DISPATCH
-
-#define MDR_MULTI_ROLLOUT(BBV)                                                                             \
-  switch (p.tiles * 100 + p.threads) {                                                                     \
-    case 204: hipLaunchKernelGGL((k_rollout_multi<4, 2, BBV>), g, b, 0, s, a, r); break;                   \
-    case 208: hipLaunchKernelGGL((k_rollout_multi<8, 2, BBV>), g, b, 0, s, a, r); break;                   \
-    case 216: hipLaunchKernelGGL((k_rollout_multi<16, 2, BBV>), g, b, 0, s, a, r); break;                  \
-    case 232: hipLaunchKernelGGL((k_rollout_multi<32, 2, BBV>), g, b, 0, s, a, r); break;                  \
-    case 264: hipLaunchKernelGGL((k_rollout_multi<64, 2, BBV>), g, b, 0, s, a, r); break;                  \
-    default: return hipErrorInvalidValue;                                                                  \
-  }
-
+// STEP_PACKED only: a STEP_MULTI plan's multi-step kernel is k_rollout_group (plan_rollout)
 hipError_t launch_rollout_multi(const StepArgs& a, const RolloutArgs& r, const StepPlan& p, hipStream_t s) {
+  if (p.kind != STEP_PACKED) return hipErrorInvalidValue;
   const dim3 g((unsigned)multi_blocks(a.E, p)), b(256);
-  const bool bb = a.action_source == MDR_ACTIONS_BANGBANG;
-  if (p.kind == STEP_PACKED) {
-    if (bb) hipLaunchKernelGGL(k_rollout_packed<true>, g, b, 0, s, a, r);
-    else hipLaunchKernelGGL(k_rollout_packed<false>, g, b, 0, s, a, r);
-    return hipGetLastError();
-  }
-  if (bb) { MDR_MULTI_ROLLOUT(true) }
-  else { MDR_MULTI_ROLLOUT(false) }
+  if (a.action_source == MDR_ACTIONS_BANGBANG) hipLaunchKernelGGL(k_rollout_packed<true>, g, b, 0, s, a, r);
+  else hipLaunchKernelGGL(k_rollout_packed<false>, g, b, 0, s, a, r);
   return hipGetLastError();
 }
-#undef MDR_MULTI_ROLLOUT
 
 }  // namespace mdr

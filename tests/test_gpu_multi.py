@@ -1,7 +1,8 @@
 """Device-filling batches of small envs with N % 4 == 2 - the reference deploys with 50 houses (cli.py:629) - take the
-kernels that put TWO envs into one lane group, four flat houses per lane on 16-byte accesses (csrc/mdr_multi.hip).  Against
-the oracle, against the one-env-per-group kernels a small batch of the same global envs takes, and fused rollout == single
-steps bit for bit (env/MA_DemandResponse.py:1005-1055, 234-373)."""
+step kernel that puts TWO envs into one lane group, four flat houses per lane on 16-byte accesses (csrc/mdr_multi.hip), with
+the totals of the one-env-per-group mapping whose multi-step kernel is its closed loop.  Against the oracle, against the
+one-env-per-group kernels a small batch of the same global envs takes, and fused rollout == single steps bit for bit
+(env/MA_DemandResponse.py:1005-1055, 234-373)."""
 import numpy as np
 import pytest
 import torch
@@ -67,7 +68,7 @@ def test_multi_env_groups_match_oracle_and_single_env_groups(N, mode, odd):
         assert torch.equal(env.t["obs"][:5, sl], small.t["obs"][:5]) and torch.equal(env.t["obs"][5:, sl], small.t["obs"][5:])
         if mode == "individual_L2":
             assert torch.equal(env.t["reward"][sl], small.t["reward"])
-        else:                                 # the penalty sum meets the houses in fours here, in ones / twos there
+        else:                                 # the penalty sum meets the houses in pairs / fours here, one by one there
             torch.testing.assert_close(env.t["reward"][sl], small.t["reward"], rtol=1e-6, atol=1e-6)
         np.testing.assert_array_equal(env.t["sso"][sl].cpu().numpy(), ora.sso)
         assert np.array_equal(env.t["P"][sl].cpu().numpy(), ora.P)
