@@ -115,6 +115,18 @@ int mdr_actor_sample(const mdr_actor_t *actor, const float *obs, int64_t obs_pla
 int mdr_env_actor_sample(mdr_env_t *env, const mdr_obs_spec_t *spec, const mdr_actor_t *actor, uint64_t seed, uint64_t step,
                          const int32_t *step_dev, uint8_t *action, float *a_prob, float *probs, float *rows_out, void *stream);
 
+/* The same for senders that are NOT the circular neighbours: a static link table (spec->links: agents_comm_mode closed_groups /
+ * random_fixed / neighbours_2D, ClusterHouses.build_agent_comm_links env 806-902) or random_sample (spec->random_links, env 976-983:
+ * nb_comm distinct senders drawn per house and step).  The call first writes every house's SingleHouse.message record into
+ * `msg_scratch` (device float [nb_envs][nb_houses][4], 16-byte aligned; mdr_env_obs_messages' kernel) and - random_sample - this step's
+ * senders into `senders_scratch` (device int32 [nb_envs][nb_houses][nb_comm], the draws of mdr_env_comm_draws; may be NULL otherwise);
+ * the actor kernel then stages one lane per agent and GATHERS its nb_comm records through the table.  Same draws, outputs and
+ * `rows_out` as mdr_env_actor_sample (rows bit for bit those of mdr_env_obs_vector); the optional MESSAGE columns stay unsupported
+ * (-4: with 10 senders they do not fit the 64 features of a staged row).  Circular neighbours are accepted too (NULL links). */
+int mdr_env_actor_sample_links(mdr_env_t *env, const mdr_obs_spec_t *spec, const mdr_actor_t *actor, float *msg_scratch,
+                               int32_t *senders_scratch, uint64_t seed, uint64_t step, const int32_t *step_dev, uint8_t *action,
+                               float *a_prob, float *probs, float *rows_out, void *stream);
+
 /* The Monte-Carlo return scan of PPO.update (agents/ppo.py:123-134) for every agent at once: backwards over t,
  * R <- reward[t] + gamma * (done[t] ? bootstrap[t] : R).  `reward`, `out` float [nb_steps][nb_agents]; `done` uint8 of that
  * shape or NULL (no restarts); `bootstrap` float of that shape (the critic's value of the next state where done) or NULL

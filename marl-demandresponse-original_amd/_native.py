@@ -143,7 +143,7 @@ EXPORTS = (
     "mdr_env_set_controller", "mdr_env_greedy_myopic_actions", "mdr_mailbox_bytes", "mdr_persist_records", "mdr_env_rollout_persistent",
     "mdr_mailbox_alloc", "mdr_mailbox_free", "mdr_mailbox_export", "mdr_mailbox_open", "mdr_mailbox_close", "mdr_mailbox_peek",
     # include/mdr_policy.h
-    "mdr_actor_steps1", "mdr_actor_steps1_order", "mdr_actor_steps2", "mdr_actor_frag1_floats", "mdr_actor_frag2_floats", "mdr_actor_sample", "mdr_env_actor_sample",
+    "mdr_actor_steps1", "mdr_actor_steps1_order", "mdr_actor_steps2", "mdr_actor_frag1_floats", "mdr_actor_frag2_floats", "mdr_actor_sample", "mdr_env_actor_sample", "mdr_env_actor_sample_links",
     "mdr_discounted_returns",
 )
 
@@ -218,6 +218,7 @@ def load():
         "mdr_actor_frag2_floats": (i64, [i32, i32]),
         "mdr_actor_sample": (C.c_int, [vp, vp, i64, i64, u64, u64, vp, vp, vp, vp, vp]),
         "mdr_env_actor_sample": (C.c_int, [vp, C.POINTER(MdrObsSpec), vp, u64, u64, vp, vp, vp, vp, vp, vp]),
+        "mdr_env_actor_sample_links": (C.c_int, [vp, C.POINTER(MdrObsSpec), vp, vp, vp, u64, u64, vp, vp, vp, vp, vp, vp]),
         "mdr_discounted_returns": (C.c_int, [vp, vp, vp, C.c_float, i32, i64, vp, vp]),
         "mdr_env_pack": (C.c_int, [vp, i32, vp, vp]),
         "mdr_env_graph_room": (i64, [vp]),

@@ -1240,8 +1240,10 @@ int mdr_env_obs_vector_ext(mdr_env_t* env, const mdr_obs_spec_t* spec, const flo
   return MDR_OK;
 }
 
-int mdr_env_actor_sample(mdr_env_t* env, const mdr_obs_spec_t* spec, const mdr_actor_t* actor, uint64_t seed, uint64_t step,
-                         const int32_t* step_dev, uint8_t* action, float* a_prob, float* probs, float* rows_out, void* stream) {
+// msg_scratch / senders_scratch: the caller's scratch of mdr_env_actor_sample_links, NULL for mdr_env_actor_sample
+static int actor_sample_impl(mdr_env_t* env, const mdr_obs_spec_t* spec, const mdr_actor_t* actor, float* msg_scratch, int32_t* senders_scratch,
+                             uint64_t seed, uint64_t step, const int32_t* step_dev, uint8_t* action, float* a_prob, float* probs, float* rows_out,
+                             void* stream) {
   if (!env || !spec || !actor || !action) return MDR_ERR_INVALID;
   if (env->cfg.nb_houses_total != env->cfg.nb_houses) return fail(env, MDR_ERR_UNSUPPORTED, "observe -> act needs unsharded houses");
   mdr::ObsArgs a;
@@ -1250,8 +1252,12 @@ int mdr_env_actor_sample(mdr_env_t* env, const mdr_obs_spec_t* spec, const mdr_a
   if (rc != MDR_OK) return rc;
   // circular neighbours with 4-field messages (utils.py:843-878 without the optional message columns); the optional STATE columns
   // (774-830), any neighbour count and link defects (env 988-1002) take the extended kernels
-  if (spec->message_thermal || spec->message_hvac || spec->links != nullptr || spec->random_links)
-    return fail(env, MDR_ERR_UNSUPPORTED, "observe -> act covers circular neighbours with 4-field messages: link tables, random_sample and the optional message columns go through mdr_env_obs_vector + mdr_actor_sample");
+  if (spec->message_thermal || spec->message_hvac)
+    return fail(env, MDR_ERR_UNSUPPORTED, "observe -> act covers 4-field messages: the optional message columns go through mdr_env_obs_vector + mdr_actor_sample");
+  const bool table = spec->nb_comm > 0 && (spec->links != nullptr || spec->random_links);
+  if (table && !msg_scratch)
+    return fail(env, MDR_ERR_UNSUPPORTED, "observe -> act with a link table or random_sample senders gathers message records: call mdr_env_actor_sample_links with its scratch");
+  if (table && spec->random_links && !senders_scratch) return fail(env, MDR_ERR_INVALID, "random_sample: senders_scratch is NULL");
   mdr::ObserveArgs o{};
   o.Ta = a.Ta; o.Tm = a.Tm; o.target = a.target; o.deadband = a.deadband; o.capacity = a.capacity; o.P_max = a.P_max;
   o.sso = a.sso; o.lockout = a.lockout; o.flags = a.flags; o.P = a.P; o.sig_now = a.sig_now;
@@ -1260,7 +1266,7 @@ int mdr_env_actor_sample(mdr_env_t* env, const mdr_obs_spec_t* spec, const mdr_a
   o.obs_tshift = a.obs_tshift; o.inv_norm_reg = a.inv_norm_reg; o.inv_cap = a.inv_cap; o.inv_obs_norm = a.inv_obs_norm;
   static const bool force_ext = [] { const char* t = getenv("MDR_OBSERVE_EXT"); return t && t[0] == '1'; }();   // experiment knob: the extended kernels on the default shape
   const bool ext = spec->state_hour || spec->state_day || spec->state_solar_gain || spec->state_thermal || spec->state_hvac ||
-                   spec->nb_comm != 10 || spec->comm_defect_prob > 0.0 || force_ext;
+                   spec->nb_comm != 10 || spec->comm_defect_prob > 0.0 || force_ext || table;
   if (ext) {
     if (env->split_pending) return fail(env, MDR_ERR_INVALID, "step_begin without step_end");
     o.ext = 1;
@@ -1280,10 +1286,38 @@ int mdr_env_actor_sample(mdr_env_t* env, const mdr_obs_spec_t* spec, const mdr_a
     o.env_offset = a.env_offset; o.house_offset = a.house_offset;
     o.k0 = a.k0; o.k1 = a.k1; o.episode = a.episode;
   }
+  if (table) {   // every house's message record of this step, and - random_sample - this step's senders, then the gather inside the actor kernel
+    mdr::ObsArgs w = a;
+    w.msg_ext_out = msg_scratch;
+    w.ext_entries = env->cfg.nb_houses;
+    hipError_t e = mdr::launch_obs_messages(w, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(env, e, "obs_messages");
+    o.msg_rec = msg_scratch;
+    o.links = spec->links;
+    o.links_env_stride = 0;
+    if (spec->random_links) {
+      e = mdr::launch_comm_draws(a, senders_scratch, nullptr, (hipStream_t)stream);
+      if (e != hipSuccess) return hip_fail(env, e, "comm_draws");
+      o.links = senders_scratch;
+      o.links_env_stride = (int64_t)env->cfg.nb_houses * spec->nb_comm;
+    }
+  }
   rc = mdr::launch_actor_observe(actor, o, seed, step, step_dev, action, a_prob, probs, rows_out, (hipStream_t)stream);
   if (rc == MDR_ERR_UNSUPPORTED) return fail(env, rc, "observe -> act: shape or actor layout without a kernel (nb_houses > nb_comm <= 13, at most 64 features, FRAG16 / BF16X3 packed in MDR_FEATURES_OBSERVE order for this nb_comm)");
   if (rc != MDR_OK) return fail(env, rc, "actor_observe launch failed");
   return MDR_OK;
+}
+
+int mdr_env_actor_sample(mdr_env_t* env, const mdr_obs_spec_t* spec, const mdr_actor_t* actor, uint64_t seed, uint64_t step,
+                         const int32_t* step_dev, uint8_t* action, float* a_prob, float* probs, float* rows_out, void* stream) {
+  return actor_sample_impl(env, spec, actor, nullptr, nullptr, seed, step, step_dev, action, a_prob, probs, rows_out, stream);
+}
+
+int mdr_env_actor_sample_links(mdr_env_t* env, const mdr_obs_spec_t* spec, const mdr_actor_t* actor, float* msg_scratch, int32_t* senders_scratch,
+                               uint64_t seed, uint64_t step, const int32_t* step_dev, uint8_t* action, float* a_prob, float* probs,
+                               float* rows_out, void* stream) {
+  if (!msg_scratch || ((uintptr_t)msg_scratch & 15u) != 0) return env ? fail(env, MDR_ERR_INVALID, "msg_scratch must be a 16-byte aligned device buffer of nb_envs * nb_houses * 4 floats") : MDR_ERR_INVALID;
+  return actor_sample_impl(env, spec, actor, msg_scratch, senders_scratch, seed, step, step_dev, action, a_prob, probs, rows_out, stream);
 }
 
 int mdr_env_comm_draws(mdr_env_t* env, const mdr_obs_spec_t* spec, int32_t* senders, uint8_t* keep, void* stream) {

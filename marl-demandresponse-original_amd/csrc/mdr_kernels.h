@@ -185,6 +185,13 @@ struct ObserveArgs {
   float defect_prob;
   int64_t env_offset, house_offset;
   uint32_t k0, k1, episode;
+  // Senders by a table instead of the circular neighbours (ext only): links[e * links_env_stride + h * c + m] = house id of slot m's
+  // sender within the env - the static table of agents_comm_mode closed_groups / random_fixed / neighbours_2D (stride 0: one table
+  // for every env) or this step's random_sample draws (k_comm_draws: stride N c).  msg_rec: every house's SingleHouse.message
+  // record [E][N][4] (k_obs_messages of this step), which the staging gathers.
+  const int32_t* links;
+  int64_t links_env_stride;
+  const float* msg_rec;
 };
 
 // Persistent sharded rollout (mdr_persist.hip): the mailboxes of every rank, laid out in 8-byte granules as

@@ -1591,7 +1591,7 @@ __global__ __launch_bounds__(256) void k_comm_draws(ObsArgs a, int32_t* __restri
       ok = (float)u01(x) > a.defect_prob ? 1u : 0u;
     }
     senders[i * a.c + m] = sid;
-    keep[i * a.c + m] = (uint8_t)ok;
+    if (keep != nullptr) keep[i * a.c + m] = (uint8_t)ok;
   }
 }
 

@@ -774,10 +774,12 @@ struct SegSlot {
   int e;                // ... and that env (the extended form fetches its per-env columns when the rows are staged)
 };
 
-template <int TILE, bool EXT = false>
+template <int TILE, bool EXT = false, bool TABLE = false>
 __device__ __forceinline__ HouseRegs observe_load_gen(const mdr::ObserveArgs& o, const double* sig_row, int e0, int h0, int64_t a0, int64_t A,
                                                       int lane, SegSlot& slot) {
-  const int before = EXT ? o.before : OBS_HALO, c = EXT ? o.c : 2 * OBS_HALO;   // senders before the house / in all (env 816-828)
+  // senders before the house / in all (env 816-828).  TABLE (link tables, random_sample): the window is the tile's houses alone -
+  // one lane per agent - and the senders' records are gathered when the rows are staged
+  const int before = TABLE ? 0 : (EXT ? o.before : OBS_HALO), c = TABLE ? 0 : (EXT ? o.c : 2 * OBS_HALO);
   HouseRegs r{};
   slot = SegSlot{0, 0, 0, 0, false, 0};
   // the segment walk is wave-uniform: keep it on the scalar unit (the tile index comes out of threadIdx, which the compiler
@@ -833,7 +835,7 @@ __device__ __forceinline__ HouseRegs observe_load_gen(const mdr::ObserveArgs& o,
   return r;
 }
 
-template <bool EXT = false, int ROWC = 0>
+template <bool EXT = false, int ROWC = 0, bool TABLE = false>
 __device__ __forceinline__ void observe_stage_gen(const mdr::ObserveArgs& o, const HouseRegs& r, const SegSlot& slot, float* rows) {
   if (!slot.live) return;
   const int ROW = ROWC ? ROWC : (EXT ? o.row : OBS_ROW);   // (the fp32 extended forms know their stride at compile time)
@@ -841,7 +843,7 @@ __device__ __forceinline__ void observe_stage_gen(const mdr::ObserveArgs& o, con
   const float4 rec = make_float4((r.Ta - r.tg) * 0.2f, (float)r.sso, ((r.fl & 1u) ? r.pm : 0.0f) * o.inv_norm_reg, r.pm * o.inv_norm_reg);
 #pragma unroll
   for (int m = 0; m < (EXT ? OBS_MAX_C : OBS_C); ++m) {
-    if (EXT && m >= c) break;
+    if (TABLE || (EXT && m >= c)) break;
     const int off = m < before ? m - before : m - before + 1;   // slot m listens to house h + off (env 816-828)
     int h = slot.j - off;                                      // ... so this house is slot m of house j - off
     h += h < 0 ? o.N : 0;
@@ -851,6 +853,22 @@ __device__ __forceinline__ void observe_stage_gen(const mdr::ObserveArgs& o, con
   }
   const int k = slot.j - slot.hs;
   if (EXT) {
+    if (TABLE) {   // this lane's house is a receiver (the window holds nothing else): its c senders by the table, four at a time
+      float* row = rows + (slot.rb + k) * ROW;
+      const int32_t* ids = o.links + (int64_t)slot.e * o.links_env_stride + (int64_t)slot.j * c;
+      const float4* recs = reinterpret_cast<const float4*>(o.msg_rec) + (int64_t)slot.e * o.N;
+#pragma unroll 1
+      for (int m0 = 0; m0 < c; m0 += 4) {
+        const int last = c - 1;
+        const int s0 = ids[m0], s1 = ids[min(m0 + 1, last)], s2 = ids[min(m0 + 2, last)], s3 = ids[min(m0 + 3, last)];
+        const float4 r0 = recs[s0], r1 = recs[s1], r2 = recs[s2], r3 = recs[s3];
+        float* dst = row + 4 * m0;
+        *reinterpret_cast<float4*>(dst) = r0;
+        if (m0 + 1 < c) *reinterpret_cast<float4*>(dst + 4) = r1;
+        if (m0 + 2 < c) *reinterpret_cast<float4*>(dst + 8) = r2;
+        if (m0 + 3 < c) *reinterpret_cast<float4*>(dst + 12) = r3;
+      }
+    }
     if (k >= 0 && k < slot.len) {
       HouseRegs own = r;
       const int e = slot.e;      // per lane here: a tile may span envs
@@ -988,7 +1006,7 @@ struct TileCursor {
 };
 
 // ---- bf16x3 form: 32 agents per wavefront (two 16-agent column blocks), k-step s of layer 1 = row floats [32 s + 8 g, + 8)
-template <int MB, bool STORE, bool GEN, bool EXT = false>
+template <int MB, bool STORE, bool GEN, bool EXT = false, bool TABLE = false>   // TABLE (GEN && EXT): senders gathered through a link table
 __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a, mdr::ObserveArgs o) {
   const int NW = EXT ? (int)(blockDim.x >> 6) : WAVESB;   // waves per workgroup: the extended form takes as many as its windows leave room for (6 .. 8; two per SIMD either way)
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1079,8 +1097,8 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
   SegSlot slot{};
   if (wave < a.ntiles) {
     if (GEN) {
-      const HouseRegs first = observe_load_gen<TILE, EXT>(o, sig_row, tc.e, tc.h0, (int64_t)wave * TILE, a.A, lane, slot);
-      observe_stage_gen<EXT>(o, first, slot, rows);
+      const HouseRegs first = observe_load_gen<TILE, EXT, TABLE>(o, sig_row, tc.e, tc.h0, (int64_t)wave * TILE, a.A, lane, slot);
+      observe_stage_gen<EXT, 0, TABLE>(o, first, slot, rows);
     } else {
       const HouseRegs first = observe_load<TILE, EXT>(o, sig_row, tc.e, tc.h0, lane);
       observe_stage<TILE, EXT>(o, first, rows, lane, tc.e);
@@ -1104,7 +1122,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
     const bool more = t + nwaves < ntiles;
     tc.next();
     HouseRegs nxt{};
-    if (more) nxt = GEN ? observe_load_gen<TILE, EXT>(o, sig_row, tc.e, tc.h0, (int64_t)(t + nwaves) * TILE, a.A, lane, slot) : observe_load<TILE, EXT>(o, sig_row, tc.e, tc.h0, lane);
+    if (more) nxt = GEN ? observe_load_gen<TILE, EXT, TABLE>(o, sig_row, tc.e, tc.h0, (int64_t)(t + nwaves) * TILE, a.A, lane, slot) : observe_load<TILE, EXT>(o, sig_row, tc.e, tc.h0, lane);
     f32x4 acc[NCB][MB];
 #pragma unroll
     for (int c = 0; c < NCB; ++c)
@@ -1142,7 +1160,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
 #pragma unroll
     for (int s = 0; s < S2B; ++s) {
       if (s == 1 && more) {
-        if (GEN) observe_stage_gen<EXT>(o, nxt, slot, rows);
+        if (GEN) observe_stage_gen<EXT, 0, TABLE>(o, nxt, slot, rows);
         else observe_stage<TILE, EXT>(o, nxt, rows, lane, tc.e);
       }
       bf16x8 Bh[NCB], Bl[NCB];
@@ -1207,7 +1225,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a,
 // EXTK = 0: the default observation; 13 | 15 | 16: the extended form specialised for that many k-steps of layer 1 (features up to
 // 52 | 60 | 64) - the k-steps, the row stride and with it all window addressing are compile-time values as in the default form.
 constexpr int observe16_row(int extk) { return extk == 0 ? OBS_ROW : (((4 * extk + 2 + 3) & ~3) | 4); }   // 4 S1 + 2 floats as 4 x odd: 60 | 68 | 68
-template <int MB, bool STORE, bool GEN, bool TAIL, int EXTK = 0>
+template <int MB, bool STORE, bool GEN, bool TAIL, int EXTK = 0, bool TABLE = false>   // TABLE (GEN && EXTK): senders gathered through a link table
 __global__ __launch_bounds__(64 * (EXTK ? WAVES16_EXT : WAVES16)) void k_actor_observe16(ActorArgs a, mdr::ObserveArgs o) {
   constexpr bool EXT = EXTK != 0;
   const int NW = EXT ? (int)(blockDim.x >> 6) : WAVES16;   // waves per workgroup (the extended form: as many of its 16 as the windows leave room for)
@@ -1275,8 +1293,8 @@ __global__ __launch_bounds__(64 * (EXTK ? WAVES16_EXT : WAVES16)) void k_actor_o
   SegSlot slot{};
   if (wave < a.ntiles) {
     if (GEN) {
-      const HouseRegs first = observe_load_gen<TILE, EXT>(o, sig_row, tc.e, tc.h0, wave * TILE, a.A, lane, slot);
-      observe_stage_gen<EXT, EXT ? ROW : 0>(o, first, slot, rows);
+      const HouseRegs first = observe_load_gen<TILE, EXT, TABLE>(o, sig_row, tc.e, tc.h0, wave * TILE, a.A, lane, slot);
+      observe_stage_gen<EXT, EXT ? ROW : 0, TABLE>(o, first, slot, rows);
     } else {
       const HouseRegs first = observe_load<TILE, EXT>(o, sig_row, tc.e, tc.h0, lane);
       observe_stage<TILE, EXT, EXT ? ROW : 0>(o, first, rows, lane, tc.e);
@@ -1296,7 +1314,7 @@ __global__ __launch_bounds__(64 * (EXTK ? WAVES16_EXT : WAVES16)) void k_actor_o
     const bool more = t + nwaves < a.ntiles;
     tc.next();
     HouseRegs nxt{};
-    if (more) nxt = GEN ? observe_load_gen<TILE, EXT>(o, sig_row, tc.e, tc.h0, (t + nwaves) * TILE, a.A, lane, slot) : observe_load<TILE, EXT>(o, sig_row, tc.e, tc.h0, lane);
+    if (more) nxt = GEN ? observe_load_gen<TILE, EXT, TABLE>(o, sig_row, tc.e, tc.h0, (t + nwaves) * TILE, a.A, lane, slot) : observe_load<TILE, EXT>(o, sig_row, tc.e, tc.h0, lane);
     f32x4 acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[mb] = bias1[mb * 4];
@@ -1313,7 +1331,7 @@ __global__ __launch_bounds__(64 * (EXTK ? WAVES16_EXT : WAVES16)) void k_actor_o
     // ---- layer 2; the next tile's rows are staged after a few k-steps, read back at the end (STAGE_Q < 0: before the layer starts,
     // while the accumulators of layer 2 do not exist yet)
     if (STAGE_Q < 0 && more) {
-      if (GEN) observe_stage_gen<EXT, EXT ? ROW : 0>(o, nxt, slot, rows);
+      if (GEN) observe_stage_gen<EXT, EXT ? ROW : 0, TABLE>(o, nxt, slot, rows);
       else observe_stage<TILE, EXT, EXT ? ROW : 0>(o, nxt, rows, lane, tc.e);
     }
     f32x4 out[MB];
@@ -1322,7 +1340,7 @@ __global__ __launch_bounds__(64 * (EXTK ? WAVES16_EXT : WAVES16)) void k_actor_o
 #pragma unroll
     for (int q = 0; q < 4 * MB; ++q) {
       if (q == STAGE_Q && more) {
-        if (GEN) observe_stage_gen<EXT, EXT ? ROW : 0>(o, nxt, slot, rows);
+        if (GEN) observe_stage_gen<EXT, EXT ? ROW : 0, TABLE>(o, nxt, slot, rows);
         else observe_stage<TILE, EXT, EXT ? ROW : 0>(o, nxt, rows, lane, tc.e);
       }
       if (q < a.S2) {
@@ -1472,8 +1490,10 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
   int waves = lbf ? WAVESB : (ext ? WAVES16_EXT : WAVES16);
   if (o.N < c + 1) return MDR_ERR_UNSUPPORTED;   // c distinct circular neighbours
   static const bool force_gen = [] { const char* t = getenv("MDR_OBSERVE_GEN"); return t && t[0] == '1'; }();   // experiment knob
-  const bool gen = o.N % 32 != 0 || force_gen;     // tiles that start anywhere in an env / span several: the general staging
-  if (gen && observe_window_lanes(o.N, c, tile) > 64) return MDR_ERR_UNSUPPORTED;
+  const bool table = ext && o.links != nullptr;    // senders by a link table: gathered from the message records, one staging lane per agent
+  if (table && o.msg_rec == nullptr) return MDR_ERR_INVALID;
+  const bool gen = o.N % 32 != 0 || force_gen || table;   // tiles that start anywhere in an env / span several: the general staging
+  if (gen && observe_window_lanes(o.N, table ? 0 : c, tile) > 64) return MDR_ERR_UNSUPPORTED;
   ActorArgs a{};
   a.frag1 = static_cast<const float*>(actor->frag1); a.frag2 = static_cast<const float*>(actor->frag2); a.wdiff = actor->wdiff;
   a.action = action; a.a_prob = a_prob; a.probs = probs;
@@ -1521,8 +1541,9 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
   if (ext) {   // optional state columns / c != 10 / link defects: the general staging with run-time row shape
     if (lbf) {
 #define MDR_OBSERVE_BF16_EXT(MBV)                                                                                                    \
-  (gen ? (rows_out ? launch(k_actor_observe_bf16<MBV, true, true, true>) : launch(k_actor_observe_bf16<MBV, false, true, true>))    \
-       : (rows_out ? launch(k_actor_observe_bf16<MBV, true, false, true>) : launch(k_actor_observe_bf16<MBV, false, false, true>)))
+  (table ? (rows_out ? launch(k_actor_observe_bf16<MBV, true, true, true, true>) : launch(k_actor_observe_bf16<MBV, false, true, true, true>)) \
+   : gen ? (rows_out ? launch(k_actor_observe_bf16<MBV, true, true, true>) : launch(k_actor_observe_bf16<MBV, false, true, true>))    \
+         : (rows_out ? launch(k_actor_observe_bf16<MBV, true, false, true>) : launch(k_actor_observe_bf16<MBV, false, false, true>)))
       return mb == 7 ? MDR_OBSERVE_BF16_EXT(7) : MDR_OBSERVE_BF16_EXT(8);
 #undef MDR_OBSERVE_BF16_EXT
     }
@@ -1531,10 +1552,19 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
   (extk == 13 ? (rows_out ? launch(k_actor_observe16<MBV, true, GENV, TAILV, 13>) : launch(k_actor_observe16<MBV, false, GENV, TAILV, 13>))   \
    : extk == 15 ? (rows_out ? launch(k_actor_observe16<MBV, true, GENV, TAILV, 15>) : launch(k_actor_observe16<MBV, false, GENV, TAILV, 15>)) \
                 : (rows_out ? launch(k_actor_observe16<MBV, true, GENV, TAILV, 16>) : launch(k_actor_observe16<MBV, false, GENV, TAILV, 16>)))
+#define MDR_OBSERVE16_EXT_T(MBV, TAILV)                                                                                                                    \
+  (extk == 13 ? (rows_out ? launch(k_actor_observe16<MBV, true, true, TAILV, 13, true>) : launch(k_actor_observe16<MBV, false, true, TAILV, 13, true>))   \
+   : extk == 15 ? (rows_out ? launch(k_actor_observe16<MBV, true, true, TAILV, 15, true>) : launch(k_actor_observe16<MBV, false, true, TAILV, 15, true>)) \
+                : (rows_out ? launch(k_actor_observe16<MBV, true, true, TAILV, 16, true>) : launch(k_actor_observe16<MBV, false, true, TAILV, 16, true>)))
+    if (table) {
+      if (layout == MDR_ACTOR_FRAG16T) return MDR_OBSERVE16_EXT_T(7, true);
+      return mb == 7 ? MDR_OBSERVE16_EXT_T(7, false) : MDR_OBSERVE16_EXT_T(8, false);
+    }
     // (the whole-tile staging for the reference's [100, 100] actor; other hidden sizes take the general windows whatever N is)
     if (layout == MDR_ACTOR_FRAG16T) return gen ? MDR_OBSERVE16_EXT_G(7, true, true) : MDR_OBSERVE16_EXT_G(7, true, false);
     return mb == 7 ? MDR_OBSERVE16_EXT_G(7, false, true) : MDR_OBSERVE16_EXT_G(8, false, true);
 #undef MDR_OBSERVE16_EXT_G
+#undef MDR_OBSERVE16_EXT_T
   }
 #define MDR_OBSERVE_VARIANT(KERNEL, ...)                                                                     \
   (rows_out ? (gen ? launch(KERNEL<__VA_ARGS__, true, true>) : launch(KERNEL<__VA_ARGS__, true, false>))   \

@@ -214,8 +214,9 @@ class FusedActor:
         """Observe -> act in ONE kernel (``mdr_env_actor_sample``): ``utils.normStateDict`` of every agent of ``env`` (a
         ``BatchedDemandResponseEnv`` in its current state) is built in LDS from the compact state and fed straight to the
         matrix-core forward - no observation rows.  Needs an actor packed with ``feature_order=FEATURES_OBSERVE`` (layout FRAG16
-        or BF16X3) and the default observation (51 features); raises ``NotImplementedError`` otherwise (use
-        ``env.obs_vector('rows')`` + ``sample``).  Same draws and outputs as ``sample`` on the rows (agent = env * N + house).
+        or BF16X3) for this observation shape (optional state columns, up to 13 senders - circular neighbours, a link table or
+        random_sample -, link defects; at most 64 features); raises ``NotImplementedError`` otherwise - the optional MESSAGE
+        columns - (use ``env.obs_vector('rows')`` + ``sample``).  Same draws and outputs as ``sample`` on the rows (agent = env * N + house).
         ``rows_out`` (float32 [A, 51] contiguous): also receives the observation rows in normStateDict order - bit for bit
         ``env.obs_vector('rows')`` - written on the side by the same kernel (the transition buffer's ``state``)."""
         A = env.nb_envs * env.nb_houses
@@ -228,13 +229,26 @@ class FusedActor:
         if rows_out is not None and (rows_out.dtype != torch.float32 or rows_out.device != self.device or not rows_out.is_contiguous()
                                      or rows_out.numel() != A * self.num_state):
             raise ValueError("rows_out must be a contiguous float32 [A, %d] tensor on the device" % self.num_state)
+        tail = (C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(step & (2 ** 64 - 1)), C.c_void_p(step_dev.data_ptr()) if step_dev is not None else None,
+                C.c_void_p(action.data_ptr()), C.c_void_p(a_prob.data_ptr()), C.c_void_p(probs.data_ptr()) if want_probs else None,
+                C.c_void_p(rows_out.data_ptr()) if rows_out is not None else None)
         with torch.cuda.device(self.device):
-            rc = self._lib.mdr_env_actor_sample(env._handle, C.byref(spec), C.byref(self._desc), C.c_uint64(seed & (2 ** 64 - 1)),
-                                                C.c_uint64(step & (2 ** 64 - 1)), C.c_void_p(step_dev.data_ptr()) if step_dev is not None else None,
-                                                C.c_void_p(action.data_ptr()), C.c_void_p(a_prob.data_ptr()),
-                                                C.c_void_p(probs.data_ptr()) if want_probs else None,
-                                                C.c_void_p(rows_out.data_ptr()) if rows_out is not None else None,
-                                                C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            if spec.nb_comm > 0 and (spec.links or spec.random_links):
+                # senders by a link table / re-drawn every step: the kernel gathers the senders' message records, which the call
+                # writes into scratch kept with the env (64 MB at 4.19 M houses; random_sample: + 4 nb_comm bytes per house)
+                msg = getattr(env, "_observe_msg", None)
+                if msg is None or msg.numel() != A * 4 or msg.device != self.device:
+                    msg = env._observe_msg = torch.empty(A * 4, dtype=torch.float32, device=self.device)
+                senders = None
+                if spec.random_links:
+                    senders = getattr(env, "_observe_senders", None)
+                    if senders is None or senders.numel() != A * spec.nb_comm or senders.device != self.device:
+                        senders = env._observe_senders = torch.empty(A * spec.nb_comm, dtype=torch.int32, device=self.device)
+                rc = self._lib.mdr_env_actor_sample_links(env._handle, C.byref(spec), C.byref(self._desc), C.c_void_p(msg.data_ptr()),
+                                                          C.c_void_p(senders.data_ptr()) if senders is not None else None, *tail, stream)
+            else:
+                rc = self._lib.mdr_env_actor_sample(env._handle, C.byref(spec), C.byref(self._desc), *tail, stream)
         if rc == nat.MDR_ERR_UNSUPPORTED:
             raise NotImplementedError("observe -> act: " + self._lib.mdr_last_error(env._handle).decode())
         nat.check(self._lib, env._handle, rc, "mdr_env_actor_sample")

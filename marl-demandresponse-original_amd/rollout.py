@@ -88,16 +88,19 @@ def _fused_policy(actor, dev, precision: str = "fp32", observe: bool = False, ms
 
 
 def _observe_act_supported(env, actor) -> bool:
-    """Can ``FusedActor.sample_env`` serve this env / actor?  Circular neighbours (at most 13, fewer than the houses) with 4-field
-    messages, any of the optional STATE columns, link defects, at most 64 features, unsharded houses."""
-    from .comm import nb_comm
-    env_prop = env.config["default_env_prop"]
-    cluster, mp = env_prop["cluster_prop"], env_prop["message_properties"]
-    c = nb_comm(cluster)
+    """Can ``FusedActor.sample_env`` serve this env / actor?  At most 13 senders (fewer than the houses) - the circular neighbours,
+    a link table or random_sample - with 4-field messages, any of the optional STATE columns, link defects, at most 64 features,
+    unsharded houses."""
+    mp = env.config["default_env_prop"]["message_properties"]
+    c = _observe_senders(env)
     F = env.obs_vector_length()
-    return (not env.sharded and cluster["agents_comm_mode"] == "neighbours" and not getattr(env, "_links_forced", False)
-            and not mp["thermal"] and not mp["hvac"] and c <= 13 and env.nb_houses >= c + 1 and F <= 64
+    return (not env.sharded and not mp["thermal"] and not mp["hvac"] and c <= 13 and env.nb_houses >= c + 1 and F <= 64
             and actor.fc[0].in_features == F)
+
+
+def _observe_senders(env) -> int:
+    """Message slots per house of this env's observation (the width of its link table where it has one)."""
+    return int(env._obs_spec("rows").nb_comm)
 
 
 def _fusable(actor) -> bool:
@@ -141,7 +144,7 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
     ``policy_precision="bf16x3"`` runs the fused kernel on bf16 matrix instructions with every operand split into a
     bf16 head and tail (16 significand bits; probabilities within ~1e-5 of the fp32 forward) - about 2.7x faster.
     ``observe_act`` (default: for every shape the kernels cover - the reference's default observation of 51 features and 10
-    circular neighbours, optional state columns, up to 13 circular neighbours, link defects):
+    circular neighbours, optional state columns, up to 13 senders - circular neighbours, a link table or random_sample -, link defects):
     observation and policy are ONE kernel (``FusedActor.sample_env``): the 51 features of every agent are built in LDS from the
     compact state and fed to the matrix cores from there; with ``store_states`` the same kernel copies the rows into the
     transition buffer on the side (written once, never read back by the policy), without it they are not materialised at all.
@@ -173,9 +176,8 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
     if observe_act and not fused:
         raise ValueError("observe_act needs the fused policy")
     if fused:
-        from .comm import nb_comm
         policy = _fused_policy(actor, dev, policy_precision, observe=observe_act,
-                               msg_floats=4 * nb_comm(env.config["default_env_prop"]["cluster_prop"]))
+                               msg_floats=4 * _observe_senders(env))
         act_u8 = torch.empty((T, E * N), dtype=torch.uint8, device=dev)
 
     def observe(t):      # straight into the transition buffer when states are kept: no 4 F bytes/agent copy per step

@@ -148,16 +148,66 @@ def test_observe_act_extended_shapes(E, N, flags, nb_comm, defects, layout):
         _walk(env, 7, seed=k)
 
 
+@pytest.mark.parametrize("E,N,mode,nb_comm,flags,defects", [
+    (6, 64, "closed_groups", 10, (), 0.0),                      # groups of 11 that all hear each other (env 830-857)
+    (40, 50, "closed_groups", 4, ("hour", "day"), 0.1),         # the deployment size, tiles across envs, link defects on top
+    (3, 1024, "random_fixed", 10, ("thermal", "hvac"), 0.0),    # one table drawn per episode, senders anywhere in the env (env 866-878)
+    (9, 96, "random_fixed", 13, (), 0.3),
+    (25, 36, "neighbours_2D", 8, ("solar_gain",), 0.0),         # the 2-D neighbourhood table (env 859-897)
+    (7, 33, "random_sample", 10, (), 0.0),                      # senders re-drawn per house and step (env 976-983)
+    (2, 1000, "random_sample", 5, ("day",), 0.2),
+    (100, 20, "random_sample", 3, (), 0.0),
+])
+@pytest.mark.parametrize("layout", [3, 2, 1])
+def test_observe_act_link_tables(E, N, mode, nb_comm, flags, defects, layout):
+    """Senders that are not the circular neighbours (ClusterHouses.build_agent_comm_links, env 806-902; random_sample 976-983):
+    the actor kernel gathers their message records through the table (mdr_env_actor_sample_links).  Rows written on the side ==
+    mdr_env_obs_vector bit for bit, probabilities == the actor on those rows."""
+    import mdr_amd
+    from mdr_amd.policy import FEATURES_OBSERVE, FusedActor
+    from mdr_amd.rollout import ActorMLP
+    cfg = _shape_cfg(N, flags, nb_comm, defects)
+    cluster = cfg["default_env_prop"]["cluster_prop"]
+    cluster["agents_comm_mode"] = mode
+    if mode == "neighbours_2D":
+        cluster["agents_comm_parameters"]["neighbours_2D"].update({"row_size": 6, "distance_comm": 2})
+    env = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=5 + N)
+    env.reset(episode=1)
+    F = env.obs_vector_length()
+    c = (F - 11 - 2 * ("hour" in flags) - 2 * ("day" in flags) - ("solar_gain" in flags) - 5 * ("thermal" in flags) - 2 * ("hvac" in flags)) // 4
+    torch.manual_seed(E)
+    actor = ActorMLP(F, 2, (100, 100)).to("cuda:0")
+    with torch.no_grad():
+        for lin in actor.fc:
+            lin.weight.mul_(2.0)
+            lin.bias.uniform_(-0.5, 0.5)
+    by_rows = FusedActor.from_module(actor, layout=layout)
+    by_state = FusedActor.from_module(actor, layout=layout, feature_order=FEATURES_OBSERVE, observe_msg_floats=4 * c)
+    for k in range(3):
+        rows = env.obs_vector("rows").view(E * N, F)
+        a0, p0, probs0 = by_rows.sample(rows, seed=9, step=k, want_probs=True)
+        kept = torch.full((E * N, F), float("nan"), device="cuda:0")
+        a1, p1, probs1 = by_state.sample_env(env, seed=9, step=k, want_probs=True, rows_out=kept)
+        assert torch.equal(kept, rows), "rows_out differs from obs_vector('rows')"
+        a2, p2, probs2 = by_state.sample_env(env, seed=9, step=k, want_probs=True)
+        assert torch.equal(a2, a1) and torch.equal(probs2, probs1)
+        with torch.no_grad():
+            ref = actor(rows)
+        tol = dict(rtol=2e-3, atol=2e-5) if layout == 2 else dict(rtol=1e-5, atol=2e-6)
+        torch.testing.assert_close(probs1, ref, **tol)
+        torch.testing.assert_close(probs1, probs0, **tol)
+        assert int((a0 != a1).sum()) <= max(2, E * N // 20000)
+        _walk(env, 7, seed=k)
+
+
 def test_observe_act_refuses_what_it_does_not_cover():
     import mdr_amd
     from mdr_amd.policy import FEATURES_OBSERVE, FusedActor
     from mdr_amd.rollout import ActorMLP
     actor = _actor()
     by_state = FusedActor.from_module(actor, layout=1, feature_order=FEATURES_OBSERVE)
-    # what stays with rows + actor: senders that are not the circular neighbours, the optional MESSAGE columns, more than 64 features
-    for patches in ({"default_env_prop.cluster_prop.agents_comm_mode": "closed_groups"},
-                    {"default_env_prop.cluster_prop.agents_comm_mode": "random_sample"},
-                    {"default_env_prop.message_properties.thermal": True},
+    # what stays with rows + actor: the optional MESSAGE columns (with 10 senders beyond the 64 features of a staged row), more than 64 features
+    for patches in ({"default_env_prop.message_properties.thermal": True},
                     {"default_env_prop.message_properties.hvac": True}):
         env = mdr_amd.BatchedDemandResponseEnv(_cfg(64, **patches), nb_envs=4, device="cuda:0", seed=1)
         env.reset(episode=0)

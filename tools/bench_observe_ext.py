@@ -39,14 +39,18 @@ def main():
     E, N = (int(x) for x in args.shape.split("x"))
     cases = (("default F=51", (), 10, 0.0), ("thermal + hvac F=58", ("thermal", "hvac"), 10, 0.0), ("10 % link defects F=51", (), 10, 0.1),
              ("every state column F=63", ("hour", "day", "solar_gain", "thermal", "hvac"), 10, 0.0), ("6 neighbours F=35", (), 6, 0.0),
-             ("thermal + hvac, 10 % defects F=58", ("thermal", "hvac"), 10, 0.1))
+             ("thermal + hvac, 10 % defects F=58", ("thermal", "hvac"), 10, 0.1),
+             # senders by a link table / re-drawn every step: gathered from the message records (mdr_env_actor_sample_links)
+             ("closed_groups F=51", (), 10, 0.0, "closed_groups"), ("random_fixed F=51", (), 10, 0.0, "random_fixed"),
+             ("random_sample F=51", (), 10, 0.0, "random_sample"))
     base = {}
     if args.cases:
         cases = tuple(cases[int(i)] for i in args.cases.split(","))
-    for name, flags, c, defects in cases:
+    for name, flags, c, defects, *mode in cases:
         cfg = mdr_amd.default_config()
         env_prop = cfg["default_env_prop"]
         env_prop["cluster_prop"]["nb_agents"] = N
+        env_prop["cluster_prop"]["agents_comm_mode"] = mode[0] if mode else "neighbours"
         env_prop["cluster_prop"]["nb_agents_comm"] = c
         env_prop["cluster_prop"]["comm_defect_prob"] = defects
         env_prop["power_grid_prop"]["base_power_mode"] = "constant"
