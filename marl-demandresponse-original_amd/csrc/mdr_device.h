@@ -216,7 +216,8 @@ __device__ __forceinline__ HouseOut house_step(const HouseIn& h, bool cmd, float
   const float hi = fmaf(0.5f, h.deadband, h.target);
   const float lo = fmaf(-0.5f, h.deadband, h.target);
   const float above = o.Ta - hi, below = lo - o.Ta;
-  o.pen = above > 0.0f ? above * above : (below > 0.0f ? below * below : 0.0f);
+  const float excess = above > 0.0f ? above : (below > 0.0f ? below : 0.0f);   // one select chain and ONE product: the same bits as
+  o.pen = excess * excess;                                                     // squaring inside each arm, without the arms' branches
   o.power = on2 ? h.P_max : 0.0f;
   return o;
 }
@@ -338,9 +339,10 @@ __device__ __forceinline__ Red3 block_reduce(Red3 v, double* lds /* [3][THREADS/
   __syncthreads();
   Red3 t{0.0, 0.0, 0.0f};
 #pragma unroll
-  for (int w = 0; w < WAVES; ++w) {  // same order in every thread: identical totals, no second barrier
-    t.sum_p += lds[w];
-    if (pen) {
+  for (int w = 0; w < WAVES; ++w) t.sum_p += lds[w];  // same order in every thread: identical totals, no second barrier
+  if (pen) {
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
       t.sum_pen += lds[WAVES + w];
       t.max_pen = fmaxf(t.max_pen, (float)lds[2 * WAVES + w]);
     }

@@ -7,12 +7,14 @@
 
 namespace mdr {
 
+// Selects on the (wave-uniform) mode, not branches: written as an if-chain this cost the multi-step kernels a dozen scalar branches
+// per HOUSE and step; the env-wide parts (common, the inner fma) are the same for every house of a lane and are formed once.
 __device__ __forceinline__ float temp_penalty(const StepArgs& a, float pen, double sum_pen, float max_pen) {
-  if (a.penalty_mode == MDR_PENALTY_INDIVIDUAL_L2) return pen;
   const float common = (float)(sum_pen * a.inv_n_total);
-  if (a.penalty_mode == MDR_PENALTY_COMMON_L2) return common;
-  if (a.penalty_mode == MDR_PENALTY_COMMON_MAX) return max_pen;
-  return __fmaf_rn(a.mix_i, pen, __fmaf_rn(a.mix_c, common, a.mix_m * max_pen));   // explicit: no context-dependent contraction
+  const float mixture = __fmaf_rn(a.mix_i, pen, __fmaf_rn(a.mix_c, common, a.mix_m * max_pen));   // explicit: no context-dependent contraction
+  const float env_wide = a.penalty_mode == MDR_PENALTY_COMMON_L2 ? common : max_pen;
+  const float single = a.penalty_mode == MDR_PENALTY_INDIVIDUAL_L2 ? pen : env_wide;
+  return (a.penalty_mode == MDR_PENALTY_INDIVIDUAL_L2 || a.penalty_mode == MDR_PENALTY_COMMON_L2 || a.penalty_mode == MDR_PENALTY_COMMON_MAX) ? single : mixture;
 }
 
 // r_i = -(alpha_temp * pen_i / norm_T + alpha_sig * sig / norm_S)  (env 364-372); one explicit fma so that every
