@@ -198,8 +198,16 @@ struct HouseOut {
   float pen, power;
 };
 
-__device__ __forceinline__ HouseOut house_step(const HouseIn& h, bool cmd, float od_old, float solar, int dt) {
-  const bool on = (h.flags & 1u) != 0u;
+// The same step with the HVAC's on / lockout bits as booleans: the multi-step kernels carry them from step to step as lane masks
+// (scalar registers) instead of packing them into `flags` after every step and unpacking them before the next.
+struct HouseNext {
+  float Ta, Tm;
+  int sso;
+  bool on, lock;
+  float pen, power;
+};
+
+__device__ __forceinline__ HouseNext house_advance(const HouseIn& h, bool on, bool cmd, float od_old, float solar, int dt) {
   const int sso1 = on ? h.sso : h.sso + dt;          // env 475-476
   const bool can = on || (sso1 >= h.lockout);        // env 478-481
   const bool on2 = can && cmd;                       // env 483-486
@@ -208,11 +216,12 @@ __device__ __forceinline__ HouseOut house_step(const HouseIn& h, bool cmd, float
   const float Qa = (on2 ? h.Q_hvac : 0.0f) + solar;  // env 690-699
   const float Tinf = fmaf(Qa, h.inv_Ua, od_old);     // uses the PREVIOUS step's outdoor temperature (env 1034)
   const float dm = h.Tm - h.Ta;
-  HouseOut o;
+  HouseNext o;
   o.Ta = h.Ta + fmaf(h.k01, dm, h.s0 * (h.Ta - Tinf));
   o.Tm = h.Tm + fmaf(-h.k10, dm, h.s1 * (h.Tm - Tinf));
   o.sso = sso2;
-  o.flags = (on2 ? 1u : 0u) | (lock2 ? 2u : 0u);
+  o.on = on2;
+  o.lock = lock2;
   const float hi = fmaf(0.5f, h.deadband, h.target);
   const float lo = fmaf(-0.5f, h.deadband, h.target);
   const float above = o.Ta - hi, below = lo - o.Ta;
@@ -220,6 +229,52 @@ __device__ __forceinline__ HouseOut house_step(const HouseIn& h, bool cmd, float
   o.pen = excess * excess;                                                     // squaring inside each arm, without the arms' branches
   o.power = on2 ? h.P_max : 0.0f;
   return o;
+}
+
+// ... and with the bits of all 64 lanes as LANE MASKS - wave-uniform 64-bit values in scalar registers.  The HVAC's little state
+// machine is then scalar-unit logic on whole masks between the vector compares that feed it (a compare writes its mask straight
+// into a scalar register pair), and a mask steers a per-lane select for free (inverse ballot): 9 vector instructions per house
+// instead of ~18 with per-lane booleans, which the compiler materialises as 0 / 1 in vector registers around every step.  Must be
+// called in wave-uniform control flow (a mask defined under a divergent branch is not one value per wave).  Same arithmetic, same bits.
+struct HouseNextM {
+  float Ta, Tm;
+  int sso;
+  uint64_t on, lock;
+  float pen, power;
+};
+
+__device__ __forceinline__ bool lane_bit(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+
+__device__ __forceinline__ HouseNextM house_advance_m(const HouseIn& h, uint64_t on_m, uint64_t cmd_m, float od_old, float solar, int dt) {
+  const int sso1 = lane_bit(on_m) ? h.sso : h.sso + dt;                                        // env 475-476
+  const uint64_t can_m = on_m | __builtin_amdgcn_ballot_w64(sso1 >= h.lockout);                // env 478-481
+  const uint64_t on2_m = can_m & cmd_m;                                                        // env 483-486
+  const bool on2 = lane_bit(on2_m);
+  const int sso2 = on2 ? 0 : sso1;                                                             // env 487-488
+  const uint64_t lock2_m = ~can_m | (~on2_m & __builtin_amdgcn_ballot_w64(sso2 + dt < h.lockout));   // env 489-492
+  const float Qa = (on2 ? h.Q_hvac : 0.0f) + solar;  // env 690-699
+  const float Tinf = fmaf(Qa, h.inv_Ua, od_old);     // uses the PREVIOUS step's outdoor temperature (env 1034)
+  const float dm = h.Tm - h.Ta;
+  HouseNextM o;
+  o.Ta = h.Ta + fmaf(h.k01, dm, h.s0 * (h.Ta - Tinf));
+  o.Tm = h.Tm + fmaf(-h.k10, dm, h.s1 * (h.Tm - Tinf));
+  o.sso = sso2;
+  o.on = on2_m;
+  o.lock = lock2_m;
+  const float hi = fmaf(0.5f, h.deadband, h.target);
+  const float lo = fmaf(-0.5f, h.deadband, h.target);
+  const float above = o.Ta - hi, below = lo - o.Ta;
+  const float excess = above > 0.0f ? above : (below > 0.0f ? below : 0.0f);
+  o.pen = excess * excess;
+  o.power = on2 ? h.P_max : 0.0f;
+  return o;
+}
+
+__device__ __forceinline__ unsigned house_flags(bool on, bool lock) { return (on ? 1u : 0u) | (lock ? 2u : 0u); }
+
+__device__ __forceinline__ HouseOut house_step(const HouseIn& h, bool cmd, float od_old, float solar, int dt) {
+  const HouseNext n = house_advance(h, (h.flags & 1u) != 0u, cmd, od_old, solar, dt);
+  return HouseOut{n.Ta, n.Tm, n.sso, house_flags(n.on, n.lock), n.pen, n.power};
 }
 
 // a / L for integer-valued a and L (exact in fp32) with y = RN(1 / L): q = RN(a y), r = a - q L (exact in one fma),

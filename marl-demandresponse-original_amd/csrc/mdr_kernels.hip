@@ -726,14 +726,20 @@ __global__ __launch_bounds__(THREADS) void k_rollout_fused(StepArgs a, RolloutAr
   const int e = blockIdx.x;
   const int64_t base = (int64_t)e * a.N;
   HouseIn hs[TILES][VEC];
-  HouseOut o[TILES][VEC];
-  float rsum[TILES][VEC];
-  unsigned act[TILES][VEC];
+  float rsum[TILES][VEC], pen[TILES][VEC];
+  // The HVAC's on / lockout bits and the latest command as 64-bit LANE MASKS (house_advance_m); bytes are formed once, at the end.
+  uint64_t on_m[TILES][VEC], lock_m[TILES][VEC], cmd_m[TILES][VEC];
   bool live[TILES];
 #pragma unroll
   for (int t = 0; t < TILES; ++t) {
     const int h = (t * THREADS + (int)threadIdx.x) * VEC;
     live[t] = h < a.N;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      hs[t][v] = HouseIn{};
+      rsum[t][v] = 0.0f;
+      pen[t][v] = 0.0f;
+    }
     if (live[t]) {
       const int64_t i = base + h;
       float Ta[VEC], Tm[VEC], k01[VEC], s0[VEC], k10[VEC], s1[VEC], iu[VEC], q[VEC], pm[VEC], tg[VEC], db[VEC];
@@ -756,9 +762,14 @@ __global__ __launch_bounds__(THREADS) void k_rollout_fused(StepArgs a, RolloutAr
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         hs[t][v] = HouseIn{Ta[v], Tm[v], sso[v], fl[v], k01[v], s0[v], k10[v], s1[v], iu[v], q[v], pm[v], tg[v], db[v], lk[v]};
-        rsum[t][v] = 0.0f;
       }
       if (ro.reward_sum) load_vec<VEC>(ro.reward_sum, i, rsum[t]);   // continue the caller's running sum in step order
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {   // (outside the branch: a ballot is a wave-wide value)
+      on_m[t][v] = __builtin_amdgcn_ballot_w64(live[t] && (hs[t][v].flags & 1u) != 0u);
+      lock_m[t][v] = __builtin_amdgcn_ballot_w64(live[t] && (hs[t][v].flags & 2u) != 0u);
+      cmd_m[t][v] = 0;
     }
   }
   double terr = 0.0, serr = 0.0;
@@ -788,24 +799,25 @@ __global__ __launch_bounds__(THREADS) void k_rollout_fused(StepArgs a, RolloutAr
     Red3 acc{0.0, 0.0, 0.0f};
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
-      if (live[t]) {
+      {   // every lane, also those past the env's end: their blank houses (all parameters 0) stay at 0 degrees, draw no power and earn no
+          // penalty - exact zeros in every sum - and with no divergent branch around them the ballots below see the whole wave
         float p = 0.0f, ps = 0.0f, te = 0.0f;
-        bool cmds[VEC];
-        controller_cmds<VEC>(BB ? MDR_ACTIONS_BANGBANG : a.action_source, hs[t], cmds);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          const bool cmd = cmds[v];
-          act[t][v] = cmd ? 1u : 0u;
-          o[t][v] = house_step(hs[t][v], cmd, od_old, solar, a.dt);
-          hs[t][v].Ta = o[t][v].Ta;
-          hs[t][v].Tm = o[t][v].Tm;
-          hs[t][v].sso = o[t][v].sso;
-          hs[t][v].flags = o[t][v].flags;
-          p += o[t][v].power;
-          ps += o[t][v].pen;
-          acc.max_pen = fmaxf(acc.max_pen, o[t][v].pen);
+          cmd_m[t][v] = BB ? __builtin_amdgcn_ballot_w64(hs[t][v].Ta > hs[t][v].target)   // agents/bangbang_controllers.py:49-59
+                           : controller_cmd_m(a.action_source, hs[t][v].Ta, hs[t][v].target, hs[t][v].deadband, on_m[t][v]);
+          const HouseNextM n = house_advance_m(hs[t][v], on_m[t][v], cmd_m[t][v], od_old, solar, a.dt);
+          hs[t][v].Ta = n.Ta;
+          hs[t][v].Tm = n.Tm;
+          hs[t][v].sso = live[t] ? n.sso : 0;
+          on_m[t][v] = n.on;
+          lock_m[t][v] = n.lock;
+          pen[t][v] = n.pen;
+          p += n.power;
+          ps += n.pen;
+          acc.max_pen = fmaxf(acc.max_pen, n.pen);
           if (want_terr) {
-            const float d = o[t][v].Ta - hs[t][v].target;
+            const float d = n.Ta - hs[t][v].target;
             te = fmaf(d, d, te);
           }
         }
@@ -822,7 +834,7 @@ __global__ __launch_bounds__(THREADS) void k_rollout_fused(StepArgs a, RolloutAr
         if (live[t]) {
 #pragma unroll
           for (int v = 0; v < VEC; ++v)
-            rsum[t][v] = __fadd_rn(rsum[t][v], reward_value(a, o[t][v].pen, tot.sum_pen, tot.max_pen, sig_term));
+            rsum[t][v] = __fadd_rn(rsum[t][v], reward_value(a, pen[t][v], tot.sum_pen, tot.max_pen, sig_term));
         }
     }
     if (threadIdx.x == 0) {
@@ -839,25 +851,27 @@ __global__ __launch_bounds__(THREADS) void k_rollout_fused(StepArgs a, RolloutAr
   for (int t = 0; t < TILES; ++t) {
     if (!live[t]) continue;
     const int64_t i = base + (t * THREADS + (int)threadIdx.x) * VEC;
-    float nTa[VEC], nTm[VEC], pen[VEC];
+    float nTa[VEC], nTm[VEC];
     int nsso[VEC], lk[VEC];
-    unsigned nfl[VEC];
+    unsigned nfl[VEC], act[VEC];
+    HouseOut o[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       nTa[v] = hs[t][v].Ta;
       nTm[v] = hs[t][v].Tm;
       nsso[v] = hs[t][v].sso;
-      nfl[v] = hs[t][v].flags;
+      nfl[v] = house_flags(__builtin_amdgcn_inverse_ballot_w64(on_m[t][v]), __builtin_amdgcn_inverse_ballot_w64(lock_m[t][v]));
       lk[v] = hs[t][v].lockout;
-      pen[v] = o[t][v].pen;
+      act[v] = __builtin_amdgcn_inverse_ballot_w64(cmd_m[t][v]) ? 1u : 0u;
+      o[v] = HouseOut{nTa[v], nTm[v], nsso[v], nfl[v], pen[t][v], 0.0f};
     }
     store_vec<VEC>(a.Ta, i, nTa);
     store_vec<VEC>(a.Tm, i, nTm);
     store_vec<VEC>(a.sso, i, nsso);
     store_bytes<VEC>(a.flags, i, nfl);
-    if (a.actions != nullptr) store_bytes<VEC>(a.actions, i, act[t]);
-    store_obs_local<VEC>(a, i, o[t], lk);
-    store_reward_power<VEC>(a, i, pen, tot.sum_pen, tot.max_pen, sig_term, o_sig, o_pow);
+    if (a.actions != nullptr) store_bytes<VEC>(a.actions, i, act);
+    store_obs_local<VEC>(a, i, o, lk);
+    store_reward_power<VEC>(a, i, pen[t], tot.sum_pen, tot.max_pen, sig_term, o_sig, o_pow);
     if (ro.reward_sum) store_vec<VEC>(ro.reward_sum, i, rsum[t]);
   }
   if (ro.sq_temp_error_sum) {   // one more reduction; the parity of the LDS buffer continues the step sequence

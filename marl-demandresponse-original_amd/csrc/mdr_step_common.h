@@ -149,7 +149,7 @@ __device__ __forceinline__ void store_bytes(uint8_t* __restrict__ p, int64_t i, 
 // values of house v's env (one env per call in most kernels; k_step_multi's lanes may hold the end of one env and the start of the next).
 // The reference's rule-based controllers on the pre-step observation (agents/bangbang_controllers.py): BangBangController 41-61,
 // DeadbandBangBangController 13-38 == BasicController 64-88, AlwaysOnController 1-10.  `src` is wave-uniform.
-__device__ __forceinline__ bool controller_cmd(int src, float Ta, float target, float deadband, unsigned flags) {
+__device__ __forceinline__ bool controller_cmd(int src, float Ta, float target, float deadband, bool on) {
 #if defined(MDR_CONTROLLER_BANGBANG_ONLY) && MDR_CONTROLLER_BANGBANG_ONLY   // experiment build: what the other two rules cost the bang-bang loop
   return Ta > target;
 #endif
@@ -158,8 +158,12 @@ __device__ __forceinline__ bool controller_cmd(int src, float Ta, float target, 
   // deadband rule keeps what the HVAC is doing, bang-bang says off (its band is the single point Ta == target)
   const float h = (src == MDR_ACTIONS_DEADBAND ? 0.5f : 0.0f) * deadband;
   const bool above = Ta > target + h, below = Ta < target - h;
-  const bool keep = src == MDR_ACTIONS_DEADBAND && (flags & 1u) != 0u;
+  const bool keep = src == MDR_ACTIONS_DEADBAND && on;
   return above || (!below && keep) || src == MDR_ACTIONS_ALWAYS_ON;
+}
+
+__device__ __forceinline__ bool controller_cmd(int src, float Ta, float target, float deadband, unsigned flags) {   // flags: bit 0 = on
+  return controller_cmd(src, Ta, target, deadband, (flags & 1u) != 0u);
 }
 
 // The commands of a lane's VEC houses.  The bang-bang rule - the default of every closed loop - sits behind a wave-uniform BRANCH
@@ -171,7 +175,27 @@ __device__ __forceinline__ void controller_cmds(int src, const HouseIn* hs, bool
     for (int v = 0; v < VEC; ++v) cmd[v] = hs[v].Ta > hs[v].target;   // agents/bangbang_controllers.py:49-59
   } else {
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) cmd[v] = controller_cmd(src, hs[v].Ta, hs[v].target, hs[v].deadband, hs[v].flags);
+    for (int v = 0; v < VEC; ++v) cmd[v] = controller_cmd(src, hs[v].Ta, hs[v].target, hs[v].deadband, (hs[v].flags & 1u) != 0u);
+  }
+}
+
+// The same rules on lane masks (house_advance_m): the commands of all 64 lanes' house v as one mask
+__device__ __forceinline__ uint64_t controller_cmd_m(int src, float Ta, float target, float deadband, uint64_t on_m) {
+  const float h = (src == MDR_ACTIONS_DEADBAND ? 0.5f : 0.0f) * deadband;
+  const uint64_t above = __builtin_amdgcn_ballot_w64(Ta > target + h), below = __builtin_amdgcn_ballot_w64(Ta < target - h);
+  const uint64_t keep = src == MDR_ACTIONS_DEADBAND ? on_m : 0ull;
+  return above | (~below & keep) | (src == MDR_ACTIONS_ALWAYS_ON ? ~0ull : 0ull);
+}
+
+// ... with the on bits carried as booleans (house_advance)
+template <int VEC>
+__device__ __forceinline__ void controller_cmds(int src, const HouseIn* hs, const bool* on, bool* cmd) {
+  if (src == MDR_ACTIONS_BANGBANG) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) cmd[v] = hs[v].Ta > hs[v].target;
+  } else {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) cmd[v] = controller_cmd(src, hs[v].Ta, hs[v].target, hs[v].deadband, on[v]);
   }
 }
 
@@ -212,7 +236,7 @@ __device__ __forceinline__ void step_vec_rows(const StepArgs& a, int64_t i, cons
   } else {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-      cmds[v] = controller_cmd(a.action_source, Ta[v], tg[v], db[v], fl[v]);
+      cmds[v] = controller_cmd(a.action_source, Ta[v], tg[v], db[v], (fl[v] & 1u) != 0u);
       act[v] = cmds[v] ? 1u : 0u;
     }
   }
