@@ -1019,17 +1019,15 @@ __global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs r
   const bool active = env_ok && lane * VEC < a.N;
   const int64_t i = (int64_t)e * a.N + lane * VEC;
   HouseIn hs[VEC];
-  HouseOut o[VEC];
   int lockout[VEC];
   float rsum[VEC], pen[VEC];
-  unsigned act[VEC];
+  uint64_t on_m[VEC], lock_m[VEC], cmd_m[VEC];   // the HVAC bits and the latest command as lane masks (house_advance_m)
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
     hs[v] = HouseIn{};
-    o[v] = HouseOut{};
     lockout[v] = 1;
     rsum[v] = 0.0f;
-    act[v] = 0;
+    pen[v] = 0.0f;
   }
   if (active) {
     float Ta[VEC], Tm[VEC], k01[VEC], s0[VEC], k10[VEC], s1[VEC], iu[VEC], q[VEC], pm[VEC], tg[VEC], db[VEC];
@@ -1054,6 +1052,12 @@ __global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs r
       hs[v] = HouseIn{Ta[v], Tm[v], sso[v], fl[v], k01[v], s0[v], k10[v], s1[v], iu[v], q[v], pm[v], tg[v], db[v], lockout[v]};
     if (ro.reward_sum) load_vec<VEC>(ro.reward_sum, i, rsum);   // continue the caller's running sum in step order
   }
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    on_m[v] = __builtin_amdgcn_ballot_w64((hs[v].flags & 1u) != 0u);
+    lock_m[v] = __builtin_amdgcn_ballot_w64((hs[v].flags & 2u) != 0u);
+    cmd_m[v] = 0;
+  }
   float sig_term = 0.0f;
   double terr = 0.0, serr = 0.0;
   Red3 tot{0.0, 0.0, 0.0f};
@@ -1075,23 +1079,24 @@ __global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs r
       er = EnvRow{a.od_old[row], a.solar_new[row], a.sig_old[row], a.sig_new[row]};
     }
     Red3 acc{0.0, 0.0, 0.0f};
-    if (active) {
+    {   // every lane, idle ones too: their blank houses (all parameters 0) stay at 0 degrees, draw no power and earn no penalty - exact
+        // zeros in every sum - and the lane masks are formed in wave-uniform control flow
       float p = 0.0f, ps = 0.0f, te = 0.0f;
-      bool cmds[VEC];
-      controller_cmds<VEC>(BB ? MDR_ACTIONS_BANGBANG : a.action_source, hs, cmds);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        const bool cmd = cmds[v];
-        act[v] = cmd ? 1u : 0u;
-        o[v] = house_step(hs[v], cmd, er.od, er.solar, a.dt);
-        hs[v].Ta = o[v].Ta;
-        hs[v].Tm = o[v].Tm;
-        hs[v].sso = o[v].sso;
-        hs[v].flags = o[v].flags;
-        p += o[v].power;
-        ps += o[v].pen;
-        acc.max_pen = fmaxf(acc.max_pen, o[v].pen);
-        const float d = o[v].Ta - hs[v].target;
+        cmd_m[v] = BB ? __builtin_amdgcn_ballot_w64(hs[v].Ta > hs[v].target)   // agents/bangbang_controllers.py:49-59
+                      : controller_cmd_m(a.action_source, hs[v].Ta, hs[v].target, hs[v].deadband, on_m[v]);
+        const HouseNextM n = house_advance_m(hs[v], on_m[v], cmd_m[v], er.od, er.solar, a.dt);
+        hs[v].Ta = n.Ta;
+        hs[v].Tm = n.Tm;
+        hs[v].sso = active ? n.sso : 0;
+        on_m[v] = n.on;
+        lock_m[v] = n.lock;
+        pen[v] = n.pen;
+        p += n.power;
+        ps += n.pen;
+        acc.max_pen = fmaxf(acc.max_pen, n.pen);
+        const float d = n.Ta - hs[v].target;
         te = fmaf(d, d, te);
       }
       acc.sum_p = (double)p;
@@ -1103,7 +1108,7 @@ __global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs r
     if (active) {
       if (want_rsum) {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) rsum[v] = __fadd_rn(rsum[v], reward_value(a, o[v].pen, tot.sum_pen, tot.max_pen, sig_term));
+        for (int v = 0; v < VEC; ++v) rsum[v] = __fadd_rn(rsum[v], reward_value(a, pen[v], tot.sum_pen, tot.max_pen, sig_term));
       }
       if (lane == 0) {
         if (ro.power_trace) ro.power_trace[row] = tot.sum_p;
@@ -1118,14 +1123,16 @@ __global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs r
   if (!active) return;
   float nTa[VEC], nTm[VEC];
   int nsso[VEC];
-  unsigned nfl[VEC];
+  unsigned nfl[VEC], act[VEC];
+  HouseOut o[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
     nTa[v] = hs[v].Ta;
     nTm[v] = hs[v].Tm;
     nsso[v] = hs[v].sso;
-    nfl[v] = hs[v].flags;
-    pen[v] = o[v].pen;
+    nfl[v] = house_flags(lane_bit(on_m[v]), lane_bit(lock_m[v]));
+    act[v] = lane_bit(cmd_m[v]) ? 1u : 0u;
+    o[v] = HouseOut{nTa[v], nTm[v], nsso[v], nfl[v], pen[v], 0.0f};
   }
   store_vec<VEC>(a.Ta, i, nTa);
   store_vec<VEC>(a.Tm, i, nTm);

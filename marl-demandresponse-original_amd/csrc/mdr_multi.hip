@@ -221,17 +221,15 @@ __global__ __launch_bounds__(256) void k_rollout_packed(StepArgs a, RolloutArgs 
   const int e = active ? (int)m.env : a.E - 1;
   const int64_t i = (int64_t)e * a.N + m.lane * 4;
   HouseIn hs[4];
-  HouseOut o[4];
   int lockout[4];
   float rsum[4], pen[4];
-  unsigned act[4];
+  uint64_t on_m[4], lock_m[4], cmd_m[4];   // the HVAC bits and the latest command as lane masks (house_advance_m)
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     hs[v] = HouseIn{};
-    o[v] = HouseOut{};
     lockout[v] = 1;
     rsum[v] = 0.0f;
-    act[v] = 0;
+    pen[v] = 0.0f;
   }
   if (active) {
     float Ta[4], Tm[4], k01[4], s0[4], k10[4], s1[4], iu[4], q[4], pm[4], tg[4], db[4];
@@ -255,6 +253,12 @@ __global__ __launch_bounds__(256) void k_rollout_packed(StepArgs a, RolloutArgs 
     for (int v = 0; v < 4; ++v) hs[v] = HouseIn{Ta[v], Tm[v], sso[v], fl[v], k01[v], s0[v], k10[v], s1[v], iu[v], q[v], pm[v], tg[v], db[v], lockout[v]};
     if (ro.reward_sum) load_vec<4>(ro.reward_sum, i, rsum);
   }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    on_m[v] = __builtin_amdgcn_ballot_w64((hs[v].flags & 1u) != 0u);
+    lock_m[v] = __builtin_amdgcn_ballot_w64((hs[v].flags & 2u) != 0u);
+    cmd_m[v] = 0;
+  }
   float sig_term = 0.0f;
   double terr = 0.0, serr = 0.0, sig_new = 0.0;
   Red3 tot{0.0, 0.0, 0.0f};
@@ -264,23 +268,23 @@ __global__ __launch_bounds__(256) void k_rollout_packed(StepArgs a, RolloutArgs 
     const double sig_old = a.sig_old[row];
     sig_new = a.sig_new[row];
     Red3 acc{0.0, 0.0, 0.0f};
-    if (active) {
+    {   // every lane, idle ones too (blank houses: exact zeros in every sum): the lane masks need wave-uniform control flow
       float p = 0.0f, ps = 0.0f, te = 0.0f;
-      bool cmds[4];
-      controller_cmds<4>(BB ? MDR_ACTIONS_BANGBANG : a.action_source, hs, cmds);
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const bool cmd = cmds[v];
-        act[v] = cmd ? 1u : 0u;
-        o[v] = house_step(hs[v], cmd, od, solar, a.dt);
-        hs[v].Ta = o[v].Ta;
-        hs[v].Tm = o[v].Tm;
-        hs[v].sso = o[v].sso;
-        hs[v].flags = o[v].flags;
-        p += o[v].power;
-        ps += o[v].pen;
-        acc.max_pen = fmaxf(acc.max_pen, o[v].pen);
-        const float d = o[v].Ta - hs[v].target;
+        cmd_m[v] = BB ? __builtin_amdgcn_ballot_w64(hs[v].Ta > hs[v].target)   // agents/bangbang_controllers.py:49-59
+                      : controller_cmd_m(a.action_source, hs[v].Ta, hs[v].target, hs[v].deadband, on_m[v]);
+        const HouseNextM n = house_advance_m(hs[v], on_m[v], cmd_m[v], od, solar, a.dt);
+        hs[v].Ta = n.Ta;
+        hs[v].Tm = n.Tm;
+        hs[v].sso = active ? n.sso : 0;
+        on_m[v] = n.on;
+        lock_m[v] = n.lock;
+        pen[v] = n.pen;
+        p += n.power;
+        ps += n.pen;
+        acc.max_pen = fmaxf(acc.max_pen, n.pen);
+        const float d = n.Ta - hs[v].target;
         te = fmaf(d, d, te);
       }
       acc.sum_p = (double)p;
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(256) void k_rollout_packed(StepArgs a, RolloutArgs 
     if (active) {
       if (want_rsum) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) rsum[v] = __fadd_rn(rsum[v], reward_value(a, o[v].pen, tot.sum_pen, tot.max_pen, sig_term));
+        for (int v = 0; v < 4; ++v) rsum[v] = __fadd_rn(rsum[v], reward_value(a, pen[v], tot.sum_pen, tot.max_pen, sig_term));
       }
       if (m.lane == 0) {
         if (ro.power_trace) ro.power_trace[row] = tot.sum_p;
@@ -307,14 +311,16 @@ __global__ __launch_bounds__(256) void k_rollout_packed(StepArgs a, RolloutArgs 
   if (!active) return;
   float nTa[4], nTm[4];
   int nsso[4];
-  unsigned nfl[4];
+  unsigned nfl[4], act[4];
+  HouseOut o[4];
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     nTa[v] = hs[v].Ta;
     nTm[v] = hs[v].Tm;
     nsso[v] = hs[v].sso;
-    nfl[v] = hs[v].flags;
-    pen[v] = o[v].pen;
+    nfl[v] = house_flags(lane_bit(on_m[v]), lane_bit(lock_m[v]));
+    act[v] = lane_bit(cmd_m[v]) ? 1u : 0u;
+    o[v] = HouseOut{nTa[v], nTm[v], nsso[v], nfl[v], pen[v], 0.0f};
   }
   store_vec<4>(a.Ta, i, nTa);
   store_vec<4>(a.Tm, i, nTm);
