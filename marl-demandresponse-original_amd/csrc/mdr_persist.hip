@@ -249,13 +249,12 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
   const int64_t i = (int64_t)e * a.N + h;
   HouseIn hs[VEC];
   float rsum[VEC], pen_now[VEC], pen_old[VEC];   // pen_old: the penalty of step it - D, back from LDS
-  unsigned act[VEC];
+  uint64_t on_m[VEC], lock_m[VEC], cmd_m[VEC];   // the HVAC bits and the latest command as lane masks (house_advance_m)
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
     hs[v] = HouseIn{};
     hs[v].lockout = 1;
     rsum[v] = 0.0f;
-    act[v] = 0u;
     pen_now[v] = pen_old[v] = 0.0f;
   }
   if (live) {
@@ -288,6 +287,9 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
     asm volatile("" : "+v"(hs[v].Ta), "+v"(hs[v].Tm), "+v"(hs[v].sso), "+v"(hs[v].flags), "+v"(hs[v].k01), "+v"(hs[v].s0), "+v"(hs[v].k10));
     asm volatile("" : "+v"(hs[v].s1), "+v"(hs[v].inv_Ua), "+v"(hs[v].Q_hvac), "+v"(hs[v].P_max), "+v"(hs[v].target), "+v"(hs[v].deadband),
                  "+v"(hs[v].lockout), "+v"(rsum[v]));
+    on_m[v] = __builtin_amdgcn_ballot_w64((hs[v].flags & 1u) != 0u);
+    lock_m[v] = __builtin_amdgcn_ballot_w64((hs[v].flags & 2u) != 0u);
+    cmd_m[v] = 0;
   }
   // A single wavefront issues one instruction every four cycles whatever its kind: this loop is bound by its INSTRUCTION COUNT on the
   // busiest wave (r03 trace: 840 per step, half of them scalar address arithmetic and spilled-pointer reloads).  So: what changes from
@@ -316,17 +318,18 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
     Red3 acc{0.0, 0.0, 0.0f};
     if (it < T) {
       const float od_old = row_od[it], solar = row_solar[it];
-      if (live) {
+      {   // every lane, idle ones too (blank houses: exact zeros in every sum): the lane masks need wave-uniform control flow
         float p = 0.0f, ps = 0.0f, te = 0.0f;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          const bool cmd = BB ? hs[v].Ta > hs[v].target : controller_cmd(a.action_source, hs[v].Ta, hs[v].target, hs[v].deadband, hs[v].flags);   // agents/bangbang_controllers.py
-          act[v] = cmd ? 1u : 0u;
-          const HouseOut o = house_step(hs[v], cmd, od_old, solar, a.dt);
+          cmd_m[v] = BB ? __builtin_amdgcn_ballot_w64(hs[v].Ta > hs[v].target)   // agents/bangbang_controllers.py
+                        : controller_cmd_m(a.action_source, hs[v].Ta, hs[v].target, hs[v].deadband, on_m[v]);
+          const HouseNextM o = house_advance_m(hs[v], on_m[v], cmd_m[v], od_old, solar, a.dt);
           hs[v].Ta = o.Ta;
           hs[v].Tm = o.Tm;
-          hs[v].sso = o.sso;
-          hs[v].flags = o.flags;
+          hs[v].sso = live ? o.sso : 0;
+          on_m[v] = o.on;
+          lock_m[v] = o.lock;
           pen_now[v] = o.pen;
           p += o.power;
           ps += o.pen;
@@ -442,17 +445,18 @@ __global__ __launch_bounds__(256, 4) void k_rollout_persist(StepArgs a, RolloutA
   const float o_pow = (float)(tot.sum_p * a.inv_obs_norm);
   float nTa[VEC], nTm[VEC], pen[VEC];
   int nsso[VEC], lk[VEC];
-  unsigned nfl[VEC];
+  unsigned nfl[VEC], act[VEC];
   HouseOut o[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
     nTa[v] = hs[v].Ta;
     nTm[v] = hs[v].Tm;
     nsso[v] = hs[v].sso;
-    nfl[v] = hs[v].flags;
+    nfl[v] = house_flags(lane_bit(on_m[v]), lane_bit(lock_m[v]));
+    act[v] = lane_bit(cmd_m[v]) ? 1u : 0u;
     lk[v] = hs[v].lockout;
     pen[v] = pen_old[v];
-    o[v] = HouseOut{hs[v].Ta, hs[v].Tm, hs[v].sso, hs[v].flags, pen_old[v], 0.0f};
+    o[v] = HouseOut{hs[v].Ta, hs[v].Tm, hs[v].sso, nfl[v], pen_old[v], 0.0f};
   }
   store_vec<VEC>(a.Ta, i, nTa);
   store_vec<VEC>(a.Tm, i, nTm);
