@@ -814,11 +814,16 @@ __global__ __launch_bounds__(THREADS) void k_rollout_fused(StepArgs a, RolloutAr
           lock_m[t][v] = n.lock;
           pen[t][v] = n.pen;
           p += n.power;
-          ps += n.pen;
-          acc.max_pen = fmaxf(acc.max_pen, n.pen);
           if (want_terr) {
             const float d = n.Ta - hs[t][v].target;
             te = fmaf(d, d, te);
+          }
+        }
+        if (need_pen) {   // individual_L2 reduces the cluster power alone
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            ps += pen[t][v];
+            acc.max_pen = fmaxf(acc.max_pen, pen[t][v]);
           }
         }
         acc.sum_p += (double)p;
@@ -832,9 +837,7 @@ __global__ __launch_bounds__(THREADS) void k_rollout_fused(StepArgs a, RolloutAr
 #pragma unroll
       for (int t = 0; t < TILES; ++t)
         if (live[t]) {
-#pragma unroll
-          for (int v = 0; v < VEC; ++v)
-            rsum[t][v] = __fadd_rn(rsum[t][v], reward_value(a, pen[t][v], tot.sum_pen, tot.max_pen, sig_term));
+          add_rewards<VEC>(a, need_pen, pen[t], tot.sum_pen, tot.max_pen, sig_term, rsum[t]);
         }
     }
     if (threadIdx.x == 0) {
@@ -1094,10 +1097,15 @@ __global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs r
         lock_m[v] = n.lock;
         pen[v] = n.pen;
         p += n.power;
-        ps += n.pen;
-        acc.max_pen = fmaxf(acc.max_pen, n.pen);
         const float d = n.Ta - hs[v].target;
         te = fmaf(d, d, te);
+      }
+      if (need_pen) {   // individual_L2 reduces the cluster power alone
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          ps += pen[v];
+          acc.max_pen = fmaxf(acc.max_pen, pen[v]);
+        }
       }
       acc.sum_p = (double)p;
       acc.sum_pen = (double)ps;
@@ -1107,8 +1115,7 @@ __global__ __launch_bounds__(256) void k_rollout_group(StepArgs a, RolloutArgs r
     sig_term = signal_term(a, tot.sum_p, er.sig_old);
     if (active) {
       if (want_rsum) {
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) rsum[v] = __fadd_rn(rsum[v], reward_value(a, pen[v], tot.sum_pen, tot.max_pen, sig_term));
+        add_rewards<VEC>(a, need_pen, pen, tot.sum_pen, tot.max_pen, sig_term, rsum);
       }
       if (lane == 0) {
         if (ro.power_trace) ro.power_trace[row] = tot.sum_p;

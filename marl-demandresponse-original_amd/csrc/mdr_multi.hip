@@ -282,10 +282,15 @@ __global__ __launch_bounds__(256) void k_rollout_packed(StepArgs a, RolloutArgs 
         lock_m[v] = n.lock;
         pen[v] = n.pen;
         p += n.power;
-        ps += n.pen;
-        acc.max_pen = fmaxf(acc.max_pen, n.pen);
         const float d = n.Ta - hs[v].target;
         te = fmaf(d, d, te);
+      }
+      if (need_pen) {   // individual_L2 reduces the cluster power alone
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          ps += pen[v];
+          acc.max_pen = fmaxf(acc.max_pen, pen[v]);
+        }
       }
       acc.sum_p = (double)p;
       acc.sum_pen = (double)ps;
@@ -295,8 +300,7 @@ __global__ __launch_bounds__(256) void k_rollout_packed(StepArgs a, RolloutArgs 
     sig_term = signal_term(a, tot.sum_p, sig_old);
     if (active) {
       if (want_rsum) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) rsum[v] = __fadd_rn(rsum[v], reward_value(a, pen[v], tot.sum_pen, tot.max_pen, sig_term));
+        add_rewards<4>(a, need_pen, pen, tot.sum_pen, tot.max_pen, sig_term, rsum);
       }
       if (m.lane == 0) {
         if (ro.power_trace) ro.power_trace[row] = tot.sum_p;

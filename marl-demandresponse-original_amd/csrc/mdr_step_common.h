@@ -23,6 +23,19 @@ __device__ __forceinline__ float reward_value(const StepArgs& a, float pen, doub
   return -__fmaf_rn(a.c_temp, temp_penalty(a, pen, sum_pen, max_pen), sig_term);
 }
 
+// The running reward sum of a multi-step kernel.  individual_L2 (the default mode; `common` false, wave-uniform) has its own arm: its
+// reward is -(c_temp pen + sig) - what reward_value() returns there, bit for bit - without forming the mixture and selecting it away.
+template <int VEC>
+__device__ __forceinline__ void add_rewards(const StepArgs& a, bool common, const float* pen, double sum_pen, float max_pen, float sig_term, float* rsum) {
+  if (!common) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) rsum[v] = __fadd_rn(rsum[v], -__fmaf_rn(a.c_temp, pen[v], sig_term));
+  } else {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) rsum[v] = __fadd_rn(rsum[v], reward_value(a, pen[v], sum_pen, max_pen, sig_term));
+  }
+}
+
 // signal part of the reward with the OLD signal (env 196, 234-251), fp64 per env
 __device__ __forceinline__ float signal_term(const StepArgs& a, double P, double S_old) {
   const double d = (P - S_old) * a.inv_n_total;
