@@ -163,9 +163,11 @@ def test_greedy_myopic_closed_loop_reproduces_the_reference():
         np.testing.assert_allclose(env.house_temp()[0].cpu().numpy(), a["Ta"][t], rtol=1e-5, atol=0)
 
 
-@pytest.mark.parametrize("E,N", [(300, 20), (64, 50), (16, 1024), (3, 2048), (5, 777)])
+@pytest.mark.parametrize("E,N", [(1001, 10), (501, 7), (333, 13), (300, 20), (77, 32), (3, 1), (64, 50), (41, 100), (23, 200), (9, 400), (16, 1024), (3, 2048),
+                                  (5, 777), (7, 1500)])
 def test_greedy_myopic_matches_the_oracle_on_batches(E, N):
-    """Every kernel form (64- and 256-thread workgroups, padded sorts) against the oracle's restatement on device-sampled episodes."""
+    """Every kernel form (8 / 4 / 2 small envs or one env per wavefront with 1 / 2 / 4 / 8 / 16 sorted positions per lane, the LDS workgroup form
+    above 1024 houses, padded sorts, a last workgroup with idle waves) against the rule restated on the device's own state."""
     import mdr_amd
     from oracle import mdr_oracle as mo
     cfg = _cfg(N)
