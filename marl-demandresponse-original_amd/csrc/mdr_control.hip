@@ -12,8 +12,8 @@
 // position c on sees total(s) = S(s) + (total_c - S(c)), so every lane tests its R positions at once and the first position that is
 // not taken ends the run; the run of refusals behind it is found the same way with the total held.  The pass alternates only
 // inside the last house power below the budget - a handful of runs, not N dependent fp64 additions.  The prefix form equals the
-// sequential sum bit for bit as long as the fp64 sums of the fp32 powers are exact (powers of one env within 2^18 of each other;
-// the same property k_env_max_power rests on).
+// sequential sum bit for bit as long as the fp64 sums of the fp32 powers are exact (exponent spread + 24 + log2(N) <= 53: physical
+// HVAC powers by a wide margin); the kernel checks that per env and walks an env that fails it house by house.
 // 1025-2048 houses: one workgroup per env (k_greedy_myopic: bitonic sort of (key, house) pairs in LDS, the pass by one lane).
 #include "mdr_device.h"
 #include "mdr_kernels.h"
@@ -106,13 +106,48 @@ __global__ __launch_bounds__(256) void k_greedy_wave(StepArgs a) {
     if (gl >= d) incl += up;
   }
   const double lane_off = incl - lane_sum;                                        // S(gl R)
+  // The prefix form equals the sequential total only while every partial sum is exact in fp64: the env's powers as multiples of the
+  // smallest one's last place must stay below 2^53 - exponent spread + 24 + log2(N) <= 53.  Otherwise (or with a negative power) the
+  // env takes the sequential pass below.
+  int ex_hi = 0, ex_lo = 255;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t u = __float_as_uint(pw[r]);
+    const int ex = (int)((u >> 23) & 0xFFu);
+    if ((u << 1) != 0u) {
+      ex_hi = max(ex_hi, (int)(u >> 31) != 0 ? 4096 : ex);
+      ex_lo = min(ex_lo, ex);
+    }
+  }
+#pragma unroll
+  for (int d = 1; d < G; d <<= 1) {
+    ex_hi = max(ex_hi, __shfl_xor(ex_hi, d));
+    ex_lo = min(ex_lo, __shfl_xor(ex_lo, d));
+  }
+  const bool exact = ex_hi - ex_lo <= 29 - (32 - __clz(max(a.N - 1, 1)));
   const double target = valid ? a.sig_old[e] : 0.0;                               // obs["reg_signal"]: the signal of the current time index
   const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull) << (lane & ~(G - 1));
   const int last = (lane & ~(G - 1)) + G - 1;                                      // the env's last lane
   uint32_t taken = 0;
   double total = 0.0, off = 0.0;                                                  // off = total_c - S(c)
   int c = 0;
-  bool active = n > 0;
+  bool active = n > 0 && exact;
+  if (__any(n > 0 && !exact)) {                                                   // the reference's pass as written, house by house
+    double tot = 0.0;
+    uint32_t tk = 0;
+    for (int q = 0; q < G && q * R < a.N; ++q) {
+      const int src = (lane & ~(G - 1)) + q;
+      const uint32_t lk = __shfl(locks, src);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const double p = (double)__shfl(pw[r], src);
+        const bool take = q * R + r < n && greedy_take(p, tot, target, (lk >> r) & 1u);
+        if (take) tot += p;
+        tk |= (uint32_t)(take && q == gl) << r;
+      }
+    }
+    if (!exact) taken = tk;
+  }
   for (int guard = 0; guard <= a.N; ++guard) {
     if (!__any(active)) break;
     // run of takes from c: the first position >= c that is refused given everything from c up to it was taken

@@ -198,6 +198,41 @@ def test_greedy_myopic_matches_the_oracle_on_batches(E, N):
         big.greedy_myopic_actions()
 
 
+@pytest.mark.parametrize("E,N", [(37, 10), (21, 50), (6, 300), (5, 1024)])
+def test_greedy_myopic_keeps_the_sequential_totals_when_prefix_sums_would_round(E, N):
+    """Powers spread over sixteen decades (and zeros) in every other env: fp64 prefix sums of those are not exact, so the kernel must
+    walk such an env house by house, as the reference's loop does; the envs in between keep the run-wise pass."""
+    import mdr_amd
+    env = mdr_amd.BatchedDemandResponseEnv(_cfg(N), nb_envs=E, device="cuda:0", seed=5, table_steps=16)
+    env.reset(episode=0)
+    rng = np.random.default_rng(N)
+    pw32 = env.t["P_max"].cpu().numpy().copy()
+    wild = (10.0 ** rng.uniform(-8, 8, size=(E, N))).astype(np.float32)
+    wild[rng.random((E, N)) < 0.1] = 0.0
+    pw32[::2] = wild[::2]
+    env.t["P_max"].copy_(torch.from_numpy(pw32).to(env.t["P_max"].device))
+    for t in range(4):
+        acts = env.greedy_myopic_actions().clone().cpu().numpy()
+        Ta, tg = env.t["Ta"].cpu().numpy(), env.t["target"].cpu().numpy()
+        lock = ((env.t["flags"].cpu().numpy() >> 1) & 1).astype(bool)
+        sig = env.reg_signal().cpu().numpy()
+        if t % 2:                          # budgets inside the wild sums as well
+            sig = sig * 0 + np.float64(pw32.astype(np.float64).sum(axis=1) * rng.uniform(0.0, 1.0, size=E))
+            tab = env.table("tab_signal")
+            tab[:] = torch.from_numpy(sig).to(tab.device)[None, :]
+            acts = env.greedy_myopic_actions().clone().cpu().numpy()
+        want = np.zeros((E, N), dtype=np.uint8)
+        for e in range(E):
+            total = 0.0
+            for h in np.argsort(-(Ta[e] - tg[e]), kind="stable"):
+                p = float(pw32[e, h])
+                if p + total < sig[e] or (abs(p + total - sig[e]) < abs(total - sig[e]) and not lock[e, h]):
+                    total += p
+                    want[e, h] = 1
+        assert np.array_equal(acts, want), t
+        env.step(torch.from_numpy((rng.random((E, N)) < 0.5).astype(np.uint8)).to(env.t["actions"].device))
+
+
 def test_deploy_controller_accumulates_what_the_stepwise_loop_does():
     """rollout.deploy_controller (main-deploy.py's loop under a rule-based agent): the fused rollout's accumulators for the in-kernel
     rules, a step loop for GreedyMyopic - against plain stepping with the sums kept on the side."""
