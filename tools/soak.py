@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Soak run: many simulated days of the C3 batch in closed loop; checks that the state stays finite and physical.
+"""Soak run: many simulated days of the C3 batch in closed loop; checks that the state stays finite and physical, and that the fused
+rollout (houses resident in registers) ends the same episode in the same bits as the step-by-step run.
 
     python tools/soak.py [steps]      (default 432,000 steps = 20 simulated days at 4 s)
 """
@@ -45,6 +46,22 @@ def main():
     el = time.perf_counter() - t0
     print(json.dumps({"total_steps": done, "house_steps": done * 4096 * 1024, "wall_s": round(el, 1),
                       "house_steps_per_s": done * 4096 * 1024 / el}))
+    # the same episode once more with the houses resident in registers (mdr_env_rollout_fused): must end in the same bits
+    twin = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=4096, device="cuda:0", seed=2024)
+    twin.reset(episode=0)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    done = 0
+    while done < steps:
+        n = min(43200, steps - done)
+        twin.rollout_fused(n, accumulate=False)
+        done += n
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t1
+    same = {name: bool(torch.equal(twin.t[name], env.t[name])) for name in ("Ta", "Tm", "sso", "flags", "reward", "P")}
+    print(json.dumps({"fused_rollout_total_steps": done, "wall_s": round(el, 1), "house_steps_per_s": done * 4096 * 1024 / el,
+                      "bit_identical_to_the_stepwise_run": same}))
+    assert all(same.values()), same
 
 
 if __name__ == "__main__":
