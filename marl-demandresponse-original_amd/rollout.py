@@ -130,11 +130,27 @@ def discounted_returns(reward: torch.Tensor, done: torch.Tensor, gamma: float,
     return out
 
 
+def others_actions(action: torch.Tensor, nb_envs: int, nb_houses: int) -> torch.Tensor:
+    """MAPPO's ``Transition.others_actions`` (train_mappo.py:79-84: the step's action dict without agent k, in agent order) for the
+    flat per-agent layout of ``collect_ppo_rollout``: ``action`` [T, E*N] -> [T, E*N, N-1] of the same dtype, entry j of agent i
+    being the action of agent j (j < i) or j + 1 (j >= i) of the same env - what agents/mappo.py:64,87 concatenates to the state as
+    the centralised critic's input.  One gather on the device; meant for the reference's cluster sizes (N - 1 values per agent-step)."""
+    T = action.shape[0]
+    E, N = int(nb_envs), int(nb_houses)
+    if action.shape[1] != E * N:
+        raise ValueError("action must be [T, nb_envs * nb_houses]")
+    i = torch.arange(N, device=action.device)[:, None]
+    j = torch.arange(N - 1, device=action.device)[None, :]
+    idx = j + (j >= i).to(j.dtype)                                   # [N, N-1]: the other agents of agent i, in agent order
+    return action.view(T, E, N)[:, :, idx].reshape(T, E * N, N - 1)
+
+
 @torch.no_grad()
 def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.99, critic: Optional[nn.Module] = None,
                         generator: Optional[torch.Generator] = None, store_states: bool = True,
                         fused: Optional[bool] = None, seed: int = 0, policy_precision: str = "fp32",
-                        observe_act: Optional[bool] = None, obs_planes: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+                        observe_act: Optional[bool] = None, obs_planes: Optional[bool] = None,
+                        with_others_actions: bool = False) -> Dict[str, torch.Tensor]:
     """Roll ``nb_steps`` with actions sampled from ``actor`` for every agent of every env.
 
     ``fused`` (default: whenever the actor has the reference's shape - two hidden layers of <= 127 units, two actions -
@@ -156,8 +172,12 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
     Returns tensors with the agents flattened as [T, E*N, ...] in the reference's per-agent order:
     ``state`` [T+1, E*N, F] (``state[t+1]`` is ``next_state[t]``; omitted if ``store_states`` is False), ``action`` int64,
     ``a_prob`` (probability of the taken action - the reference stores the probability, not its log: agents/ppo.py:75),
-    ``reward``, ``done`` (True on the last step: train_ppo.py:84) and ``return`` (discounted_returns)."""
+    ``reward``, ``done`` (True on the last step: train_ppo.py:84) and ``return`` (discounted_returns).
+    ``with_others_actions``: MAPPO's transitions (train_mappo.py:46, 79-86) - adds ``others_actions`` [T, E*N, N-1] (``others_actions()``);
+    the bootstrap through ``critic`` is PPO's (a critic over the state alone) and is refused together with it."""
     E, N = env.nb_envs, env.nb_houses
+    if with_others_actions and critic is not None:
+        raise ValueError("MAPPO's critic takes state + others_actions (agents/mappo.py:87); the reference does not bootstrap it either")
     F_len = env.obs_vector_length()
     dev = env.device
     T = int(nb_steps)
@@ -224,6 +244,8 @@ def collect_ppo_rollout(env, actor: nn.Module, nb_steps: int, gamma: float = 0.9
            "return": discounted_returns(reward, done, gamma, bootstrap)}
     if store_states:
         out["state"] = states
+    if with_others_actions:
+        out["others_actions"] = others_actions(action, E, N)
     return out
 
 

@@ -178,3 +178,31 @@ def test_dqn_transitions_follow_the_greedy_network_and_the_global_coin():
     mixed = collect_dqn_transitions(env, q, 8, epsilon=0.5, epsilon_decay=0.9, min_epsilon=0.1, seed=3)
     frac = float(mixed["explored"].float().mean())
     assert 0.2 < frac < 0.6 and abs(mixed["epsilon"] - 0.5 * 0.9 ** 8) < 1e-12
+
+
+def test_mappo_transitions_carry_the_other_agents_actions():
+    """train_mappo.py:79-86 for all envs at once: `others_actions` of agent k is the step's action dict without k, in agent order
+    (deepcopy(action); pop(k); list(values())) - the centralised critic's extra input (agents/mappo.py:64, 87)."""
+    from mdr_amd.rollout import ActorMLP, CriticMLP, collect_ppo_rollout
+    E, N, T = 5, 20, 4
+    env = _env(E, N)
+    torch.manual_seed(2)
+    actor = ActorMLP(env.obs_vector_length()).cuda()
+    ro = collect_ppo_rollout(env, actor, T, with_others_actions=True, seed=9)
+    oa = ro["others_actions"]
+    assert oa.shape == (T, E * N, N - 1) and oa.dtype == ro["action"].dtype
+    act = ro["action"].cpu().numpy().reshape(T, E, N)
+    got = oa.cpu().numpy().reshape(T, E, N, N - 1)
+    for t in range(T):
+        for e in range(E):
+            action = {k: int(act[t, e, k]) for k in range(N)}
+            for k in range(N):
+                action_k = dict(action)
+                action_k.pop(k)
+                assert got[t, e, k].tolist() == list(action_k.values())
+    # the critic of agents/mappo.py:87 takes state and others_actions side by side
+    critic = CriticMLP(env.obs_vector_length() + N - 1).cuda()
+    v = critic(torch.cat((ro["state"][0], oa[0].float()), dim=1))
+    assert v.shape == (E * N, 1)
+    with pytest.raises(ValueError):
+        collect_ppo_rollout(env, actor, 2, critic=critic, with_others_actions=True)
