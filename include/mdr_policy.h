@@ -29,10 +29,12 @@ extern "C" {
 enum mdr_actor_layout {
   MDR_ACTOR_FRAG32 = 0, /* v_mfma_f32_32x32x2_f32: 32 agents per wavefront, any num_state that fits the LDS */
   MDR_ACTOR_FRAG16 = 1, /* v_mfma_f32_16x16x4_f32: 16 agents per wavefront, hidden units padded to 112 instead of 128 rows and a
-                           quarter of the accumulator registers; num_state <= 64 */
+                           quarter of the accumulator registers; num_state <= 128 (16 feature registers per lane up to 64
+                           features, 32 beyond - observations with the optional message columns, utils.py:858-866) */
   MDR_ACTOR_BF16X3 = 2, /* v_mfma_f32_16x16x32_bf16 on operands split into bf16 head + tail (x = xh + xl): w x ~ wh xh + wl xh +
                            wh xl, fp32 accumulation - 16 significand bits per operand instead of 24 (probabilities within ~1e-5
-                           of the fp32 forward) at 16 / 3 times the fp32 matrix rate; num_state <= 64.  frag1 / frag2 hold bf16 */
+                           of the fp32 forward) at 16 / 3 times the fp32 matrix rate; num_state <= 128 (mdr_actor_sample; 64 through
+                           mdr_env_actor_sample).  frag1 / frag2 hold bf16 */
   MDR_ACTOR_FRAG16T = 3 /* MDR_ACTOR_FRAG16 for hidden layers of 97..100 units (the reference's [100, 100]): six 16-row blocks on
                            v_mfma_f32_16x16x4_f32 and the last 1..4 units of either layer on v_mfma_f32_4x4x1_16B_f32 (exact fp32,
                            a third of the time of the block it replaces): ~9 % fewer matrix cycles per agent */

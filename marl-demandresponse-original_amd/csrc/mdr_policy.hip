@@ -234,7 +234,9 @@ __device__ __forceinline__ f32x4 sum_lane_groups(f32x4 v) {
 
 __device__ __forceinline__ float pick_register(f32x4 v, int g) { return g == 0 ? v[0] : (g == 1 ? v[1] : (g == 2 ? v[2] : v[3])); }
 
-template <int MB, bool TAIL>
+// XS: feature registers per lane = the k-steps of layer 1 a form is compiled for - 16 (num_state <= 64) or 32 (<= 128: observations
+// with the optional message columns, utils.py:858-866 - 81 / 91 / 121 features with ten senders).
+template <int MB, bool TAIL, int XS = 16>
 __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* f1 = lds;                       // [S1][64][8]
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
   const f32x4* bias1 = reinterpret_cast<const f32x4*>(wd + 128) + g;   // [mb] at stride 4 vectors
   const f32x4* bias2 = reinterpret_cast<const f32x4*>(wd + 256) + g;
   const float bias3 = wd[384];
-  float xr[16];
+  float xr[XS];
   // Feature k of agent i sits `(i F + k) * 4` (rows) or `(k plane + i) * 4` (planes) bytes behind a.obs: 32-bit byte offsets from the
   // wave-uniform base (the launcher keeps the buffer below 4 GiB per launch), so a feature load is `global_load v, voffset, s[base]`
   // and what the tile loop keeps per feature is nothing - 64-bit per-feature addresses were 32 registers this kernel does not have.
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
   if (wave < a.ntiles) {
     const uint32_t x = row_of(wave);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) xr[s] = feature(x, s < a.S1 ? s : 0);
+    for (int s = 0; s < XS; ++s) xr[s] = feature(x, s < a.S1 ? s : 0);
   }
   // One Philox call serves four tiles: lane group g draws for the tile this wave reaches g iterations from now (the
   // counter is that tile's agent index, so the draw stays a function of (seed, step, agent) alone).
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
     for (int mb = 0; mb < MB; ++mb) acc[mb] = bias1[mb * 4];
     // ---- layer 1
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
+    for (int s = 0; s < XS; ++s) {
       if (s < a.S1) {
         const float4 w0 = *reinterpret_cast<const float4*>(f1 + s * 512 + lane * 8);
         const float4 w1 = *reinterpret_cast<const float4*>(f1 + s * 512 + lane * 8 + 4);
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
     for (int mb = 0; mb < MB; ++mb) out[mb] = bias2[mb * 4];
 #pragma unroll
     for (int q = 0; q < 4 * MB; ++q) {
-      if (q < 16 && q < a.S1 && more) xr[q < 16 ? q : 0] = feature(xn, q);
+      if (q < XS && q < a.S1 && more) xr[q < XS ? q : 0] = feature(xn, q);
       if (q < a.S2) {
         const float b = relu(TAIL && q >= 4 * (MB - 1) ? pick_register(acc[MB - 1], g) : acc[q >> 2][q & 3]);   // tail: k-index g is unit 96 + g
         const float4 w0 = *reinterpret_cast<const float4*>(f2 + q * 512 + lane * 8);
@@ -317,6 +319,9 @@ __global__ __launch_bounds__(64 * WAVES16) void k_actor_sample16(ActorArgs a) {
       }
     }
     if (TAIL) out[MB - 1] = sum_lane_groups(out[MB - 1]);
+#pragma unroll
+    for (int q = 4 * MB; q < XS; ++q)      // feature registers beyond layer 2's k-steps (XS = 32 with seven blocks)
+      if (q < a.S1 && more) xr[q] = feature(xn, q);
     // ---- head: this lane's 4 MB rows, then the other three lane groups'
     float d = 0.0f;
 #pragma unroll
@@ -385,7 +390,8 @@ constexpr int WAVESB = 8;    // 2 per SIMD: two column blocks of accumulators (~
 constexpr int NCB = 2;       // 16-agent column blocks per wavefront: every weight fragment read from LDS feeds NCB MFMAs (with one block
                              // the fragment reads, 84 KB per 16 agents, kept the LDS busier than the matrix pipe)
 
-template <int MB>
+// XF: feature registers per lane and column block = 8 per k-step of layer 1 - 16 (num_state <= 64) or 32 (<= 128).
+template <int MB, int XF = 16>
 __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int S2B = (MB + 1) / 2;
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) 
   const f32x4* bias1 = reinterpret_cast<const f32x4*>(wd + 128) + g;   // [mb] at stride 4 vectors
   const f32x4* bias2 = reinterpret_cast<const f32x4*>(wd + 256) + g;
   const float bias3 = wd[384];
-  float xr[NCB][16];                      // S1 <= 2 k-steps (F <= 64): 8 features per step and column block
+  float xr[NCB][XF];                      // S1 <= XF / 8 k-steps: 8 features per step and column block
   auto row_of = [&](int64_t t, int c) {   // a tile = NCB * 16 consecutive agents
     const int64_t agent = (t * NCB + c) * 16 + r;
     return a.obs + (agent < a.A ? agent : a.A - 1) * (a.plane ? 1 : (int64_t)a.F);
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) 
     for (int c = 0; c < NCB; ++c) {
       const float* x = row_of(wave, c);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) xr[c][i] = feature(x, i < 8 * a.S1 ? i : 0);
+      for (int i = 0; i < XF; ++i) xr[c][i] = feature(x, i < 8 * a.S1 ? i : 0);
     }
   }
   // One Philox call per agent serves four tiles: lane group g draws for the tile this wave reaches g iterations from now
@@ -447,7 +453,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) 
       for (int mb = 0; mb < MB; ++mb) acc[c][mb] = bias1[mb * 4];
     // ---- layer 1
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < XF / 8; ++s) {
       if (s < a.S1) {
         bf16x8 Bh[NCB], Bl[NCB];
 #pragma unroll
@@ -486,7 +492,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) 
 #pragma unroll
         for (int c = 0; c < NCB; ++c)
 #pragma unroll
-          for (int i = 4 * s; i < 4 * s + 4 && i < 16; ++i)
+          for (int i = (XF / 4) * s; i < (XF / 4) * (s + 1) && i < XF; ++i)
             if (i < 8 * a.S1) xr[c][i] = feature(xn[c], i);
       }
       bf16x8 Bh[NCB], Bl[NCB];
@@ -512,11 +518,11 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) 
         }
       }
     }
-    if (more && S2B * 4 < 16) {
+    if (more && S2B * (XF / 4) < XF) {
 #pragma unroll
       for (int c = 0; c < NCB; ++c)
 #pragma unroll
-        for (int i = S2B * 4; i < 16; ++i)
+        for (int i = S2B * (XF / 4); i < XF; ++i)
           if (i < 8 * a.S1) xr[c][i] = feature(xn[c], i);
     }
     // ---- head: this lane's 4 MB rows, then the other three lane groups'
@@ -1006,12 +1012,18 @@ struct TileCursor {
 };
 
 // ---- bf16x3 form: 32 agents per wavefront (two 16-agent column blocks), k-step s of layer 1 = row floats [32 s + 8 g, + 8)
+// The forward reads 64 floats from the start of EVERY row whatever the row stride (against zero weights past the features), so the
+// last row of a window reaches 64 - ROW floats past the rows: the pad behind them covers that.  With the fixed 16 floats a stride
+// below 48 (F <= 42: six neighbours or fewer) let the last wave's last row read past the workgroup's LDS - whatever bits a previous
+// kernel left there, and a NaN or infinity among them times a zero weight is a NaN logit for that one agent (seen once as a
+// with / without rows_out mismatch in tests/test_gpu_observe_act.py).
+__host__ __device__ constexpr int observe_bf16_pad(int row) { return 64 - row > OBS_PAD ? 64 - row : OBS_PAD; }
 template <int MB, bool STORE, bool GEN, bool EXT = false, bool TABLE = false>   // TABLE (GEN && EXT): senders gathered through a link table
 __global__ __launch_bounds__(64 * WAVESB) void k_actor_observe_bf16(ActorArgs a, mdr::ObserveArgs o) {
   const int NW = EXT ? (int)(blockDim.x >> 6) : WAVESB;   // waves per workgroup: the extended form takes as many as its windows leave room for (6 .. 8; two per SIMD either way)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int S2B = (MB + 1) / 2, TILE = 16 * NCB;
-  const int ROW = EXT ? o.row : OBS_ROW, WIN = TILE * ROW + OBS_PAD;
+  const int ROW = EXT ? o.row : OBS_ROW, WIN = TILE * ROW + observe_bf16_pad(ROW);
   const int F = EXT ? o.own + 4 * o.c : 51;
   // the packed fragments hold 8 row blocks per k-step; the extended form keeps only the MB it uses in LDS (MB = 7: 12 KB less, which
   // is what lets eight 68-float windows fit beside them)
@@ -1510,7 +1522,7 @@ int launch_actor_observe(const mdr_actor_t* actor, const ObserveArgs& o, uint64_
   a.greedy = actor->greedy != 0;
   ObserveArgs oo = o;
   oo.row = row;
-  const size_t window = (size_t)tile * row + OBS_PAD;
+  const size_t window = (size_t)tile * row + (lbf ? observe_bf16_pad(row) : OBS_PAD);
   auto lds_need = [&](int w) {
     const int s1_lds = ext ? (lbf ? 2 : extk) : a.S1;   // the extended form stages layer 1 zero-padded to its full k-step count
     size_t per_step = (size_t)floats_per_step(layout);
@@ -1610,7 +1622,7 @@ int mdr_actor_sample(const mdr_actor_t* actor, const float* obs, int64_t obs_pla
   const bool lbf = layout == MDR_ACTOR_BF16X3;
   const bool l16 = layout == MDR_ACTOR_FRAG16 || layout == MDR_ACTOR_FRAG16T || lbf;             // 16 agents per wavefront
   if (layout == MDR_ACTOR_FRAG16T && !tail_shape_ok(actor)) return MDR_ERR_UNSUPPORTED;
-  if (l16 && actor->num_state > 64) return MDR_ERR_UNSUPPORTED;   // 16 features per lane: pack FRAG32 instead
+  if (l16 && actor->num_state > 128) return MDR_ERR_UNSUPPORTED;   // 32 feature registers per lane (and column block): pack FRAG32 instead
   ActorArgs a{};
   a.frag1 = static_cast<const float*>(actor->frag1); a.frag2 = static_cast<const float*>(actor->frag2); a.wdiff = actor->wdiff;
   a.obs = obs; a.action = action; a.a_prob = a_prob; a.probs = probs;
@@ -1636,7 +1648,10 @@ int mdr_actor_sample(const mdr_actor_t* actor, const float* obs, int64_t obs_pla
     return hipGetLastError() == hipSuccess ? MDR_OK : MDR_ERR_HIP;
   };
   const int mb = blocks16(actor->hidden1, actor->hidden2);
-  if (lbf) return mb == 7 ? launch(k_actor_sample_bf16<7>) : launch(k_actor_sample_bf16<8>);
+  if (lbf) {
+    if (a.S1 <= 2) return mb == 7 ? launch(k_actor_sample_bf16<7>) : launch(k_actor_sample_bf16<8>);
+    return mb == 7 ? launch(k_actor_sample_bf16<7, 32>) : launch(k_actor_sample_bf16<8, 32>);   // 65..128 features
+  }
   if (l16) {
     // k_actor_sample16 addresses its features by 32-bit byte offsets from `obs`: a launch covers at most 4 GiB of observations
     // (20 million agents at F = 51); a bigger batch goes out in slices of whole tiles
@@ -1653,8 +1668,13 @@ int mdr_actor_sample(const mdr_actor_t* actor, const float* obs, int64_t obs_pla
       a.A = count;
       a.agent0 = first;
       a.ntiles = (count + tile - 1) / tile;
-      const int rc = layout == MDR_ACTOR_FRAG16T ? launch(k_actor_sample16<7, true>)
-                                                  : (mb == 7 ? launch(k_actor_sample16<7, false>) : launch(k_actor_sample16<8, false>));
+      int rc;
+      if (a.S1 <= 16)
+        rc = layout == MDR_ACTOR_FRAG16T ? launch(k_actor_sample16<7, true>)
+                                         : (mb == 7 ? launch(k_actor_sample16<7, false>) : launch(k_actor_sample16<8, false>));
+      else      // 65..128 features: the same kernel with 32 feature registers per lane
+        rc = layout == MDR_ACTOR_FRAG16T ? launch(k_actor_sample16<7, true, 32>)
+                                         : (mb == 7 ? launch(k_actor_sample16<7, false, 32>) : launch(k_actor_sample16<8, false, 32>));
       if (rc != MDR_OK) return rc;
     }
     return MDR_OK;

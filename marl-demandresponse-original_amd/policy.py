@@ -48,9 +48,10 @@ class FusedActor:
         """w1 [H1, F], b1 [H1], w2 [H2, H1], b2 [H2], w3 [2, H2], b3 [2] (torch.nn.Linear layout).
         ``feature_order=FEATURES_OBSERVE`` packs W1's columns in the order ``sample_env`` stages the default observation in
         (observe -> act without observation rows: ``mdr_env_actor_sample``); such an actor serves ``sample_env`` only.
-        ``layout``: FRAG16 (v_mfma_f32_16x16x4_f32, exact fp32, the default whenever F <= 63), FRAG32
+        ``layout``: FRAG16 (v_mfma_f32_16x16x4_f32, exact fp32, the default whenever F <= 128 - 16 feature registers per lane up to
+        64 features, 32 beyond: the observations with the optional message columns, 81 / 91 / 121 features), FRAG32
         (v_mfma_f32_32x32x2_f32, exact fp32, any F) or BF16X3 (bf16 MFMA on head + tail halves of every operand:
-        probabilities within ~1e-5 of the fp32 forward, several times faster; F <= 63)."""
+        probabilities within ~1e-5 of the fp32 forward, several times faster; F <= 128 on observation rows, F <= 64 for observe -> act)."""
         self._lib = nat.load()
         w1, b1, w2, b2, w3, b3 = (torch.as_tensor(t, dtype=torch.float32).detach().cpu() for t in (w1, b1, w2, b2, w3, b3))
         self.feature_order = int(feature_order)
@@ -66,7 +67,7 @@ class FusedActor:
         if H1 > MAX_HIDDEN or H2 > MAX_HIDDEN:
             raise ValueError("hidden layers of at most %d units" % MAX_HIDDEN)
         if layout is None:      # exact fp32; hidden layers of 97..100 units (the reference's [100, 100]) take the 4x4-tail form
-            layout = (FRAG16T if self._tail_shape(H1, H2) else FRAG16) if F <= 64 else FRAG32
+            layout = (FRAG16T if self._tail_shape(H1, H2) else FRAG16) if F <= 128 else FRAG32
         if layout == FRAG16T and not self._tail_shape(H1, H2):
             raise ValueError("FRAG16T needs hidden layers of 97..100 units")
         self.layout = int(layout)

@@ -80,7 +80,7 @@ def _fused_policy(actor, dev, precision: str = "fp32", observe: bool = False, ms
     slot = "_mdr_fused_observe" if observe else "_mdr_fused"
     cached = getattr(actor, slot, None)
     if cached is None or cached[0] != key:
-        layout = BF16X3 if precision == "bf16x3" and actor.fc[0].in_features <= 64 else None      # None: the exact-fp32 form that fits
+        layout = BF16X3 if precision == "bf16x3" and actor.fc[0].in_features <= 128 else None      # None: the exact-fp32 form that fits
         cached = (key, FusedActor.from_module(actor, device=dev, layout=layout,
                                               feature_order=FEATURES_OBSERVE if observe else FEATURES_NORMSTATE, observe_msg_floats=msg_floats))
         setattr(actor, slot, cached)
@@ -266,7 +266,7 @@ def collect_dqn_transitions(env, q_net: nn.Module, nb_steps: int, epsilon: float
     F_len = env.obs_vector_length()
     T = int(nb_steps)
     layout = None
-    if policy_precision == "bf16x3" and q_net.fc[0].in_features <= 64:
+    if policy_precision == "bf16x3" and q_net.fc[0].in_features <= 128:
         from .policy import BF16X3
         layout = BF16X3
     greedy = FusedActor.from_module(q_net, device=dev, layout=layout, greedy=True)

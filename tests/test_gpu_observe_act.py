@@ -83,6 +83,21 @@ def test_observe_act_equals_rows_then_actor(E, N, layout, layers):
         _walk(env, 7, seed=k)
 
 
+_POISON = {}
+
+
+def _poison_lds():
+    """Leave NaN in ~150 KB of every CU's LDS (the weight fragments of an all-NaN actor): whatever a kernel launched next reads from LDS
+    without having written it shows up as a NaN or a flushed logit instead of passing by luck."""
+    from mdr_amd.policy import FusedActor
+    if not _POISON:
+        nan = float("nan")
+        _POISON["actor"] = FusedActor(torch.full((100, 180), nan), torch.full((100,), nan), torch.full((100, 100), nan),
+                                      torch.full((100,), nan), torch.full((2, 100), nan), torch.full((2,), nan), layout=0)
+        _POISON["junk"] = torch.zeros((256 * 256 * 2, 180), device="cuda:0")
+    _POISON["actor"].sample(_POISON["junk"], seed=0, step=0)
+
+
 _STATE_FLAGS = ("hour", "day", "solar_gain", "thermal", "hvac")
 
 
@@ -134,8 +149,10 @@ def test_observe_act_extended_shapes(E, N, flags, nb_comm, defects, layout):
             assert abs(float(dead) - defects) < 0.05 + 2.0 / (E * N * nb_comm) ** 0.5      # the defects really are in the rows
         a0, p0, probs0 = by_rows.sample(rows, seed=9, step=k, want_probs=True)
         kept = torch.full((E * N, F), float("nan"), device="cuda:0")
+        _poison_lds()
         a1, p1, probs1 = by_state.sample_env(env, seed=9, step=k, want_probs=True, rows_out=kept)
         assert torch.equal(kept, rows), "rows_out differs from obs_vector('rows')"
+        _poison_lds()
         a2, p2, probs2 = by_state.sample_env(env, seed=9, step=k, want_probs=True)
         assert torch.equal(a2, a1) and torch.equal(probs2, probs1)
         with torch.no_grad():
@@ -187,8 +204,10 @@ def test_observe_act_link_tables(E, N, mode, nb_comm, flags, defects, layout):
         rows = env.obs_vector("rows").view(E * N, F)
         a0, p0, probs0 = by_rows.sample(rows, seed=9, step=k, want_probs=True)
         kept = torch.full((E * N, F), float("nan"), device="cuda:0")
+        _poison_lds()
         a1, p1, probs1 = by_state.sample_env(env, seed=9, step=k, want_probs=True, rows_out=kept)
         assert torch.equal(kept, rows), "rows_out differs from obs_vector('rows')"
+        _poison_lds()
         a2, p2, probs2 = by_state.sample_env(env, seed=9, step=k, want_probs=True)
         assert torch.equal(a2, a1) and torch.equal(probs2, probs1)
         with torch.no_grad():
@@ -360,3 +379,29 @@ def test_fuzz_observe_act_vs_rows(idx):
         assert torch.equal(kept, rows), "case %d (E=%d N=%d layout %d): rows differ" % (idx, E, N, layout)
         torch.testing.assert_close(probs1, probs0, rtol=2e-3 if layout == 2 else 1e-5, atol=2e-5 if layout == 2 else 2e-6)
         assert int((a0 != a1).sum()) <= max(2, E * N // 20000)
+
+
+@pytest.mark.parametrize("N,nb_comm", [(20, 6), (64, 6), (20, 2), (50, 0), (96, 4)])
+def test_bf16_extended_rows_never_read_past_their_window(N, nb_comm):
+    """The bf16x3 forward reads 64 floats per row whatever the row stride; with strides below 48 floats (F <= 42) the last row of
+    the last wave's window used to reach past the workgroup's LDS, where a NaN left by an earlier kernel times a zero weight made a
+    NaN logit.  Poison: an actor with NaN weights whose fragments fill 150 KB of every CU's LDS; then every probability of the
+    small-row shapes must still be finite and equal with and without rows_out."""
+    import mdr_amd
+    from mdr_amd.policy import FEATURES_OBSERVE, FusedActor
+    from mdr_amd.rollout import ActorMLP
+    env = mdr_amd.BatchedDemandResponseEnv(_shape_cfg(N, ("solar_gain",), nb_comm, 0.0), nb_envs=100, device="cuda:0", seed=N)
+    env.reset(episode=0)
+    F = env.obs_vector_length()
+    torch.manual_seed(N)
+    actor = ActorMLP(F, 2, (100, 100)).to("cuda:0")
+    by_state = FusedActor.from_module(actor, layout=2, feature_order=FEATURES_OBSERVE, observe_msg_floats=4 * nb_comm)
+    for k in range(3):
+        _poison_lds()                                                # every CU's LDS now holds NaN up to ~150 KB
+        a1, _, probs1 = by_state.sample_env(env, seed=3, step=k, want_probs=True)
+        _poison_lds()
+        kept = torch.empty((100 * N, F), device="cuda:0")
+        a2, _, probs2 = by_state.sample_env(env, seed=3, step=k, want_probs=True, rows_out=kept)
+        assert bool(torch.isfinite(probs1).all()) and bool(torch.isfinite(probs2).all())
+        assert torch.equal(a1, a2) and torch.equal(probs1, probs2)
+        _walk(env, 5, seed=k)

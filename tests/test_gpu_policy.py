@@ -24,7 +24,8 @@ def _actor(F, layers, seed=0, scale=1.0):
 @pytest.mark.parametrize("A,F,layers", [(1, 51, (100, 100)), (31, 51, (100, 100)), (33, 51, (100, 100)), (1000, 51, (100, 100)),
                                         (4097, 47, (100, 100)), (777, 133, (100, 100)), (500, 11, (64, 32)), (300, 51, (127, 127)),
                                         (300, 50, (1, 1)), (300000, 51, (100, 100)), (1000, 51, (97, 100)), (999, 33, (100, 98)),
-                                        (50, 64, (99, 97))])
+                                        (50, 64, (99, 97)), (1000, 65, (100, 100)), (777, 81, (100, 100)), (4097, 91, (100, 100)),
+                                        (3000, 121, (100, 100)), (513, 128, (127, 113)), (200, 97, (64, 100))])
 @pytest.mark.parametrize("layout", [0, 1, 2, 3])
 def test_fused_actor_matches_torch_forward(A, F, layers, layout):
     from mdr_amd.policy import FusedActor
@@ -32,7 +33,7 @@ def test_fused_actor_matches_torch_forward(A, F, layers, layout):
         with pytest.raises(ValueError):
             FusedActor.from_module(_actor(min(F, 64), layers), layout=3)
         return
-    if layout >= 1 and F > 64:
+    if layout >= 1 and F > 128:      # the 16-agent forms hold at most 32 feature registers per lane
         with pytest.raises(RuntimeError):
             FusedActor.from_module(_actor(F, layers), layout=1).sample(torch.zeros((4, F), device="cuda:0"), 0, 0)
         return
@@ -126,7 +127,7 @@ def test_fused_actor_argument_checks():
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2, 3])
-@pytest.mark.parametrize("A,F", [(1000, 51), (4097, 47), (33, 11)])
+@pytest.mark.parametrize("A,F", [(1000, 51), (4097, 47), (33, 11), (2050, 91)])
 def test_feature_plane_input_gives_the_same_bits_as_rows(A, F, layout):
     """obs as feature planes [F][stride] (what mdr_env_obs_vector MDR_OBS_PLANES writes) instead of rows [A][F]."""
     from mdr_amd.policy import FusedActor
@@ -174,7 +175,8 @@ def test_fuzz_random_network_shapes(idx):
     from mdr_amd.policy import FusedActor
     rng = np.random.default_rng(100 + idx)
     layout = idx % 4
-    F = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 47, 50, 51, 52, 62, 63, 64] + ([65, 100, 133] if layout == 0 else [])))
+    F = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 47, 50, 51, 52, 62, 63, 64] + ([65, 100, 133] if layout == 0 else [])
+                       + ([65, 66, 79, 80, 81, 91, 95, 96, 97, 100, 121, 127, 128] if layout >= 1 else [])))
     H1 = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 95, 96, 97, 100, 111, 112, 113, 126, 127]))
     H2 = int(rng.choice([1, 3, 16, 17, 32, 48, 64, 99, 100, 111, 112, 113, 127]))
     if layout == 3:
