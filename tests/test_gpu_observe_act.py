@@ -83,20 +83,7 @@ def test_observe_act_equals_rows_then_actor(E, N, layout, layers):
         _walk(env, 7, seed=k)
 
 
-_POISON = {}
-
-
-def _poison_lds():
-    """Leave NaN in ~150 KB of every CU's LDS (the weight fragments of an all-NaN actor): whatever a kernel launched next reads from LDS
-    without having written it shows up as a NaN or a flushed logit instead of passing by luck."""
-    from mdr_amd.policy import FusedActor
-    if not _POISON:
-        nan = float("nan")
-        _POISON["actor"] = FusedActor(torch.full((100, 180), nan), torch.full((100,), nan), torch.full((100, 100), nan),
-                                      torch.full((100,), nan), torch.full((2, 100), nan), torch.full((2,), nan), layout=0)
-        _POISON["junk"] = torch.zeros((256 * 256 * 2, 180), device="cuda:0")
-    _POISON["actor"].sample(_POISON["junk"], seed=0, step=0)
-
+from tests.conftest import poison_lds as _poison_lds  # noqa: E402
 
 _STATE_FLAGS = ("hour", "day", "solar_gain", "thermal", "hvac")
 
