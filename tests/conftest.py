@@ -44,4 +44,10 @@ def _lds_poisoned_before_every_gpu_test(request):
         import torch
         if torch.cuda.is_available():
             poison_lds()
+            if os.environ.get("MDR_TEST_POISON_HBM", "1") != "0":
+                # ... and on recycled device memory full of NaN: torch.empty() hands out blocks of the caching allocator, so a buffer
+                # this library reads before anything wrote it holds NaN (0xFF bytes: -1 / 255 as integers) instead of old zeros
+                junk = torch.full((192 * 1024 * 1024,), float("nan"), device="cuda:0")
+                junk.view(torch.int32).fill_(-1)
+                del junk
     yield
