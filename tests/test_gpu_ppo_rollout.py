@@ -206,3 +206,33 @@ def test_mappo_transitions_carry_the_other_agents_actions():
     assert v.shape == (E * N, 1)
     with pytest.raises(ValueError):
         collect_ppo_rollout(env, actor, 2, critic=critic, with_others_actions=True)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_wide_observations_go_to_the_policy_as_planes_with_the_same_result(precision):
+    """Message columns on (config.py message_properties: F = 121): without kept states the rollout hands the policy kernel feature
+    planes instead of rows - same actions, probabilities and rewards as the rows path (store_states=True takes rows)."""
+    import mdr_amd
+    from mdr_amd.rollout import ActorMLP, CriticMLP, collect_ppo_rollout
+    cfg = mdr_amd.default_config()
+    cfg["default_env_prop"]["cluster_prop"]["nb_agents"] = 20
+    cfg["default_env_prop"]["power_grid_prop"]["base_power_mode"] = "constant"
+    cfg["default_env_prop"]["message_properties"]["thermal"] = True
+    cfg["default_env_prop"]["message_properties"]["hvac"] = True
+    out = []
+    torch.manual_seed(4)
+    actor, critic = None, None
+    for keep in (True, False):
+        env = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=37, device="cuda:0", seed=8)
+        env.reset(episode=0)
+        F = env.obs_vector_length()
+        assert F == 11 + 10 * 11
+        if actor is None:
+            actor, critic = ActorMLP(F).cuda(), CriticMLP(F).cuda()
+        out.append(collect_ppo_rollout(env, actor, 6, critic=critic, store_states=keep, seed=5, policy_precision=precision))
+    kept, lean = out
+    assert torch.equal(kept["action"], lean["action"]) and torch.equal(kept["a_prob"], lean["a_prob"])
+    assert torch.equal(kept["reward"], lean["reward"]) and torch.equal(kept["return"], lean["return"])
+    with torch.no_grad():
+        p = actor(kept["state"][2]).gather(1, kept["action"][2][:, None]).squeeze(1)
+    torch.testing.assert_close(kept["a_prob"][2], p, rtol=2e-3 if precision == "bf16x3" else 1e-5, atol=2e-5)
