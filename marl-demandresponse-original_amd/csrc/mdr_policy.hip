@@ -390,7 +390,9 @@ constexpr int WAVESB = 8;    // 2 per SIMD: two column blocks of accumulators (~
 constexpr int NCB = 2;       // 16-agent column blocks per wavefront: every weight fragment read from LDS feeds NCB MFMAs (with one block
                              // the fragment reads, 84 KB per 16 agents, kept the LDS busier than the matrix pipe)
 
-// XF: feature registers per lane and column block = 8 per k-step of layer 1 - 16 (num_state <= 64) or 32 (<= 128).
+// XF: features per lane and column block = 8 per k-step of layer 1 - 16 (num_state <= 64) or 32 (<= 128).  Both forms hold 16 feature
+// registers per column block: the 32-feature form converts its first two k-steps to bf16 fragments, re-uses the registers for the
+// loads of the tile's other 16 features and runs the first two k-steps' matrix instructions while those are in flight.
 template <int MB, int XF = 16>
 __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) 
   const f32x4* bias1 = reinterpret_cast<const f32x4*>(wd + 128) + g;   // [mb] at stride 4 vectors
   const f32x4* bias2 = reinterpret_cast<const f32x4*>(wd + 256) + g;
   const float bias3 = wd[384];
-  float xr[NCB][XF];                      // S1 <= XF / 8 k-steps: 8 features per step and column block
+  float xr[NCB][16];                      // two k-steps at a time: 8 features per step and column block
   auto row_of = [&](int64_t t, int c) {   // a tile = NCB * 16 consecutive agents
     const int64_t agent = (t * NCB + c) * 16 + r;
     return a.obs + (agent < a.A ? agent : a.A - 1) * (a.plane ? 1 : (int64_t)a.F);
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) 
     for (int c = 0; c < NCB; ++c) {
       const float* x = row_of(wave, c);
 #pragma unroll
-      for (int i = 0; i < XF; ++i) xr[c][i] = feature(x, i < 8 * a.S1 ? i : 0);
+      for (int i = 0; i < 16; ++i) xr[c][i] = feature(x, i < 8 * a.S1 ? i : 0);
     }
   }
   // One Philox call per agent serves four tiles: lane group g draws for the tile this wave reaches g iterations from now
@@ -452,27 +454,55 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) 
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) acc[c][mb] = bias1[mb * 4];
     // ---- layer 1
+    auto mma1 = [&](int s, const bf16x8* Bh, const bf16x8* Bl) {
 #pragma unroll
-    for (int s = 0; s < XF / 8; ++s) {
-      if (s < a.S1) {
-        bf16x8 Bh[NCB], Bl[NCB];
+      for (int mb = 0; mb < MB; ++mb) {
+        const bf16x8 Ah = __builtin_bit_cast(bf16x8, f1[((s * 8 + mb) * 2 + 0) * 64 + lane]);
+        const bf16x8 Al = __builtin_bit_cast(bf16x8, f1[((s * 8 + mb) * 2 + 1) * 64 + lane]);
 #pragma unroll
         for (int c = 0; c < NCB; ++c) {
-          uint4 bh, bl;
-          split8(xr[c] + 8 * s, bh, bl);
-          Bh[c] = __builtin_bit_cast(bf16x8, bh);
-          Bl[c] = __builtin_bit_cast(bf16x8, bl);
+          acc[c][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh[c], acc[c][mb], 0, 0, 0);
+          acc[c][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh[c], acc[c][mb], 0, 0, 0);
+          acc[c][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl[c], acc[c][mb], 0, 0, 0);
         }
+      }
+    };
+    auto split_step = [&](int s, bf16x8* Bh, bf16x8* Bl) {   // k-step s of the registers' pair of k-steps
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-          const bf16x8 Ah = __builtin_bit_cast(bf16x8, f1[((s * 8 + mb) * 2 + 0) * 64 + lane]);
-          const bf16x8 Al = __builtin_bit_cast(bf16x8, f1[((s * 8 + mb) * 2 + 1) * 64 + lane]);
+      for (int c = 0; c < NCB; ++c) {
+        uint4 bh, bl;
+        split8(xr[c] + 8 * s, bh, bl);
+        Bh[c] = __builtin_bit_cast(bf16x8, bh);
+        Bl[c] = __builtin_bit_cast(bf16x8, bl);
+      }
+    };
+    if (XF == 16) {
 #pragma unroll
-          for (int c = 0; c < NCB; ++c) {
-            acc[c][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh[c], acc[c][mb], 0, 0, 0);
-            acc[c][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh[c], acc[c][mb], 0, 0, 0);
-            acc[c][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl[c], acc[c][mb], 0, 0, 0);
-          }
+      for (int s = 0; s < 2; ++s) {
+        if (s < a.S1) {
+          bf16x8 Bh[NCB], Bl[NCB];
+          split_step(s, Bh, Bl);
+          mma1(s, Bh, Bl);
+        }
+      }
+    } else {   // a.S1 = 3 | 4
+      bf16x8 Bh0[NCB], Bl0[NCB], Bh1[NCB], Bl1[NCB];
+      split_step(0, Bh0, Bl0);
+      split_step(1, Bh1, Bl1);
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) {      // the registers are free: this tile's features 64 .. 127
+        const float* x = row_of(t, c);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xr[c][i] = feature(x, 16 + i < 8 * a.S1 ? 16 + i : 16);
+      }
+      mma1(0, Bh0, Bl0);
+      mma1(1, Bh1, Bl1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (2 + s < a.S1) {
+          bf16x8 Bh[NCB], Bl[NCB];
+          split_step(s, Bh, Bl);
+          mma1(2 + s, Bh, Bl);
         }
       }
     }
@@ -492,7 +522,7 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) 
 #pragma unroll
         for (int c = 0; c < NCB; ++c)
 #pragma unroll
-          for (int i = (XF / 4) * s; i < (XF / 4) * (s + 1) && i < XF; ++i)
+          for (int i = 4 * s; i < 4 * s + 4 && i < 16; ++i)
             if (i < 8 * a.S1) xr[c][i] = feature(xn[c], i);
       }
       bf16x8 Bh[NCB], Bl[NCB];
@@ -518,11 +548,11 @@ __global__ __launch_bounds__(64 * WAVESB) void k_actor_sample_bf16(ActorArgs a) 
         }
       }
     }
-    if (more && S2B * (XF / 4) < XF) {
+    if (more && S2B * 4 < 16) {
 #pragma unroll
       for (int c = 0; c < NCB; ++c)
 #pragma unroll
-        for (int i = S2B * (XF / 4); i < XF; ++i)
+        for (int i = S2B * 4; i < 16; ++i)
           if (i < 8 * a.S1) xr[c][i] = feature(xn[c], i);
     }
     // ---- head: this lane's 4 MB rows, then the other three lane groups'
