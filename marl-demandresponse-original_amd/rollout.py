@@ -70,18 +70,18 @@ def _discounted_returns_hip(reward, done, gamma, bootstrap):
     return out
 
 
-def _fused_policy(actor, dev, precision: str = "fp32", observe: bool = False, msg_floats: int = 40):
+def _fused_policy(actor, dev, precision: str = "fp32", observe: bool = False, msg_floats: int = 40, greedy: bool = False):
     """FusedActor of `actor`, re-packed only when a parameter changed (torch bumps `_version` on in-place updates).
     ``observe``: packed for ``FusedActor.sample_env`` (W1's columns in the order the observe -> act kernels stage the features)."""
     from .policy import BF16X3, FEATURES_NORMSTATE, FEATURES_OBSERVE, FusedActor
     if precision not in ("fp32", "bf16x3"):
         raise ValueError("policy_precision must be 'fp32' or 'bf16x3'")
-    key = tuple((p.data_ptr(), p._version) for p in actor.parameters()) + (str(dev), precision, msg_floats if observe else 0)
+    key = tuple((p.data_ptr(), p._version) for p in actor.parameters()) + (str(dev), precision, msg_floats if observe else 0, bool(greedy))
     slot = "_mdr_fused_observe" if observe else "_mdr_fused"
     cached = getattr(actor, slot, None)
     if cached is None or cached[0] != key:
         layout = BF16X3 if precision == "bf16x3" and actor.fc[0].in_features <= 128 else None      # None: the exact-fp32 form that fits
-        cached = (key, FusedActor.from_module(actor, device=dev, layout=layout,
+        cached = (key, FusedActor.from_module(actor, device=dev, layout=layout, greedy=greedy,
                                               feature_order=FEATURES_OBSERVE if observe else FEATURES_NORMSTATE, observe_msg_floats=msg_floats))
         setattr(actor, slot, cached)
     return cached[1]
@@ -328,18 +328,31 @@ def deploy_controller(env, kind: str, nb_steps: int) -> Dict[str, torch.Tensor]:
     return out
 
 
-def deploy_policy(env, policy, nb_steps: int, seed: int = 0, use_graph: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+def deploy_policy(env, policy, nb_steps: int, seed: int = 0, use_graph: Optional[bool] = None, policy_precision: str = "fp32",
+                  greedy: bool = False) -> Dict[str, torch.Tensor]:
     """The evaluation loop of main-deploy.py:99-152 with a learned agent (PPOAgent / DQNAgent, agents/rl_controllers.py) for all
-    envs at once: every step observation -> ``policy`` (a ``FusedActor``; ``greedy=True`` for a DQN network) -> ``env.step``,
-    with the metrics the script accumulates: ``reward_sum`` [E, N], ``sq_temp_error_sum`` [E] (sum over steps and houses of
-    (house_temp - target)^2), ``sq_signal_error_sum`` [E] (sum over steps of (reg_signal - cluster_hvac_power)^2).
+    envs at once: every step observation -> ``policy`` -> ``env.step``, with the metrics the script accumulates: ``reward_sum``
+    [E, N], ``sq_temp_error_sum`` [E] (sum over steps and houses of (house_temp - target)^2), ``sq_signal_error_sum`` [E] (sum over
+    steps of (reg_signal - cluster_hvac_power)^2).
+
+    ``policy``: the network itself (``ActorMLP`` / the reference's ``Actor``; ``greedy=True`` for a ``DQN_network``: argmax) - packed
+    here, and observation and policy are then ONE kernel wherever ``collect_ppo_rollout`` would make them one (no observation rows at
+    all) - or a ready ``FusedActor``: one packed with ``feature_order=FEATURES_OBSERVE`` takes the same one-kernel path, any other
+    gets observation rows.
 
     ``use_graph`` (default: when the env was built with ``graph_mode=True``): the step is captured once in a
     ``torch.cuda.CUDAGraph`` and replayed - the launch-bound regime of small batches."""
+    from .policy import FEATURES_OBSERVE
     E, N = env.nb_envs, env.nb_houses
     dev = env.device
     F_len = env.obs_vector_length()
-    obs = torch.empty((E, N, F_len), dtype=torch.float32, device=dev)
+    if isinstance(policy, nn.Module):
+        if not _fusable(policy):
+            raise ValueError("deploy_policy takes Linear(F,H1) - Linear(H1,H2) - Linear(H2,2) networks on the device (or a FusedActor)")
+        policy = _fused_policy(policy, dev, policy_precision, observe=_observe_act_supported(env, policy),
+                               msg_floats=4 * _observe_senders(env), greedy=greedy)
+    observe_act = getattr(policy, "feature_order", 0) == FEATURES_OBSERVE
+    obs = None if observe_act else torch.empty((E, N, F_len), dtype=torch.float32, device=dev)
     act = torch.empty(E * N, dtype=torch.uint8, device=dev)
     out = {"reward_sum": torch.zeros((E, N), dtype=torch.float32, device=dev),
            "sq_temp_error_sum": torch.zeros(E, dtype=torch.float64, device=dev),
@@ -353,8 +366,11 @@ def deploy_policy(env, policy, nb_steps: int, seed: int = 0, use_graph: Optional
     step_dev = env.device_time_index if graph_mode else None
 
     def one_step(t):
-        env.obs_vector("rows", out=obs)
-        policy.sample(obs.view(E * N, F_len), seed, step0 + t, action=act, step_dev=step_dev)
+        if observe_act:      # normStateDict + act for all agents in one kernel: no observation rows
+            policy.sample_env(env, seed, step0 + t, action=act, step_dev=step_dev)
+        else:
+            env.obs_vector("rows", out=obs)
+            policy.sample(obs.view(E * N, F_len), seed, step0 + t, action=act, step_dev=step_dev)
         _, r, _, info = env.step(act.view(E, N))
         out["reward_sum"] += r
         d = (env.t["Ta"] - env.t["target"]).double()

@@ -178,6 +178,37 @@ def test_deploy_policy_graph_equals_eager(greedy):
     assert float(res[0]["sq_temp_error_sum"].min()) > 0
 
 
+@pytest.mark.parametrize("greedy,precision", [(False, "fp32"), (True, "fp32"), (False, "bf16x3")])
+def test_deploy_policy_takes_the_network_and_observes_and_acts_in_one_kernel(greedy, precision):
+    """deploy_policy(env, actor_module): packed in observe order, observation and policy are one kernel (no rows) - eager, captured
+    and non-graph envs agree bit for bit, and the loop stays statistically on the rows path's (same Philox draws; probabilities
+    agree to ~1e-6, so single actions may flip where a draw falls between the two)."""
+    import mdr_amd
+    from mdr_amd.policy import FusedActor
+    from mdr_amd.rollout import ActorMLP, deploy_policy
+    E, N, T = 8, 50, 40
+    cfg = _cfg(N)
+    torch.manual_seed(2)
+    envs = [mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=E, device="cuda:0", seed=6, table_steps=16, graph_mode=gm)
+            for gm in (True, True, False, False)]
+    for e in envs:
+        e.reset(episode=0)
+    actor = ActorMLP(envs[0].obs_vector_length()).cuda()
+    res = [deploy_policy(envs[0], actor, T, seed=4, use_graph=True, greedy=greedy, policy_precision=precision),
+           deploy_policy(envs[1], actor, T, seed=4, use_graph=False, greedy=greedy, policy_precision=precision),
+           deploy_policy(envs[2], actor, T, seed=4, greedy=greedy, policy_precision=precision)]
+    assert getattr(actor, "_mdr_fused_observe", None) is not None          # the one-kernel form was taken
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]) and torch.equal(res[0][k], res[2][k]), k
+    for k in ("Ta", "sso", "reward"):
+        assert torch.equal(envs[0].t[k], envs[1].t[k]) and torch.equal(envs[0].t[k], envs[2].t[k]), k
+    layout = 2 if precision == "bf16x3" else None
+    by_rows = deploy_policy(envs[3], FusedActor.from_module(actor, greedy=greedy, layout=layout), T, seed=4)
+    flips = int((envs[3].t["flags"] != envs[2].t["flags"]).sum())
+    assert flips <= E * N // 20
+    torch.testing.assert_close(by_rows["sq_temp_error_sum"], res[2]["sq_temp_error_sum"], rtol=2e-2, atol=0)
+
+
 def test_reg_signal_in_graph_mode_follows_resets_and_steps():
     import mdr_amd
     cfg = _cfg(20)
