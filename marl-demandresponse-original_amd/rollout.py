@@ -277,7 +277,12 @@ def collect_dqn_transitions(env, q_net: nn.Module, nb_steps: int, epsilon: float
     if policy_precision == "bf16x3" and q_net.fc[0].in_features <= 128:
         from .policy import BF16X3
         layout = BF16X3
-    greedy = FusedActor.from_module(q_net, device=dev, layout=layout, greedy=True)
+    # observation, Q-network and argmax in ONE kernel wherever the rollout collection has that form; the rows land in `state` on the side
+    one_kernel = _fusable(q_net) and _observe_act_supported(env, q_net)
+    if one_kernel:
+        greedy = _fused_policy(q_net, dev, policy_precision, observe=True, msg_floats=4 * _observe_senders(env), greedy=True)
+    else:
+        greedy = FusedActor.from_module(q_net, device=dev, layout=layout, greedy=True)
     state = torch.empty((T + 1, E * N, F_len), dtype=torch.float32, device=dev)
     action = torch.empty((T, E * N), dtype=torch.int64, device=dev)
     reward = torch.empty((T, E * N), dtype=torch.float32, device=dev)
@@ -286,9 +291,13 @@ def collect_dqn_transitions(env, q_net: nn.Module, nb_steps: int, epsilon: float
     gen = torch.Generator(device=dev)
     gen.manual_seed(int(seed))
     eps = float(epsilon)
-    env.obs_vector("rows", out=state[0].view(E, N, F_len))
+    if not one_kernel:
+        env.obs_vector("rows", out=state[0].view(E, N, F_len))
     for t in range(T):
-        greedy.sample(state[t], seed, env.steps_taken, action=act)
+        if one_kernel:
+            greedy.sample_env(env, seed, env.steps_taken, action=act, rows_out=state[t])
+        else:
+            greedy.sample(state[t], seed, env.steps_taken, action=act)
         coin = torch.rand(E, device=dev, generator=gen) < eps
         random_act = torch.randint(0, 2, (E, N), device=dev, generator=gen, dtype=torch.uint8)
         chosen = torch.where(coin[:, None], random_act, act.view(E, N))
@@ -296,7 +305,8 @@ def collect_dqn_transitions(env, q_net: nn.Module, nb_steps: int, epsilon: float
         action[t] = chosen.view(-1).to(torch.int64)
         reward[t] = r.view(-1)
         explored[t] = coin
-        env.obs_vector("rows", out=state[t + 1].view(E, N, F_len))
+        if not one_kernel or t == T - 1:
+            env.obs_vector("rows", out=state[t + 1].view(E, N, F_len))
         eps = max(eps * float(epsilon_decay), float(min_epsilon))
     return {"state": state, "action": action, "reward": reward, "explored": explored, "epsilon": eps}
 

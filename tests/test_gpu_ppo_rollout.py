@@ -236,3 +236,38 @@ def test_wide_observations_go_to_the_policy_as_planes_with_the_same_result(preci
     with torch.no_grad():
         p = actor(kept["state"][2]).gather(1, kept["action"][2][:, None]).squeeze(1)
     torch.testing.assert_close(kept["a_prob"][2], p, rtol=2e-3 if precision == "bf16x3" else 1e-5, atol=2e-5)
+
+
+def test_dqn_transitions_one_kernel_form_stores_the_rows_of_the_rows_form():
+    """With the default observation the DQN loop observes, evaluates and takes the argmax in one kernel and the rows reach `state`
+    on the side: with epsilon 0 and the same seeds, states / actions / rewards equal those of an env with message columns OFF forced
+    through observation rows (sharded envs and wide observations take that form) wherever no Q-value pair is a near tie."""
+    import mdr_amd
+    from mdr_amd import rollout as ro
+    cfg = mdr_amd.default_config()
+    cfg["default_env_prop"]["cluster_prop"]["nb_agents"] = 20
+    cfg["default_env_prop"]["power_grid_prop"]["base_power_mode"] = "constant"
+    torch.manual_seed(3)
+    q = None
+    outs = []
+    for force_rows in (False, True):
+        env = mdr_amd.BatchedDemandResponseEnv(cfg, nb_envs=33, device="cuda:0", seed=4)
+        env.reset(episode=0)
+        if q is None:
+            q = ro.ActorMLP(env.obs_vector_length()).to("cuda:0")
+        keep = ro._observe_act_supported
+        if force_rows:
+            ro._observe_act_supported = lambda e, a: False
+        try:
+            outs.append(ro.collect_dqn_transitions(env, q, 1, epsilon=0.0, seed=1))
+        finally:
+            ro._observe_act_supported = keep
+    one, rows = outs
+    assert getattr(q, "_mdr_fused_observe", None) is not None
+    assert torch.equal(one["state"][0], rows["state"][0])                  # the rows written on the side ARE obs_vector's rows
+    with torch.no_grad():
+        x = q.fc[2](torch.relu(q.fc[1](torch.relu(q.fc[0](one["state"][0])))))
+    clear = (x[:, 0] - x[:, 1]).abs() > 1e-5
+    assert torch.equal(one["action"][0][clear], rows["action"][0][clear]) and float(clear.float().mean()) > 0.99
+    if bool((one["action"][0] == rows["action"][0]).all()):
+        assert torch.equal(one["state"][1], rows["state"][1]) and torch.equal(one["reward"], rows["reward"])
